@@ -1,0 +1,209 @@
+/*
+ * llmc_hip.h — C ABI of libllmc_hip.so: the MI355X (gfx950) implementation of llmc's per-Linear
+ * weight-quantization hot path (GPTQ / AWQ / RTN quantizer arithmetic, packing).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the library never allocates or frees device memory: callers pass outputs and a workspace whose
+ *     size comes from the matching `*_ws_bytes` query;
+ *   - every entry point takes the hipStream_t to launch on (as void*) and never synchronises the device;
+ *   - return value: 0 ok; LLMC_EINVAL bad shape/dtype/alignment; LLMC_ENOTSUP unsupported combination;
+ *     LLMC_EIO a HIP runtime error (text via llmc_hip_last_error). No C++ exception crosses the ABI;
+ *   - dtype codes: LLMC_F16 / LLMC_BF16 / LLMC_F32. "Tensor dtype" arithmetic follows ATen's rule the
+ *     reference relies on: every elementwise op is evaluated in fp32 and rounded (RNE) to the op's
+ *     result dtype, no FMA contraction, IEEE division.
+ *
+ * Each entry cites the reference code (paths relative to the llmc tree) it replaces.
+ */
+#ifndef LLMC_HIP_H_
+#define LLMC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLMC_HIP_ABI_VERSION 1
+
+#define LLMC_OK 0
+#define LLMC_EINVAL (-22)
+#define LLMC_ENOTSUP (-95)
+#define LLMC_EIO (-5)
+
+#define LLMC_F16 0
+#define LLMC_BF16 1
+#define LLMC_F32 2
+
+/* integer code container for llmc_quant_static / llmc_quant_dynamic */
+#define LLMC_OUT_FAKE 0 /* dequantised values, written in the weight dtype              */
+#define LLMC_OUT_I32 1  /* int32 codes   (reference: bit != 8  -> torch.int32)          */
+#define LLMC_OUT_I8 2   /* int8 codes    (reference: bit == 8, qmin != 0 -> torch.int8) */
+#define LLMC_OUT_U8 3   /* uint8 codes   (reference: bit == 8, qmin == 0 -> torch.uint8)*/
+
+typedef void* llmc_stream_t; /* hipStream_t */
+
+int llmc_hip_abi_version(void);
+/* copies the last HIP error string of the calling thread into buf (NUL-terminated); returns its length */
+int llmc_hip_last_error(char* buf_host, size_t n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Quantizer arithmetic (llmc/compression/quantization/quant.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* get_minmax_range + get_qparams (quant.py:132-143, 545-559) on a [G, g] view (reshape_tensor,
+ * quant.py:612-642: per_group -> g = group_size, per_channel -> g = in_features, per_tensor -> G = 1).
+ * scales / zeros: [G] in the tensor dtype `dt`. zeros may be NULL when sym (reference returns 0).
+ * round_zp = 1 is the reference default; 0 gives zeros = qmin - min/scale. */
+size_t llmc_minmax_qparams_ws_bytes(int64_t G, int64_t g);
+int llmc_minmax_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, int round_zp,
+                        float qmin, float qmax, void* scales, void* zeros, void* ws,
+                        llmc_stream_t stream);
+
+/* IntegerQuantizer.quant / quant_dequant with given qparams (quant.py:699-717), i.e. the arithmetic of
+ * fake_quant_weight_static (quant.py:785-831) and real_quant_weight_static (quant.py:871-914).
+ * W: [G, g] dtype wdt. scales [G] dtype sdt. zeros [G] dtype zdt, or NULL (== 0, the symmetric case).
+ * out_kind LLMC_OUT_FAKE writes (q - z) * s cast to wdt; the others write integer codes.
+ * Promotion follows torch: x/s in promote(wdt,sdt); +z in promote(.,zdt); rounding after each op. */
+int llmc_quant_static(const void* W, int wdt, int64_t G, int64_t g, const void* scales, int sdt,
+                      const void* zeros, int zdt, float qmin, float qmax, int out_kind, void* out,
+                      llmc_stream_t stream);
+
+/* fake_quant_weight_dynamic (quant.py:833-869) / real_quant_weight_dynamic (quant.py:916-953):
+ * min/max -> qparams -> quant(-> dequant) in one pass over W. scales_out / zeros_out may be NULL
+ * (fake path does not keep them); when given they are [G] in dtype dt. */
+size_t llmc_quant_dynamic_ws_bytes(int64_t G, int64_t g);
+int llmc_quant_dynamic(const void* W, int dt, int64_t G, int64_t g, int sym, int round_zp, float qmin,
+                       float qmax, int out_kind, void* out, void* scales_out, void* zeros_out, void* ws,
+                       llmc_stream_t stream);
+
+/* VllmRealQuantLinear.pack (module_utils.py:836-862): codes [R, K] (int32 or int8 container) ->
+ * packed int32 [R, ceil(K / (32/bits))]; u = (code + 2^(bits-1)) & 0xff, LSB-first nibbles/bytes,
+ * zero padding on the right. code_kind is LLMC_OUT_I32 or LLMC_OUT_I8. */
+int llmc_pack_lsb(const void* codes, int code_kind, int64_t R, int64_t K, int bits, int32_t* packed,
+                  llmc_stream_t stream);
+
+/* AutoawqRealQuantLinear.gemm_pack (module_utils.py:1004-1065): recompute codes
+ * round((w + z*s) / s) in fp16 from weight [R, K] (f16), scales/zeros [R, K/g] as returned by
+ * real_quant_weight_* (scales any float dtype -> cast to f16, zeros int32), transpose to [K, R] and
+ * pack 8 nibbles per int32 along R with AWQ's order map [0,2,4,6,1,3,5,7].
+ * qweight [K, R/8] int32, qzeros [K/g, R/8] int32, scales_out [K/g, R] f16. */
+int llmc_pack_awq_gemm(const void* weight, int wdt, const void* scales, int sdt, const int32_t* zeros,
+                       int64_t R, int64_t K, int64_t g, int32_t* qweight, int32_t* qzeros,
+                       void* scales_out_f16, llmc_stream_t stream);
+
+/* FloatQuantizer e4m3 weight path with use_qtorch semantics pinned to torch's float8_e4m3fn cast
+ * (quant.py:1043-1072, 1195-1221): scale = absmax.clamp(1e-5) / 448 per row of the [G, g] view
+ * (G = 1 per-tensor, G = R per-channel), q = RNE_e4m3(x / scale). out_fp8 [G, g] bytes (OCP e4m3fn),
+ * scales [G] in dtype dt. fake != 0 writes dequantised q * scale in dt to out instead of fp8 bytes. */
+size_t llmc_fp8_quant_ws_bytes(int64_t G, int64_t g);
+int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* out, void* scales,
+                   void* ws, llmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GPTQ (llmc/compression/quantization/gptq.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* GPTQ.add_batch (gptq.py:254-295):  H <- H * (n_before / n_after) + (2 / n_after) * X^T X
+ * X: [T, K] tokens x channels (row stride ldx elements), 16-bit dtype dt (F16 / BF16); H: [K, K] fp32,
+ * full symmetric on output. n_before / n_after are the reference's `nsamples` before and after the call
+ * (counts of sequences, not tokens). Products are exact (16-bit x 16-bit in fp32), accumulation is fp32
+ * on the MFMA pipe in a fixed, launch-independent order (deterministic). */
+size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K);
+int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, int64_t K, int64_t ldx,
+                       double n_before, double n_after, void* ws, llmc_stream_t stream);
+
+/* GPTQ.process_hessian_and_weights, first half (gptq.py:135-152, 169-171):
+ *   dead = diag(H) == 0 -> H[dead,dead] = 1, W[:,dead] = 0; optional symmetric gather by perm
+ *   (Hout = H[perm][:,perm], Wout = W[:,perm]); damp = percdamp * mean(diag) ; Hout += damp * I.
+ * W [R, K] dtype wdt (model dtype or f32) -> Wout [R, K] fp32. perm may be NULL (identity).
+ * H is modified in place only for the dead-column fix; Hout must not alias H when perm != NULL. */
+size_t llmc_hessian_prep_ws_bytes(int64_t K);
+int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
+                      float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream);
+
+/* gptq.py:172-174: cholesky -> cholesky_inverse -> cholesky(upper). Computes the same upper factor U
+ * (H^-1 = U^T U) by one reverse Cholesky H = R R^T (R upper) and one triangular inverse U = R^-1, in
+ * fp32. A [K, K] is overwritten by U (strict lower triangle zeroed). info_dev: int32, 0 on success,
+ * i+1 if the leading minor i is not positive definite. */
+size_t llmc_chol_inv_upper_ws_bytes(int64_t K);
+int llmc_chol_inv_upper(float* A, int64_t K, void* ws, int32_t* info_dev, llmc_stream_t stream);
+
+/* GPTQ.weight_transform (gptq.py:199-244), the blocked column loop, with the quantizer of
+ * search_column_qparams (gptq.py:359-366) fused at group starts.
+ *   W      [R, K] fp32, (already permuted / dead-fixed), overwritten with the running updated weights
+ *   Hinv   [K, K] fp32 upper factor U
+ *   Wout   [R, K] fp32 = `tmp`: the error-compensated weight of each column at the time it was visited
+ *   losses [R, K] fp32 = `Losses` (may be NULL)
+ *   group_size: 0 = per_channel (one qparam pair per row, given in scales/zeros), else group size
+ *   static_groups = 0: qparams re-derived from the current W at each group start and written to
+ *     scales/zeros [R, K/group_size] (fp32) in processing (permuted) order;
+ *   static_groups = 1: scales/zeros [R, K/group_size] are INPUT in original column order and
+ *     col_group[i] (int32 [K], = perm[i]/group_size) selects the group of processed column i.
+ *   sym: zeros ignored on input when static and sym (zero == 0).
+ * blocksize must be 128 (the reference default in every shipped GPTQ config). */
+size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K);
+int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
+                       float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
+                       float* scales, float* zeros, float* Wout, float* losses, int blocksize,
+                       void* ws, llmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AWQ (llmc/compression/quantization/awq.py, auto_clip.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Awq.get_act_scale (awq.py:74-85): mean over tokens of |x| per channel. X [N, K] dt -> out [K] dt
+ * (fp32 accumulation, one rounding to dt at the end, as ATen's mean does). */
+size_t llmc_awq_act_mean_ws_bytes(int64_t N, int64_t K);
+int llmc_awq_act_mean(const void* X, int dt, int64_t N, int64_t K, void* out, void* ws,
+                      llmc_stream_t stream);
+
+/* Awq.get_weight_scale (awq.py:48-72) for one layer: mean over rows of |W| / rowgroup-max(|W|).
+ * W [R, K] dt, groups of g along K (g = K for per-channel). acc [K] fp32 accumulates the per-layer means
+ * rounded to dt exactly as total_scale.add_ does (first != 0 overwrites). */
+int llmc_awq_weight_mean(const void* W, int dt, int64_t R, int64_t K, int64_t g, void* out_dt,
+                         llmc_stream_t stream);
+
+/* Awq.get_scales (awq.py:88-108): v2: s = x_mean^ratio clamp(1e-4); v1: x^r / w^(1-r) clamp(1e-4);
+ * then s /= sqrt(max(s) * min(s)). x_mean / w_mean / out: [K] dt. w_mean may be NULL for v2. */
+int llmc_awq_scales(const void* x_mean, const void* w_mean, int dt, int64_t K, float ratio, int version,
+                    void* out, llmc_stream_t stream);
+
+/* fake_quantize_weight + scaling_weight (awq.py:40-46,147-164): out = fakequant_dyn(W * s[None,:]) in dt. */
+int llmc_awq_scale_fakequant(const void* W, const void* s, int dt, int64_t R, int64_t K, int64_t g,
+                             int sym, float qmin, float qmax, void* out, llmc_stream_t stream);
+
+/* scaling_input (base_blockwise_quantization.py:877-889): out = X / s[None,:] in dt. */
+int llmc_div_cols(const void* X, const void* s, int dt, int64_t N, int64_t K, void* out,
+                  llmc_stream_t stream);
+/* apply_scale helpers (base_blockwise_quantization.py:597-611,750-778): W *= s[None,:] ; v /= s. */
+int llmc_mul_cols(void* W, const void* s, int dt, int64_t R, int64_t K, llmc_stream_t stream);
+
+/* The fake-quant W4A16 matmul of Awq.search_scale_subset (awq.py:110-145, 229-236):
+ *   Y = X [N, K] . Wq [R, K]^T  (16-bit in, fp32 accumulate on MFMA, rounded to dt like F.linear)
+ * mode 0: store Y to Yout [N, R] (dt)                       -- get_original_out
+ * mode 1: loss += sum((Y0 - Y)^2), diff formed in dt like the reference, squared and summed in fp32;
+ *         *loss_sum (device fp32, caller zeroes) ; mean = loss_sum / (N*R) is taken by the caller. */
+size_t llmc_linear_eval_ws_bytes(int64_t N, int64_t K, int64_t R);
+int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N, int64_t K, int64_t R, int mode,
+                     void* Yout, const void* Y0, float* loss_sum, void* ws, llmc_stream_t stream);
+
+/* AutoClipper.auto_clip_layer (auto_clip.py:84-191), clip_version v1, w_only:
+ *   W [R, K] dt; X [n_tok, K] dt (already token-subsampled); groups of g along K.
+ *   for i_s in 0 .. n_shrink-1: max = org_max * (1 - i_s / n_grid), min = -max (clip_sym) or
+ *   org_min * (1 - i_s/n_grid); q_w = fakequant_dyn(clamp(w, min, max));
+ *   err = mean_tok((sum_g x*q_w - sum_g x*w)^2); keep argmin.  Outputs best_max / best_min [R, K/g] dt. */
+size_t llmc_awq_clip_search_ws_bytes(int64_t R, int64_t K, int64_t g, int64_t n_tok);
+int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g,
+                         int64_t n_tok, int n_grid, int n_shrink, int clip_sym, int sym, float qmin,
+                         float qmax, void* best_max, void* best_min, void* ws, llmc_stream_t stream);
+
+/* apply_clip v1 (auto_clip.py:194-212): W = clamp(W, min, max) per (row, group). */
+int llmc_clamp_groups(void* W, int dt, int64_t R, int64_t K, int64_t g, const void* min_val,
+                      const void* max_val, llmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLMC_HIP_H_ */

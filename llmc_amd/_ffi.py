@@ -1,0 +1,104 @@
+"""ctypes binding of libllmc_hip.so (include/llmc_hip.h). Thin: raw device pointers + stream in,
+status code out. The library is required: every failure to load or run raises (no fallback)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libllmc_hip.so')
+
+F16, BF16, F32 = 0, 1, 2
+OUT_FAKE, OUT_I32, OUT_I8, OUT_U8 = 0, 1, 2, 3
+
+_DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
+
+_i64, _i32, _f32, _f64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes). Must list every symbol include/llmc_hip.h declares
+# (tests/test_abi.py parses the header and checks both directions).
+SIGNATURES = {
+    'llmc_hip_abi_version': (_i32, []),
+    'llmc_hip_last_error': (_i32, [C.c_char_p, _sz]),
+    'llmc_minmax_qparams_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_minmax_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    'llmc_quant_static': (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _i32, _f32, _f32, _i32, _vp, _vp]),
+    'llmc_quant_dynamic_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_quant_dynamic': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'llmc_pack_lsb': (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class LlmcHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the library. Raises if it is missing — build with `python -m llmc_amd.build`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LlmcHipError(
+                f'{LIB_PATH} not found: the HIP extension is required (run `python -m llmc_amd.build`). '
+                'llmc_amd has no CPU fallback.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        ver = handle.llmc_hip_abi_version()
+        if ver != 1:
+            raise LlmcHipError(f'libllmc_hip.so ABI version {ver} != 1')
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().llmc_hip_last_error(buf, 512)
+    return buf.value.decode(errors='replace')
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == -22:
+        raise ValueError(f'{what}: invalid argument: {msg}')
+    if rc == -95:
+        raise NotImplementedError(f'{what}: unsupported: {msg}')
+    raise LlmcHipError(f'{what}: HIP error: {msg}')
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise ValueError(f'unsupported dtype {t.dtype if isinstance(t, torch.Tensor) else t}')
+
+
+def require_gpu(*tensors):
+    """The product path runs on the GPU only; refuse anything else loudly."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise LlmcHipError(
+                'llmc_amd operators run on MI355X only (tensor is on '
+                f'{t.device}); there is no CPU fallback. Use oracle/ for CPU checks in tests.')
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes, device):
+    if nbytes <= 0:
+        return None
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -1,0 +1,76 @@
+"""Build libllmc_hip.so (gfx950) in-tree with hipcc. No torch C++ extension, no hipify.
+
+`python -m llmc_amd.build` or `llmc_amd.build.build()`; `__graft_entry__.build()` calls this.
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(CSRC, 'libllmc_hip.so')
+OBJ = os.path.join(CSRC, 'build')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# -ffp-contract=off: the quantizer chains must round after every op like ATen does (no fused mul-add).
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _digest(path, deps):
+    h = hashlib.sha256()
+    for p in [path] + deps:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src, verbose):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src[:-4] + '.o')
+    stamp = obj + '.sha'
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
+    deps.append(os.path.join(HERE, '..', 'include', 'llmc_hip.h'))
+    dg = _digest(path, deps)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ['-c', path, '-o', obj]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+    with open(stamp, 'w') as f:
+        f.write(dg)
+    return obj, True
+
+
+def build(verbose=False, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, verbose), srcs))
+    objs = [o for o, _ in res]
+    changed = any(c for _, c in res) or not os.path.exists(OUT)
+    if changed:
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(verbose=True, force='--force' in sys.argv))

@@ -1,0 +1,142 @@
+// common.h — shared device/host helpers for libllmc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "../../include/llmc_hip.h"
+
+namespace llmc {
+
+// ---- error plumbing (no exception crosses the ABI) -------------------------------------------
+void set_last_error(const char* where, hipError_t e);
+void set_last_error_msg(const char* msg);
+
+#define LLMC_HIP_CHECK(expr)                                   \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) {                                \
+            ::llmc::set_last_error(#expr, _e);                 \
+            return LLMC_EIO;                                   \
+        }                                                      \
+    } while (0)
+
+#define LLMC_LAUNCH_CHECK()                                    \
+    do {                                                       \
+        hipError_t _e = hipGetLastError();                     \
+        if (_e != hipSuccess) {                                \
+            ::llmc::set_last_error("kernel launch", _e);       \
+            return LLMC_EIO;                                   \
+        }                                                      \
+    } while (0)
+
+#define LLMC_REQUIRE(cond, msg)                                \
+    do {                                                       \
+        if (!(cond)) {                                         \
+            ::llmc::set_last_error_msg(msg);                   \
+            return LLMC_EINVAL;                                \
+        }                                                      \
+    } while (0)
+
+static inline int dtype_size(int dt) { return dt == LLMC_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dt) { return dt == LLMC_F16 || dt == LLMC_BF16 || dt == LLMC_F32; }
+
+// ---- storage types ------------------------------------------------------------------------------
+struct f16_t { uint16_t u; };
+struct bf16_t { uint16_t u; };
+
+template <typename T> struct dt_of;
+template <> struct dt_of<f16_t> { static constexpr int value = LLMC_F16; };
+template <> struct dt_of<bf16_t> { static constexpr int value = LLMC_BF16; };
+template <> struct dt_of<float> { static constexpr int value = LLMC_F32; };
+
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t u) {
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float v) {
+    _Float16 h = (_Float16)v;  // RNE
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t u) {
+    return __uint_as_float(((uint32_t)u) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float v) {
+    uint32_t x = __float_as_uint(v);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x0040u);  // quiet NaN
+    uint32_t lsb = (x >> 16) & 1u;
+    x += 0x7fffu + lsb;  // RNE
+    return (uint16_t)(x >> 16);
+}
+
+// round an fp32 value to storage dtype `dt` and come back to fp32 (ATen "opmath" semantics)
+__device__ __forceinline__ float rnd(float v, int dt) {
+    if (dt == LLMC_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
+    if (dt == LLMC_BF16) return bf16_bits_to_f32(f32_to_bf16_bits(v));
+    return v;
+}
+template <int DT> __device__ __forceinline__ float rndc(float v) {
+    if constexpr (DT == LLMC_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
+    else if constexpr (DT == LLMC_BF16) return bf16_bits_to_f32(f32_to_bf16_bits(v));
+    else return v;
+}
+
+__device__ __forceinline__ float load_as_f32(const void* p, int64_t i, int dt) {
+    if (dt == LLMC_F16) return f16_bits_to_f32(((const uint16_t*)p)[i]);
+    if (dt == LLMC_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+    return ((const float*)p)[i];
+}
+__device__ __forceinline__ void store_from_f32(void* p, int64_t i, int dt, float v) {
+    if (dt == LLMC_F16) ((uint16_t*)p)[i] = f32_to_f16_bits(v);
+    else if (dt == LLMC_BF16) ((uint16_t*)p)[i] = f32_to_bf16_bits(v);
+    else ((float*)p)[i] = v;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return f16_bits_to_f32(v.u); }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_bits_to_f32(v.u); }
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f16_t{f32_to_f16_bits(v)}; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return bf16_t{f32_to_bf16_bits(v)}; }
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+
+// torch promotion among the three float dtypes (f16 + bf16 -> f32)
+__host__ __device__ __forceinline__ int promote(int a, int b) {
+    if (a == b) return a;
+    return LLMC_F32;
+}
+
+// 16-byte vector of T
+template <typename T> struct vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+// wave64 helpers
+__device__ __forceinline__ float wave_max(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int pow2_ceil(int64_t x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+}  // namespace llmc

@@ -1,0 +1,499 @@
+// quant_kernels.hip — HBM-bound quantizer kernels (K5/K6/K7 of SURVEY.md §2.3):
+//   min/max -> scale/zero, round/clamp (fake + real), LSB-first int packing.
+// Layout: W is a contiguous [G, g] view (one quantization group per row). A wave64 is cut into
+// 64/LPR sub-groups of LPR lanes, one row per sub-group, 16 B per lane per load (coalesced: a sub-group
+// reads LPR*16 contiguous bytes). Rows are distributed over a grid-stride of waves.
+#include "common.h"
+#include "quant_math.h"
+
+namespace llmc {
+
+static constexpr int kBlock = 256;
+static constexpr int kMaxGrid = 256 * 8;
+
+template <typename T, int VEC> struct RowVec {
+    T v[VEC];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ RowVec<T, VEC> load_vec(const T* p) {
+    RowVec<T, VEC> r;
+    if constexpr (VEC * sizeof(T) == 16) {
+        uint4 raw = *reinterpret_cast<const uint4*>(p);
+        __builtin_memcpy(&r, &raw, 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r.v[i] = p[i];
+    }
+    return r;
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* p, const RowVec<T, VEC>& r) {
+    if constexpr (VEC * sizeof(T) == 16) {
+        uint4 raw;
+        __builtin_memcpy(&raw, &r, 16);
+        *reinterpret_cast<uint4*>(p) = raw;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p[i] = r.v[i];
+    }
+}
+
+template <int KIND> struct code_t;
+template <> struct code_t<LLMC_OUT_I32> { using type = int32_t; };
+template <> struct code_t<LLMC_OUT_I8> { using type = int8_t; };
+template <> struct code_t<LLMC_OUT_U8> { using type = uint8_t; };
+
+// --------------------------------------------------------------------------------------------
+// row scan: min/max of one row by LPR lanes
+// --------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__device__ __forceinline__ void row_minmax(const T* row, int g, int sl, int lpr, float& mn, float& mx,
+                                           RowVec<T, VEC>& first, bool& have_first) {
+    mn = INFINITY;
+    mx = -INFINITY;
+    have_first = false;
+    for (int c = sl * VEC; c < g; c += lpr * VEC) {
+        RowVec<T, VEC> v = load_vec<T, VEC>(row + c);
+        if (!have_first) {
+            first = v;
+            have_first = true;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float f = to_f32<T>(v.v[i]);
+            mn = fminf(mn, f);
+            mx = fmaxf(mx, f);
+        }
+    }
+    mn = wave_min(mn, lpr);
+    mx = wave_max(mx, lpr);
+}
+
+// K5: [G, g] -> scales/zeros [G] (tensor dtype)
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_minmax_qparams(const T* __restrict__ W, int64_t G, int g,
+                                                           int lpr, int sym, int round_zp, float qmin,
+                                                           float qmax, T* __restrict__ scales,
+                                                           T* __restrict__ zeros) {
+    constexpr int DT = dt_of<T>::value;
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const int sub = lane / lpr, sl = lane % lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r0 = wave * rpw; r0 < G; r0 += nwaves * rpw) {
+        int64_t row = r0 + sub;
+        bool valid = row < G;
+        int64_t rr = valid ? row : G - 1;
+        float mn, mx;
+        RowVec<T, VEC> first;
+        bool hf;
+        row_minmax<T, VEC>(W + rr * g, g, sl, lpr, mn, mx, first, hf);
+        if (valid && sl == 0) {
+            QParams q = qparams_from_minmax(mn, mx, DT, sym, round_zp, qmin, qmax);
+            scales[row] = from_f32<T>(q.s);
+            if (zeros) zeros[row] = from_f32<T>(q.z);
+        }
+    }
+}
+
+// two-stage variant for few, very long rows (per_tensor / huge per_channel)
+static constexpr int kChunk = 8192;
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_minmax_partial(const T* __restrict__ W, int64_t G, int64_t g,
+                                                           int64_t nch, float2* __restrict__ part) {
+    __shared__ float smn[kBlock / 64], smx[kBlock / 64];
+    for (int64_t u = blockIdx.x; u < G * nch; u += gridDim.x) {
+        int64_t row = u / nch, ch = u % nch;
+        int64_t c0 = ch * kChunk, c1 = c0 + kChunk < g ? c0 + kChunk : g;
+        const T* p = W + row * g;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int64_t c = c0 + (int64_t)threadIdx.x * VEC; c < c1; c += (int64_t)kBlock * VEC) {
+            RowVec<T, VEC> v = load_vec<T, VEC>(p + c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float f = to_f32<T>(v.v[i]);
+                mn = fminf(mn, f);
+                mx = fmaxf(mx, f);
+            }
+        }
+        mn = wave_min(mn, 64);
+        mx = wave_max(mx, 64);
+        if ((threadIdx.x & 63) == 0) {
+            smn[threadIdx.x >> 6] = mn;
+            smx[threadIdx.x >> 6] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < kBlock / 64; ++i) {
+                mn = fminf(mn, smn[i]);
+                mx = fmaxf(mx, smx[i]);
+            }
+            part[u] = make_float2(mn, mx);
+        }
+        __syncthreads();
+    }
+}
+template <typename T>
+__global__ void k_minmax_final(const float2* __restrict__ part, int64_t G, int64_t nch, int sym,
+                               int round_zp, float qmin, float qmax, T* __restrict__ scales,
+                               T* __restrict__ zeros) {
+    constexpr int DT = dt_of<T>::value;
+    int64_t row = blockIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t c = threadIdx.x; c < nch; c += 64) {
+        float2 p = part[row * nch + c];
+        mn = fminf(mn, p.x);
+        mx = fmaxf(mx, p.y);
+    }
+    mn = wave_min(mn, 64);
+    mx = wave_max(mx, 64);
+    if (threadIdx.x == 0) {
+        QParams q = qparams_from_minmax(mn, mx, DT, sym, round_zp, qmin, qmax);
+        scales[row] = from_f32<T>(q.s);
+        if (zeros) zeros[row] = from_f32<T>(q.z);
+    }
+}
+
+// K6 static: given qparams
+template <typename T, int VEC, int KIND>
+__global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W, int64_t G, int g,
+                                                         const void* __restrict__ scales, int sdt,
+                                                         const void* __restrict__ zeros, int zdt,
+                                                         float qmin, float qmax, void* __restrict__ out) {
+    constexpr int WDT = dt_of<T>::value;
+    const int p1 = promote(WDT, sdt);
+    const int p2 = zeros ? promote(p1, zdt) : p1;
+    const int64_t nvec_row = g / VEC;
+    const int64_t total = G * nvec_row;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * kBlock) {
+        int64_t row = i / nvec_row;
+        int64_t c = (i - row * nvec_row) * VEC;
+        float s = load_as_f32(scales, row, sdt);
+        float z = zeros ? load_as_f32(zeros, row, zdt) : 0.0f;
+        RowVec<T, VEC> v = load_vec<T, VEC>(W + row * g + c);
+        if constexpr (KIND == LLMC_OUT_FAKE) {
+            RowVec<T, VEC> o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float q = quant_code(to_f32<T>(v.v[k]), s, z, p1, p2, qmin, qmax);
+                o.v[k] = from_f32<T>(dequant_code(q, s, z, p2));
+            }
+            store_vec<T, VEC>((T*)out + row * g + c, o);
+        } else {
+            using C = typename code_t<KIND>::type;
+            RowVec<C, VEC> o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                o.v[k] = (C)quant_code(to_f32<T>(v.v[k]), s, z, p1, p2, qmin, qmax);
+            C* op = (C*)out + row * g + c;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) op[k] = o.v[k];
+        }
+    }
+}
+
+// K5+K6 fused dynamic: one pass over W from HBM (second row pass hits L1/L2; the first 16 B per lane
+// stay in registers, which covers g <= LPR*VEC, i.e. every per_group case).
+template <typename T, int VEC, int KIND>
+__global__ __launch_bounds__(kBlock) void k_quant_dynamic(const T* __restrict__ W, int64_t G, int g,
+                                                          int lpr, int sym, int round_zp, float qmin,
+                                                          float qmax, void* __restrict__ out,
+                                                          T* __restrict__ scales, T* __restrict__ zeros) {
+    constexpr int DT = dt_of<T>::value;
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const int sub = lane / lpr, sl = lane % lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r0 = wave * rpw; r0 < G; r0 += nwaves * rpw) {
+        int64_t row = r0 + sub;
+        bool valid = row < G;
+        int64_t rr = valid ? row : G - 1;
+        const T* rp = W + rr * g;
+        float mn, mx;
+        RowVec<T, VEC> first;
+        bool hf;
+        row_minmax<T, VEC>(rp, g, sl, lpr, mn, mx, first, hf);
+        QParams q = qparams_from_minmax(mn, mx, DT, sym, round_zp, qmin, qmax);
+        if (valid && sl == 0) {
+            if (scales) scales[row] = from_f32<T>(q.s);
+            if (zeros) zeros[row] = from_f32<T>(q.z);
+        }
+        if (!valid) continue;
+        bool use_first = true;
+        for (int c = sl * VEC; c < g; c += lpr * VEC) {
+            RowVec<T, VEC> v = use_first ? first : load_vec<T, VEC>(rp + c);
+            use_first = false;
+            if constexpr (KIND == LLMC_OUT_FAKE) {
+                RowVec<T, VEC> o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float qq = quant_code(to_f32<T>(v.v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                    o.v[k] = from_f32<T>(dequant_code(qq, q.s, q.z, DT));
+                }
+                store_vec<T, VEC>((T*)out + rr * g + c, o);
+            } else {
+                using C = typename code_t<KIND>::type;
+                C* op = (C*)out + rr * g + c;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    op[k] = (C)quant_code(to_f32<T>(v.v[k]), q.s, q.z, DT, DT, qmin, qmax);
+            }
+        }
+    }
+}
+
+// K7: LSB-first packing. One thread per output word; 32/bits consecutive codes -> one int32.
+template <typename C, bool VECOK>
+__global__ __launch_bounds__(kBlock) void k_pack_lsb(const C* __restrict__ codes, int64_t R, int64_t K,
+                                                     int bits, int64_t Kp, int32_t* __restrict__ packed) {
+    const int pf = 32 / bits;
+    const int off = 1 << (bits - 1);
+    const int64_t total = R * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * kBlock) {
+        int64_t r = i / Kp, j = i - r * Kp;
+        const C* p = codes + r * K + j * pf;
+        uint32_t w = 0;
+        if (j * pf + pf <= K) {
+            if constexpr (sizeof(C) == 4 && VECOK) {
+                if (pf == 8) {
+                    int4 a = *reinterpret_cast<const int4*>(p);
+                    int4 b = *reinterpret_cast<const int4*>(p + 4);
+                    int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) w |= (uint32_t)((v[k] + off) & 0xff) << (bits * k);
+                } else {
+                    for (int k = 0; k < pf; ++k) w |= (uint32_t)(((int)p[k] + off) & 0xff) << (bits * k);
+                }
+            } else {
+                for (int k = 0; k < pf; ++k) w |= (uint32_t)(((int)p[k] + off) & 0xff) << (bits * k);
+            }
+        } else {
+            for (int k = 0; k < pf && j * pf + k < K; ++k)
+                w |= (uint32_t)(((int)p[k] + off) & 0xff) << (bits * k);
+        }
+        packed[i] = (int32_t)w;
+    }
+}
+
+static inline int grid_for(int64_t work_items, int per_block) {
+    int64_t b = ceil_div64(work_items, per_block);
+    if (b < 1) b = 1;
+    return (int)(b > kMaxGrid ? kMaxGrid : b);
+}
+
+static inline int choose_lpr(int64_t g, int vec) {
+    int lpr = pow2_ceil(ceil_div64(g, vec));
+    if (lpr > 64) lpr = 64;
+    if (lpr < 1) lpr = 1;
+    return lpr;
+}
+
+static inline bool use_two_stage(int64_t G, int64_t g) { return g >= 4 * kChunk && G < 4096; }
+
+}  // namespace llmc
+
+using namespace llmc;
+
+extern "C" size_t llmc_minmax_qparams_ws_bytes(int64_t G, int64_t g) {
+    if (G <= 0 || g <= 0) return 0;
+    if (!use_two_stage(G, g)) return 0;
+    return (size_t)(G * ceil_div64(g, kChunk)) * sizeof(float2);
+}
+
+template <typename T>
+static int minmax_qparams_t(const void* W, int64_t G, int64_t g, int sym, int round_zp, float qmin,
+                            float qmax, void* scales, void* zeros, void* ws, hipStream_t st) {
+    constexpr int V16 = 16 / sizeof(T);
+    bool vec_ok = (g % V16 == 0) && (((uintptr_t)W & 15) == 0);
+    if (use_two_stage(G, g)) {
+        LLMC_REQUIRE(ws != nullptr, "minmax_qparams: workspace required for long rows");
+        int64_t nch = ceil_div64(g, kChunk);
+        int grid = grid_for(G * nch, 1);
+        if (vec_ok)
+            hipLaunchKernelGGL((k_minmax_partial<T, V16>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G, g,
+                               nch, (float2*)ws);
+        else
+            hipLaunchKernelGGL((k_minmax_partial<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G, g,
+                               nch, (float2*)ws);
+        LLMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_minmax_final<T>), dim3((unsigned)G), dim3(64), 0, st, (const float2*)ws, G, nch,
+                           sym, round_zp, qmin, qmax, (T*)scales, (T*)zeros);
+        LLMC_LAUNCH_CHECK();
+        return LLMC_OK;
+    }
+    LLMC_REQUIRE(g < (1ll << 31), "minmax_qparams: row too long");
+    if (vec_ok) {
+        int lpr = choose_lpr(g, V16);
+        int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
+        hipLaunchKernelGGL((k_minmax_qparams<T, V16>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G, (int)g,
+                           lpr, sym, round_zp, qmin, qmax, (T*)scales, (T*)zeros);
+    } else {
+        int lpr = choose_lpr(g, 1);
+        int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
+        hipLaunchKernelGGL((k_minmax_qparams<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G, (int)g,
+                           lpr, sym, round_zp, qmin, qmax, (T*)scales, (T*)zeros);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+extern "C" int llmc_minmax_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, int round_zp,
+                                   float qmin, float qmax, void* scales, void* zeros, void* ws,
+                                   llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(dt), "minmax_qparams: bad dtype");
+    LLMC_REQUIRE(W && scales && G > 0 && g > 0, "minmax_qparams: null/empty argument");
+    LLMC_REQUIRE(sym || zeros, "minmax_qparams: zeros required for asymmetric");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dt) {
+        case LLMC_F16: return minmax_qparams_t<f16_t>(W, G, g, sym, round_zp, qmin, qmax, scales, zeros, ws, st);
+        case LLMC_BF16: return minmax_qparams_t<bf16_t>(W, G, g, sym, round_zp, qmin, qmax, scales, zeros, ws, st);
+        default: return minmax_qparams_t<float>(W, G, g, sym, round_zp, qmin, qmax, scales, zeros, ws, st);
+    }
+}
+
+template <typename T, int KIND>
+static int quant_static_tk(const void* W, int64_t G, int64_t g, const void* scales, int sdt,
+                           const void* zeros, int zdt, float qmin, float qmax, void* out, hipStream_t st) {
+    constexpr int V16 = 16 / sizeof(T);
+    bool vec_ok = (g % V16 == 0) && (((uintptr_t)W & 15) == 0) &&
+                  (KIND != LLMC_OUT_FAKE || ((uintptr_t)out & 15) == 0);
+    LLMC_REQUIRE(g < (1ll << 31), "quant_static: row too long");
+    if (vec_ok) {
+        int grid = grid_for(G * (g / V16), kBlock);
+        hipLaunchKernelGGL((k_quant_static<T, V16, KIND>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G,
+                           (int)g, scales, sdt, zeros, zdt, qmin, qmax, out);
+    } else {
+        int grid = grid_for(G * g, kBlock);
+        hipLaunchKernelGGL((k_quant_static<T, 1, KIND>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G,
+                           (int)g, scales, sdt, zeros, zdt, qmin, qmax, out);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+template <typename T>
+static int quant_static_t(const void* W, int64_t G, int64_t g, const void* scales, int sdt,
+                          const void* zeros, int zdt, float qmin, float qmax, int kind, void* out,
+                          hipStream_t st) {
+    switch (kind) {
+        case LLMC_OUT_FAKE: return quant_static_tk<T, LLMC_OUT_FAKE>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out, st);
+        case LLMC_OUT_I32: return quant_static_tk<T, LLMC_OUT_I32>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out, st);
+        case LLMC_OUT_I8: return quant_static_tk<T, LLMC_OUT_I8>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out, st);
+        case LLMC_OUT_U8: return quant_static_tk<T, LLMC_OUT_U8>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out, st);
+    }
+    set_last_error_msg("quant_static: bad out_kind");
+    return LLMC_EINVAL;
+}
+
+extern "C" int llmc_quant_static(const void* W, int wdt, int64_t G, int64_t g, const void* scales, int sdt,
+                                 const void* zeros, int zdt, float qmin, float qmax, int out_kind,
+                                 void* out, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(wdt) && dtype_ok(sdt) && (!zeros || dtype_ok(zdt)), "quant_static: bad dtype");
+    LLMC_REQUIRE(W && scales && out && G > 0 && g > 0, "quant_static: null/empty argument");
+    hipStream_t st = (hipStream_t)stream;
+    switch (wdt) {
+        case LLMC_F16: return quant_static_t<f16_t>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out_kind, out, st);
+        case LLMC_BF16: return quant_static_t<bf16_t>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out_kind, out, st);
+        default: return quant_static_t<float>(W, G, g, scales, sdt, zeros, zdt, qmin, qmax, out_kind, out, st);
+    }
+}
+
+extern "C" size_t llmc_quant_dynamic_ws_bytes(int64_t G, int64_t g) {
+    if (G <= 0 || g <= 0) return 0;
+    if (!use_two_stage(G, g)) return 0;
+    // partial min/max + a private copy of scales/zeros when the caller does not want them
+    return llmc_minmax_qparams_ws_bytes(G, g) + (size_t)G * 8 + 64;
+}
+
+template <typename T, int KIND>
+static int quant_dynamic_tk(const void* W, int64_t G, int64_t g, int sym, int round_zp, float qmin,
+                            float qmax, void* out, void* scales, void* zeros, hipStream_t st) {
+    constexpr int V16 = 16 / sizeof(T);
+    bool vec_ok = (g % V16 == 0) && (((uintptr_t)W & 15) == 0) &&
+                  (KIND != LLMC_OUT_FAKE || ((uintptr_t)out & 15) == 0);
+    LLMC_REQUIRE(g < (1ll << 31), "quant_dynamic: row too long");
+    if (vec_ok) {
+        int lpr = choose_lpr(g, V16);
+        int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
+        hipLaunchKernelGGL((k_quant_dynamic<T, V16, KIND>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G,
+                           (int)g, lpr, sym, round_zp, qmin, qmax, out, (T*)scales, (T*)zeros);
+    } else {
+        int lpr = choose_lpr(g, 1);
+        int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
+        hipLaunchKernelGGL((k_quant_dynamic<T, 1, KIND>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G,
+                           (int)g, lpr, sym, round_zp, qmin, qmax, out, (T*)scales, (T*)zeros);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+template <typename T>
+static int quant_dynamic_t(const void* W, int64_t G, int64_t g, int sym, int round_zp, float qmin,
+                           float qmax, int kind, void* out, void* scales, void* zeros, hipStream_t st) {
+    switch (kind) {
+        case LLMC_OUT_FAKE: return quant_dynamic_tk<T, LLMC_OUT_FAKE>(W, G, g, sym, round_zp, qmin, qmax, out, scales, zeros, st);
+        case LLMC_OUT_I32: return quant_dynamic_tk<T, LLMC_OUT_I32>(W, G, g, sym, round_zp, qmin, qmax, out, scales, zeros, st);
+        case LLMC_OUT_I8: return quant_dynamic_tk<T, LLMC_OUT_I8>(W, G, g, sym, round_zp, qmin, qmax, out, scales, zeros, st);
+        case LLMC_OUT_U8: return quant_dynamic_tk<T, LLMC_OUT_U8>(W, G, g, sym, round_zp, qmin, qmax, out, scales, zeros, st);
+    }
+    set_last_error_msg("quant_dynamic: bad out_kind");
+    return LLMC_EINVAL;
+}
+
+extern "C" int llmc_quant_dynamic(const void* W, int dt, int64_t G, int64_t g, int sym, int round_zp,
+                                  float qmin, float qmax, int out_kind, void* out, void* scales_out,
+                                  void* zeros_out, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(dt), "quant_dynamic: bad dtype");
+    LLMC_REQUIRE(W && out && G > 0 && g > 0, "quant_dynamic: null/empty argument");
+    LLMC_REQUIRE(round_zp == 1, "quant_dynamic: only round_zp=True is supported");
+    hipStream_t st = (hipStream_t)stream;
+    if (use_two_stage(G, g)) {
+        // few long rows (per_tensor): min/max by the two-stage reduction, then the static kernel
+        LLMC_REQUIRE(ws != nullptr, "quant_dynamic: workspace required for long rows");
+        char* wsb = (char*)ws;
+        size_t off = (llmc_minmax_qparams_ws_bytes(G, g) + 63) & ~(size_t)63;
+        void* s = scales_out ? scales_out : (void*)(wsb + off);
+        void* z = sym ? nullptr : (zeros_out ? zeros_out : (void*)(wsb + off + (size_t)G * 4));
+        int rc = llmc_minmax_qparams(W, dt, G, g, sym, round_zp, qmin, qmax, s, sym ? zeros_out : z, ws, stream);
+        if (rc) return rc;
+        return llmc_quant_static(W, dt, G, g, s, dt, z, dt, qmin, qmax, out_kind, out, stream);
+    }
+    void* zo = sym ? nullptr : zeros_out;
+    int rc;
+    switch (dt) {
+        case LLMC_F16: rc = quant_dynamic_t<f16_t>(W, G, g, sym, round_zp, qmin, qmax, out_kind, out, scales_out, zo, st); break;
+        case LLMC_BF16: rc = quant_dynamic_t<bf16_t>(W, G, g, sym, round_zp, qmin, qmax, out_kind, out, scales_out, zo, st); break;
+        default: rc = quant_dynamic_t<float>(W, G, g, sym, round_zp, qmin, qmax, out_kind, out, scales_out, zo, st); break;
+    }
+    if (rc) return rc;
+    if (sym && zeros_out) LLMC_HIP_CHECK(hipMemsetAsync(zeros_out, 0, (size_t)G * dtype_size(dt), st));
+    return LLMC_OK;
+}
+
+extern "C" int llmc_pack_lsb(const void* codes, int code_kind, int64_t R, int64_t K, int bits,
+                             int32_t* packed, llmc_stream_t stream) {
+    LLMC_REQUIRE(codes && packed && R > 0 && K > 0, "pack_lsb: null/empty argument");
+    LLMC_REQUIRE(bits == 4 || bits == 8, "pack_lsb: bits must be 4 or 8");
+    LLMC_REQUIRE(code_kind == LLMC_OUT_I32 || code_kind == LLMC_OUT_I8, "pack_lsb: bad code container");
+    hipStream_t st = (hipStream_t)stream;
+    int pf = 32 / bits;
+    int64_t Kp = ceil_div64(K, pf);
+    int grid = grid_for(R * Kp, kBlock);
+    if (code_kind == LLMC_OUT_I32) {
+        bool vec_ok = (K % 4 == 0) && (((uintptr_t)codes & 15) == 0);  // 16-B loads need aligned rows
+        if (vec_ok)
+            hipLaunchKernelGGL((k_pack_lsb<int32_t, true>), dim3(grid), dim3(kBlock), 0, st,
+                               (const int32_t*)codes, R, K, bits, Kp, packed);
+        else
+            hipLaunchKernelGGL((k_pack_lsb<int32_t, false>), dim3(grid), dim3(kBlock), 0, st,
+                               (const int32_t*)codes, R, K, bits, Kp, packed);
+    } else {
+        hipLaunchKernelGGL((k_pack_lsb<int8_t, false>), dim3(grid), dim3(kBlock), 0, st, (const int8_t*)codes,
+                           R, K, bits, Kp, packed);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}

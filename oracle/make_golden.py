@@ -1,0 +1,193 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (llmc @ /root/reference) on CPU.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/make_golden.py            # all suites
+    python oracle/make_golden.py quant pack # selected suites
+The reference is imported read-only with two import shims (oracle/_shims: loguru, easydict) and three
+monkeypatches that do what the reference's own CI rewrite does (ci_check/change_files.py:34-179):
+`.cuda()` -> no-op, torch.cuda.synchronize/empty_cache -> no-op, device='cuda' -> 'cpu'.  Its CI
+work-shrinkers (AWQ n_grid=1, nsamples=1) are NOT applied.  Outputs are small seeded fixtures; 16-bit
+tensors are stored as float32 (exact).  Test infrastructure only.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, os.path.join(HERE, '_shims'))
+sys.path.insert(0, '/root/reference')
+
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.empty_cache = lambda *a, **k: None
+_orig_tensor, _orig_zeros_like, _orig_zeros = torch.tensor, torch.zeros_like, torch.zeros
+
+
+def _cpu_dev(fn):
+    def wrap(*a, **k):
+        if str(k.get('device', '')).startswith('cuda'):
+            k['device'] = 'cpu'
+        return fn(*a, **k)
+    return wrap
+
+
+_orig_to = torch.Tensor.to
+
+
+def _to(self, *a, **k):
+    if str(k.get('device', '')).startswith('cuda'):
+        k['device'] = 'cpu'
+    a = tuple('cpu' if (isinstance(x, str) and x.startswith('cuda')) else x for x in a)
+    return _orig_to(self, *a, **k)
+
+
+torch.Tensor.to = _to
+torch.tensor = _cpu_dev(_orig_tensor)
+torch.zeros_like = _cpu_dev(_orig_zeros_like)
+torch.zeros = _cpu_dev(_orig_zeros)
+
+os.environ.setdefault('WORLD_SIZE', '1')
+os.environ.setdefault('RANK', '0')
+
+from llmc.compression.quantization.quant import IntegerQuantizer  # noqa: E402
+
+DT = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}
+
+
+def f32(t):
+    return t.detach().float().numpy().copy()
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+def rand_weight(gen, R, K, dt, outliers=True):
+    w = torch.randn(R, K, generator=gen) * 0.02
+    if outliers:
+        idx = torch.randperm(K, generator=gen)[: max(1, K // 64)]
+        w[:, idx] *= 20
+    # a constant group (max == min -> clamp(1e-5) path), an all-zero group and a huge group
+    w[0, :128] = 0.0
+    if R > 1:
+        w[1, :128] = 0.0173
+    if R > 2:
+        w[2, :128] *= 3000.0
+    return w.to(DT[dt])
+
+
+# ------------------------------------------------------------------------------------------------
+def suite_quant():
+    """IntegerQuantizer on weights: qparams, fake dynamic, real dynamic, static with mixed dtypes."""
+    gen = torch.Generator().manual_seed(1234)
+    out = {}
+    cases = []
+    for dt in ('f16', 'bf16', 'f32'):
+        for (bit, sym, gran, gs) in [(4, False, 'per_group', 128), (4, True, 'per_group', 128),
+                                     (8, True, 'per_channel', None), (8, False, 'per_channel', None),
+                                     (4, True, 'per_group', 64), (8, True, 'per_tensor', None),
+                                     (3, False, 'per_group', 32)]:
+            cases.append((dt, bit, sym, gran, gs))
+    for ci, (dt, bit, sym, gran, gs) in enumerate(cases):
+        kw = dict(group_size=gs) if gs else {}
+        q = IntegerQuantizer(bit, sym, gran, **kw)
+        w = rand_weight(gen, 16, 384, dt)
+        t, s, z, qmax, qmin = q.get_tensor_qparams(w)
+        fq = q.fake_quant_weight_dynamic(w)
+        rw, rs, rz = q.real_quant_weight_dynamic(w)
+        p = f'c{ci}_'
+        out[p + 'w'] = f32(w)
+        out[p + 'scales'] = f32(s).reshape(-1)
+        out[p + 'zeros'] = f32(z).reshape(-1) if z.dim() > 0 else np.zeros(0, np.float32)
+        out[p + 'scales_dtype'] = np.array(str(s.dtype))
+        out[p + 'fake'] = f32(fq)
+        out[p + 'codes'] = rw.numpy().astype(np.int32)
+        out[p + 'codes_dtype'] = np.array(str(rw.dtype))
+        out[p + 'rscales'] = f32(rs)
+        out[p + 'rzeros'] = rz.numpy().astype(np.int32) if rz is not None else np.zeros(0, np.int32)
+        out[p + 'meta'] = np.array([bit, int(sym), gs or 0, float(qmin), float(qmax)], dtype=np.float64)
+        out[p + 'gran'] = np.array(gran)
+        out[p + 'dt'] = np.array(dt)
+    out['n_cases'] = np.array(len(cases))
+
+    # static: fp32 weights (GPTQ leaves layer.weight fp32) with model-dtype / fp32 qparams
+    sc = []
+    for (wdt, sdt, zdt, sym) in [('f32', 'f16', 'f16', False), ('f32', 'bf16', 'bf16', False),
+                                 ('f32', 'f32', 'f32', False), ('f32', 'f16', None, True),
+                                 ('f16', 'f16', 'f32', False), ('bf16', 'f32', 'f32', False),
+                                 ('f32', 'f16', 'f32', False)]:
+        sc.append((wdt, sdt, zdt, sym))
+    for ci, (wdt, sdt, zdt, sym) in enumerate(sc):
+        q = IntegerQuantizer(4, sym, 'per_group', group_size=128)
+        w0 = rand_weight(gen, 16, 256, 'f16' if sdt == 'f32' else sdt)
+        _, s, z, qmax, qmin = q.get_tensor_qparams(w0)
+        s = s.to(DT[sdt])
+        z = z.to(DT[zdt]) if zdt is not None and z.dim() > 0 else z
+        w = (w0.float() + 0.003 * torch.randn(16, 256, generator=gen)).to(DT[wdt])
+        args = {'scales': s, 'zeros': z, 'qmax': qmax, 'qmin': qmin}
+        fq = q.fake_quant_weight_static(w, dict(args))
+        rw, rs, rz = q.real_quant_weight_static(w, dict(args))
+        p = f's{ci}_'
+        out[p + 'w'] = f32(w)
+        out[p + 'scales'] = f32(s).reshape(-1)
+        out[p + 'zeros'] = f32(z).reshape(-1) if z.dim() > 0 else np.zeros(0, np.float32)
+        out[p + 'fake'] = f32(fq)
+        out[p + 'fake_dtype'] = np.array(str(fq.dtype))
+        out[p + 'codes'] = rw.numpy().astype(np.int32)
+        out[p + 'meta'] = np.array([4, int(sym), 128, float(qmin), float(qmax)], dtype=np.float64)
+        out[p + 'dts'] = np.array([wdt, sdt, zdt or 'none'])
+    out['n_static'] = np.array(len(sc))
+    save('quant', **out)
+
+
+def suite_pack():
+    """VllmRealQuantLinear.pack and AutoawqRealQuantLinear.gemm_pack (never run by the reference's CI)."""
+    from easydict import EasyDict
+    from llmc.compression.quantization.module_utils import (AutoawqRealQuantLinear,
+                                                            VllmRealQuantLinear)
+    gen = torch.Generator().manual_seed(77)
+    out = {}
+    for ci, (bit, K) in enumerate([(4, 256), (8, 256), (4, 200), (8, 130)]):
+        q = IntegerQuantizer(bit, True, 'per_channel')
+        w = rand_weight(gen, 24, K, 'f16', outliers=False)
+        codes, scales, _ = q.real_quant_weight_dynamic(w)
+        cfg = EasyDict({'weight': {'bit': bit}})
+        packed, ps = VllmRealQuantLinear.pack(codes, scales, cfg)
+        out[f'v{ci}_codes'] = codes.numpy().astype(np.int32)
+        out[f'v{ci}_packed'] = packed.numpy()
+        out[f'v{ci}_bit'] = np.array(bit)
+    out['n_vllm'] = np.array(4)
+
+    for ci, (R, K, g) in enumerate([(64, 256, 128), (32, 384, 64)]):
+        q = IntegerQuantizer(4, False, 'per_group', group_size=g)
+        lin = torch.nn.Linear(K, R, bias=False).half()
+        lin.weight.data = rand_weight(gen, R, K, 'f16')
+        _, scales, zeros = q.real_quant_weight_dynamic(lin.weight.data)
+        cfg = EasyDict({'weight': {'bit': 4, 'group_size': g, 'pack_version': 'gemm_pack'}})
+        qw, sc, qz = AutoawqRealQuantLinear.gemm_pack(lin, lin.weight.data, scales, zeros, cfg)
+        out[f'a{ci}_w'] = f32(lin.weight.data)
+        out[f'a{ci}_scales'] = f32(scales)
+        out[f'a{ci}_zeros'] = zeros.numpy().astype(np.int32)
+        out[f'a{ci}_qweight'] = qw.numpy()
+        out[f'a{ci}_qscales'] = f32(sc)
+        out[f'a{ci}_qzeros'] = qz.numpy()
+        out[f'a{ci}_g'] = np.array(g)
+    out['n_awq'] = np.array(2)
+    save('pack', **out)
+
+
+SUITES = {'quant': suite_quant, 'pack': suite_pack}
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or list(SUITES)
+    for s in which:
+        SUITES[s]()

@@ -1,0 +1,220 @@
+"""Numpy restatement of llmc's IntegerQuantizer / FloatQuantizer arithmetic and the int packers.
+
+Follows (paths relative to the llmc tree):
+  llmc/compression/quantization/quant.py:132-143  get_minmax_range
+  llmc/compression/quantization/quant.py:545-559  get_qparams
+  llmc/compression/quantization/quant.py:612-658  reshape_tensor / restore_tensor
+  llmc/compression/quantization/quant.py:699-717  quant / dequant / quant_dequant
+  llmc/compression/quantization/quant.py:785-953  fake/real quant weight static/dynamic
+  llmc/compression/quantization/quant.py:1043-1072,1195-1221  FloatQuantizer (e4m3; qtorch pinned to
+      torch.float8_e4m3fn's RNE cast — parity otherwise unpinned, qtorch is not vendored)
+  llmc/compression/quantization/module_utils.py:836-862   VllmRealQuantLinear.pack
+  llmc/compression/quantization/module_utils.py:1004-1065 AutoawqRealQuantLinear.gemm_pack
+Test infrastructure only (see oracle/__init__.py).
+"""
+import numpy as np
+
+F16, BF16, F32 = 'f16', 'bf16', 'f32'
+
+
+def rnd(a, dt):
+    """Round fp32 values to dtype dt (RNE) and return them as fp32."""
+    a = np.asarray(a, dtype=np.float32)
+    if dt == F32:
+        return a
+    if dt == F16:
+        with np.errstate(over='ignore'):
+            return a.astype(np.float16).astype(np.float32)
+    if dt == BF16:
+        x = a.view(np.uint32).astype(np.uint64)
+        nan = (x & 0x7fffffff) > 0x7f800000
+        lsb = (x >> 16) & 1
+        y = ((x + 0x7fff + lsb) >> 16) << 16
+        y = np.where(nan, ((x >> 16) | 0x40) << 16, y)
+        return (y & 0xffffffff).astype(np.uint32).view(np.float32).reshape(a.shape)
+    raise ValueError(dt)
+
+
+def promote(a, b):
+    return a if a == b else F32
+
+
+def int_range(bit, sym):
+    """quant.py:665-677"""
+    if sym:
+        return float(-(2 ** (bit - 1))), float(2 ** (bit - 1) - 1)
+    return 0.0, float(2 ** bit - 1)
+
+
+def reshape_rows(w, granularity, group_size=None):
+    """quant.py:612-642 (per_group / per_channel / per_tensor). Returns a 2-D [G, g] view."""
+    w = np.asarray(w, dtype=np.float32)
+    if granularity == 'per_group':
+        if w.shape[-1] >= group_size:
+            assert w.shape[-1] % group_size == 0
+            return w.reshape(-1, group_size)
+        return w.reshape(-1, w.shape[-1])
+    if granularity == 'per_tensor':
+        return w.reshape(1, -1)
+    return w.reshape(-1, w.shape[-1])  # per_channel / per_token: reduce over last dim
+
+
+def qparams_from_minmax(mn, mx, dt, sym, qmin, qmax, round_zp=True):
+    """quant.py:545-559. mn/mx: values of dtype dt."""
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        eps = rnd(np.float32(1e-5), dt)
+        if sym:
+            a = np.maximum(np.abs(mx), np.abs(mn))
+            a = np.maximum(a, eps)
+            s = rnd(a / rnd(np.float32(qmax), dt), dt)
+            z = np.zeros_like(s)
+        else:
+            d = rnd(mx - mn, dt)
+            d = np.maximum(d, eps)
+            s = rnd(d / rnd(np.float32(qmax - qmin), dt), dt)
+            r = rnd(mn / s, dt)
+            if round_zp:
+                r = np.rint(r)
+                z = rnd(np.float32(qmin) - r, dt)
+                z = np.minimum(np.maximum(z, np.float32(qmin)), np.float32(qmax))
+            else:
+                z = rnd(np.float32(qmin) - r, dt)
+    return s.astype(np.float32), z.astype(np.float32)
+
+
+def minmax_qparams(w2d, dt, sym, qmin, qmax, round_zp=True):
+    """get_tensor_qparams on an already reshaped [G, g] array -> (scales [G,1], zeros [G,1])."""
+    mx = w2d.max(axis=-1, keepdims=True)
+    mn = w2d.min(axis=-1, keepdims=True)
+    return qparams_from_minmax(mn, mx, dt, sym, qmin, qmax, round_zp)
+
+
+def quant_codes(w2d, wdt, s, sdt, z, zdt, qmin, qmax):
+    """quant.py:699-701 (round_zp=True): clamp(round(x / s) + z, qmin, qmax); values are integers."""
+    p1 = promote(wdt, sdt)
+    p2 = promote(p1, zdt) if zdt is not None else p1
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        t = rnd(w2d / s, p1)
+        t = np.rint(t)
+        t = rnd(t + (z if z is not None else np.float32(0.0)), p2)
+        t = np.minimum(np.maximum(t, np.float32(qmin)), np.float32(qmax))
+    return t.astype(np.float32), p2
+
+
+def dequant(q, s, z, p2):
+    """quant.py:709-712"""
+    with np.errstate(over='ignore', invalid='ignore'):
+        t = rnd(q - (z if z is not None else np.float32(0.0)), p2)
+        return rnd(t * s, p2)
+
+
+def fake_quant_static(w2d, wdt, s, sdt, z, zdt, qmin, qmax):
+    q, p2 = quant_codes(w2d, wdt, s, sdt, z, zdt, qmin, qmax)
+    return rnd(dequant(q, s, z, p2), wdt)
+
+
+def fake_quant_dynamic(w2d, dt, sym, qmin, qmax):
+    s, z = minmax_qparams(w2d, dt, sym, qmin, qmax)
+    return fake_quant_static(w2d, dt, s, dt, z, dt, qmin, qmax), s, z
+
+
+def real_quant_dynamic(w2d, dt, sym, qmin, qmax):
+    s, z = minmax_qparams(w2d, dt, sym, qmin, qmax)
+    q, _ = quant_codes(w2d, dt, s, dt, z, dt, qmin, qmax)
+    return q.astype(np.int32), s, (None if sym else z.astype(np.int32))
+
+
+def pack_lsb(codes, bits):
+    """module_utils.py:836-862: u = uint8(code + 2^(b-1)); word |= u[:, i::pf] << (b*i)."""
+    codes = np.asarray(codes)
+    off = (2 ** bits) // 2
+    u = ((codes.astype(np.int64) + off) & 0xff).astype(np.uint32)
+    pf = 32 // bits
+    R, K = u.shape
+    Kp = -(-K // pf)
+    pad = Kp * pf - K
+    u = np.pad(u, [(0, 0), (0, pad)], constant_values=0)
+    packed = np.zeros((R, Kp), dtype=np.uint32)
+    for i in range(pf):
+        packed |= u[:, i::pf] << np.uint32(bits * i)
+    return packed.view(np.int32)
+
+
+AWQ_ORDER = [0, 2, 4, 6, 1, 3, 5, 7]
+
+
+def pack_awq_gemm(w, scales, zeros, group_size, bits=4):
+    """module_utils.py:1004-1065. w [R,K] f16 values; scales [R,K/g] (any dt) ; zeros [R,K/g] int.
+    Returns qweight [K, R/8] int32, scales [K/g, R] f16 values, qzeros [K/g, R/8] int32."""
+    assert bits == 4
+    w = np.asarray(w, dtype=np.float32)
+    sc = rnd(np.asarray(scales, dtype=np.float32).T.copy(), F16)      # [K/g, R] f16
+    zr = np.asarray(zeros).T.astype(np.float32)                        # [K/g, R] (int values)
+    # zeros (int32) * scales (f16) -> f16 in torch
+    sz = rnd(zr * sc, F16)
+    R, K = w.shape
+    gidx = np.arange(K) // group_size
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        t = rnd(w + sz[gidx].T, F16)          # weight[:, idx] + scale_zeros[idx // g]
+        t = rnd(t / sc[gidx].T, F16)
+        iw = np.rint(t).astype(np.int32)      # [R, K]
+    iw = iw.T.copy()                          # [K, R]
+    pack = 32 // bits
+    qw = np.zeros((K, R // pack), dtype=np.int32)
+    for i in range(pack):
+        qw |= (iw[:, AWQ_ORDER[i]::pack] << (bits * i)).astype(np.int32)
+    zi = np.asarray(zeros).T.astype(np.int32)
+    qz = np.zeros((zi.shape[0], R // pack), dtype=np.int32)
+    for i in range(pack):
+        qz |= (zi[:, AWQ_ORDER[i]::pack] << (bits * i)).astype(np.int32)
+    return qw, sc, qz
+
+
+# ---- FP8 e4m3fn (OCP) --------------------------------------------------------------------------
+def f32_to_e4m3fn_bits(a):
+    """RNE cast fp32 -> float8_e4m3fn bit pattern (torch's .to(torch.float8_e4m3fn): no saturation,
+    |x| > 464 -> NaN (0x7f), 448 < |x| <= 464 -> 448)."""
+    a = np.asarray(a, dtype=np.float32)
+    sign = (a.view(np.uint32) >> 31).astype(np.uint8) << 7
+    x = np.abs(a).astype(np.float64)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    nan = np.isnan(a)
+    # subnormal grid: multiples of 2^-9 below 2^-6
+    e = np.floor(np.log2(np.where(x > 0, x, 1.0)))
+    e = np.clip(e, -6, 8)
+    step = np.exp2(e - 3)
+    q = np.rint(x / step) * step              # RNE on the local grid (rint = half-even on the quotient)
+    # re-normalise when rounding crossed a binade
+    e2 = np.floor(np.log2(np.where(q > 0, q, 1.0)))
+    e2 = np.clip(e2, -6, 8)
+    mant = q / np.exp2(e2)                    # in [1,2) for normals, [0,1) for subnormals
+    is_sub = q < 2.0 ** -6
+    exp_field = np.where(is_sub, 0, e2 + 7).astype(np.int64)
+    man_field = np.where(is_sub, np.rint(q / 2.0 ** -9), np.rint((mant - 1.0) * 8)).astype(np.int64)
+    bits = (exp_field << 3) | man_field
+    over = q > 448.0
+    bits = np.where(over | nan, 0x7f, bits)
+    out = (bits.astype(np.uint8) | sign)
+    return out
+
+
+def e4m3fn_bits_to_f32(b):
+    b = np.asarray(b, dtype=np.uint8)
+    sign = np.where(b & 0x80, -1.0, 1.0)
+    e = ((b >> 3) & 0xf).astype(np.int64)
+    m = (b & 7).astype(np.float64)
+    v = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * np.exp2(e - 7.0))
+    v = np.where((b & 0x7f) == 0x7f, np.nan, v)
+    return (sign * v).astype(np.float32)
+
+
+def fp8_quant(w2d, dt):
+    """FloatQuantizer e4m3 sym weight path (quant.py:545-553 with qmax=448, :1061-1072, :1211):
+    s = absmax.clamp(1e-5)/448 ; q = e4m3(x / s). Returns (bits uint8 [G,g], scales [G,1])."""
+    mx = w2d.max(axis=-1, keepdims=True)
+    mn = w2d.min(axis=-1, keepdims=True)
+    s, _ = qparams_from_minmax(mn, mx, dt, True, -448.0, 448.0)
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        t = rnd(w2d / s, dt)                  # tensor / scales (+ zeros == 0) in dt
+    bits = f32_to_e4m3fn_bits(t)              # float_quantize(.float(), 4, 3) then .to(float8_e4m3fn)
+    return bits, s
