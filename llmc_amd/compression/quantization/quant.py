@@ -1,0 +1,314 @@
+"""Quantizers with llmc's operator surface, arithmetic in HIP (libllmc_hip.so).
+
+Mirrors llmc/compression/quantization/quant.py: class names, constructor kwargs, method names,
+argument meaning, return shapes/dtypes (BaseQuantizer :46-658, IntegerQuantizer :661-960,
+FloatQuantizer :963-1229).  In scope: calib_algo 'minmax' (the algorithm of every GPTQ/AWQ/RTN config
+named in BASELINE.json); granularity per_group / per_channel / per_token / per_tensor / per_head;
+FloatQuantizer e4m3 with the qtorch path pinned to torch.float8_e4m3fn's RNE cast.
+Out of scope (raise NotImplementedError): mse / learnable / hist / hqq range search, W48, per_block.
+
+Tensors must live on the GPU; there is no CPU fallback (see llmc_amd/_ffi.py).
+"""
+import torch
+
+from llmc_amd import _ffi
+
+
+def _rows(t):
+    """[G, g] geometry of an already reshaped tensor (reduction over the last dim)."""
+    g = t.shape[-1]
+    return t.numel() // g, g
+
+
+class BaseQuantizer(object):
+    def __init__(self, bit, symmetric, granularity, **kwargs):
+        self.bit = bit
+        self.sym = symmetric
+        self.granularity = granularity
+        self.kwargs = kwargs
+
+        self.calib_algo = self.kwargs.get('calib_algo', 'minmax')
+        if self.calib_algo not in ('minmax', 'static_minmax'):
+            raise NotImplementedError(
+                f'calib_algo={self.calib_algo}: only minmax ranges are on the accelerated path')
+
+        if self.granularity == 'per_group':
+            self.group_size = self.kwargs['group_size']
+        elif self.granularity == 'per_head':
+            self.head_num = self.kwargs['head_num']
+        elif self.granularity == 'per_block':
+            raise NotImplementedError('per_block (DeepSeek FP8 block-wise) is outside the hot path')
+
+        if self.kwargs.get('ste', False) or self.kwargs.get('ste_all', False):
+            raise NotImplementedError('STE rounding (training-time) is outside the hot path')
+        self.round_zp = self.kwargs.get('round_zp', True)
+
+    # -- views (quant.py:612-658) ---------------------------------------------------------------
+    def reshape_tensor(self, tensor, allow_padding=False):
+        if self.granularity == 'per_group':
+            if tensor.shape[-1] >= self.group_size:
+                if tensor.shape[-1] % self.group_size == 0:
+                    t = tensor.reshape(-1, self.group_size)
+                elif allow_padding:
+                    deficiency = self.group_size - tensor.shape[1] % self.group_size
+                    prefix = tensor.shape[:-1]
+                    pad_zeros = torch.zeros((*prefix, deficiency), device=tensor.device, dtype=tensor.dtype)
+                    t = torch.cat((tensor, pad_zeros), dim=-1).reshape(-1, self.group_size)
+                else:
+                    raise ValueError(
+                        f'Dimension {tensor.shape[-1]} not divisible by group size {self.group_size}')
+            else:
+                t = tensor
+        elif self.granularity == 'per_head':
+            t = tensor.reshape(self.head_num, -1)
+        else:
+            t = tensor
+        return t
+
+    def restore_tensor(self, tensor, shape):
+        if tensor.shape == shape:
+            return tensor
+        try:
+            return tensor.reshape(shape)
+        except RuntimeError:
+            deficiency = self.group_size - shape[1] % self.group_size
+            return tensor.reshape(*shape[:-1], -1)[..., :-deficiency]
+
+    # -- ranges -> qparams (quant.py:132-143, 545-559), fused in one kernel ------------------------
+    def _geometry(self, tensor):
+        """(G, g) of the [G, g] reduction view the reference reduces over."""
+        if self.granularity == 'per_tensor':
+            return 1, tensor.numel()
+        return _rows(tensor)
+
+    def _qparam_shape(self, tensor):
+        if self.granularity == 'per_tensor':
+            return ()
+        return (*tensor.shape[:-1], 1)
+
+    def _minmax_qparams(self, tensor):
+        """tensor: reshaped, contiguous, on GPU. Returns (scales, zeros) in tensor dtype."""
+        _ffi.require_gpu(tensor)
+        L = _ffi.lib()
+        tensor = tensor.contiguous()
+        G, g = self._geometry(tensor)
+        dt = _ffi.dt(tensor)
+        scales = torch.empty(G, dtype=tensor.dtype, device=tensor.device)
+        zeros = None if self.sym else torch.empty(G, dtype=tensor.dtype, device=tensor.device)
+        ws = _ffi.workspace(L.llmc_minmax_qparams_ws_bytes(G, g), tensor.device)
+        _ffi.check(L.llmc_minmax_qparams(
+            _ffi.ptr(tensor), dt, G, g, int(self.sym), int(self.round_zp), float(self.qmin),
+            float(self.qmax), _ffi.ptr(scales), _ffi.ptr(zeros), _ffi.ptr(ws), _ffi.stream()),
+            'llmc_minmax_qparams')
+        shp = self._qparam_shape(tensor)
+        scales = scales.reshape(shp)
+        # the reference returns torch.tensor(0.0) (0-dim fp32 on CPU) for symmetric zeros (quant.py:553)
+        zeros = torch.tensor(0.0) if self.sym else zeros.reshape(shp)
+        return scales, zeros
+
+
+class IntegerQuantizer(BaseQuantizer):
+    def __init__(self, bit, symmetric, granularity, **kwargs):
+        super().__init__(bit, symmetric, granularity, **kwargs)
+        self.quant_type = 'int-quant'
+        if 'int_range' in self.kwargs:
+            self.qmin = self.kwargs['int_range'][0]
+            self.qmax = self.kwargs['int_range'][1]
+        else:
+            if self.sym:
+                self.qmin = -(2 ** (self.bit - 1))
+                self.qmax = 2 ** (self.bit - 1) - 1
+            else:
+                self.qmin = 0.0
+                self.qmax = 2 ** self.bit - 1
+        self.qmin = torch.tensor(self.qmin)
+        self.qmax = torch.tensor(self.qmax)
+        self.dst_nbins = 2 ** bit
+
+    # ---- qparams ---------------------------------------------------------------------------------
+    def get_tensor_qparams(self, tensor, args={}):
+        """quant.py:690-697 -> (reshaped tensor, scales, zeros, qmax, qmin)."""
+        tensor = self.reshape_tensor(tensor)
+        scales, zeros = self._minmax_qparams(tensor)
+        return tensor, scales, zeros, self.qmax.to(tensor.device), self.qmin.to(tensor.device)
+
+    # ---- static arithmetic with given qparams (quant.py:699-717) ------------------------------------
+    def _static(self, tensor, scales, zeros, qmax, qmin, out_kind):
+        _ffi.require_gpu(tensor, scales)
+        if not self.round_zp:
+            raise NotImplementedError('round_zp=False quant() is outside the hot path')
+        L = _ffi.lib()
+        tensor = tensor.contiguous()
+        g = tensor.shape[-1] if self.granularity != 'per_tensor' else tensor.numel()
+        G = tensor.numel() // g
+        scales_f = scales.reshape(-1)
+        if scales_f.numel() == 1 and G > 1:
+            scales_f = scales_f.expand(G)
+        scales_f = scales_f.contiguous()
+        if scales_f.numel() != G:
+            raise ValueError(f'scales has {scales_f.numel()} entries, tensor has {G} groups')
+        zt = None
+        if torch.is_tensor(zeros) and zeros.dim() > 0 and zeros.numel() > 0:
+            zt = zeros.reshape(-1)
+            if zt.numel() == 1 and G > 1:
+                zt = zt.expand(G)
+            zt = zt.to(tensor.device).contiguous()
+            if not zt.is_floating_point():
+                zt = zt.to(scales_f.dtype)
+        elif torch.is_tensor(zeros) and zeros.dim() == 0 and float(zeros) != 0.0:
+            zt = torch.full((G,), float(zeros), dtype=scales_f.dtype, device=tensor.device)
+        elif not torch.is_tensor(zeros) and zeros not in (None, 0, 0.0):
+            zt = torch.full((G,), float(zeros), dtype=scales_f.dtype, device=tensor.device)
+        if out_kind == _ffi.OUT_FAKE:
+            out = torch.empty_like(tensor)
+        else:
+            odt = {_ffi.OUT_I32: torch.int32, _ffi.OUT_I8: torch.int8, _ffi.OUT_U8: torch.uint8}[out_kind]
+            out = torch.empty(tensor.shape, dtype=odt, device=tensor.device)
+        _ffi.check(L.llmc_quant_static(
+            _ffi.ptr(tensor), _ffi.dt(tensor), G, g, _ffi.ptr(scales_f), _ffi.dt(scales_f),
+            _ffi.ptr(zt), _ffi.dt(zt) if zt is not None else 0, float(qmin), float(qmax), out_kind,
+            _ffi.ptr(out), _ffi.stream()), 'llmc_quant_static')
+        return out
+
+    def _code_kind(self):
+        if self.bit == 8:
+            return _ffi.OUT_I8 if self.qmin != 0 else _ffi.OUT_U8
+        return _ffi.OUT_I32
+
+    def quant(self, tensor, scales, zeros, qmax, qmin):
+        """Integer-valued codes in the promoted float dtype, like the reference's quant()."""
+        codes = self._static(tensor, scales, zeros, qmax, qmin, _ffi.OUT_I32)
+        return codes.to(torch.promote_types(tensor.dtype, scales.dtype))
+
+    def dequant(self, tensor, scales, zeros):
+        return (tensor - zeros.to(tensor.device) if torch.is_tensor(zeros) else tensor - zeros) * scales
+
+    def quant_dequant(self, tensor, scales, zeros, qmax, qmin, output_scale_factor=1):
+        if output_scale_factor != 1:
+            raise NotImplementedError('output_scale_factor != 1 is outside the hot path')
+        return self._static(tensor, scales, zeros, qmax, qmin, _ffi.OUT_FAKE)
+
+    # ---- dynamic (fused min/max + quant) -----------------------------------------------------------
+    def _dynamic(self, tensor, out_kind, want_qparams):
+        _ffi.require_gpu(tensor)
+        L = _ffi.lib()
+        tensor = tensor.contiguous()
+        G, g = self._geometry(tensor)
+        dt = _ffi.dt(tensor)
+        if out_kind == _ffi.OUT_FAKE:
+            out = torch.empty_like(tensor)
+        else:
+            odt = {_ffi.OUT_I32: torch.int32, _ffi.OUT_I8: torch.int8, _ffi.OUT_U8: torch.uint8}[out_kind]
+            out = torch.empty(tensor.shape, dtype=odt, device=tensor.device)
+        scales = zeros = None
+        if want_qparams:
+            scales = torch.empty(G, dtype=tensor.dtype, device=tensor.device)
+            if not self.sym:
+                zeros = torch.empty(G, dtype=tensor.dtype, device=tensor.device)
+        ws = _ffi.workspace(L.llmc_quant_dynamic_ws_bytes(G, g), tensor.device)
+        _ffi.check(L.llmc_quant_dynamic(
+            _ffi.ptr(tensor), dt, G, g, int(self.sym), int(self.round_zp), float(self.qmin),
+            float(self.qmax), out_kind, _ffi.ptr(out), _ffi.ptr(scales), _ffi.ptr(zeros), _ffi.ptr(ws),
+            _ffi.stream()), 'llmc_quant_dynamic')
+        return out, scales, zeros
+
+    def fake_quant_weight_dynamic(self, weight, args={}):
+        """quant.py:833-869"""
+        if 'int_indices' in args or 'current_bit' in args:
+            raise NotImplementedError('mixed int/fp columns and current_bit are outside the hot path')
+        transpose = 'dim' in args and 'ic' in args['dim']
+        q_weight = weight.T if transpose else weight
+        org_w_shape = q_weight.shape
+        q_weight = self.reshape_tensor(q_weight)
+        q_weight, _, _ = self._dynamic(q_weight, _ffi.OUT_FAKE, False)
+        q_weight = self.restore_tensor(q_weight, org_w_shape)
+        return q_weight.T if transpose else q_weight
+
+    def fake_quant_weight_static(self, weight, args):
+        """quant.py:785-831"""
+        if 'int_indices' in args or 'rounding' in args or 'output_scale_factor' in args:
+            raise NotImplementedError('int_indices/rounding/output_scale_factor are outside the hot path')
+        transpose = 'dim' in args and 'ic' in args['dim']
+        q_weight = weight.T if transpose else weight
+        org_w_shape = q_weight.shape
+        org_w_dtype = q_weight.dtype
+        q_weight = self.reshape_tensor(q_weight)
+        q_weight = self.quant_dequant(q_weight, args['scales'], args['zeros'], args['qmax'], args['qmin'])
+        q_weight = self.restore_tensor(q_weight, org_w_shape).to(org_w_dtype)
+        return q_weight.T if transpose else q_weight
+
+    def fake_quant_act_dynamic(self, act, args={}):
+        """quant.py:753-783"""
+        if 'int_indices' in args or 'current_bit' in args:
+            raise NotImplementedError('mixed int/fp columns and current_bit are outside the hot path')
+        org_shape = act.shape
+        q_act = self.reshape_tensor(act)
+        q_act, _, _ = self._dynamic(q_act, _ffi.OUT_FAKE, False)
+        return self.restore_tensor(q_act, org_shape)
+
+    def fake_quant_act_static(self, act, args={}):
+        """quant.py:719-751"""
+        org_shape, org_dtype = act.shape, act.dtype
+        q_act = self.reshape_tensor(act)
+        q_act = self.quant_dequant(q_act, args['scales'], args['zeros'], args['qmax'], args['qmin'])
+        return self.restore_tensor(q_act, org_shape).to(org_dtype)
+
+    def _finish_real(self, weight, scales, zeros):
+        """common tail of real_quant_weight_* (quant.py:890-912)"""
+        if self.granularity == 'per_tensor':
+            qparams_shape = 1
+        else:
+            qparams_shape = (weight.shape[0], -1)
+        if not self.sym and self.round_zp:
+            zeros = zeros.to(weight.dtype)
+        elif self.sym:
+            zeros = None
+        if zeros is not None:
+            zeros = zeros.view(qparams_shape)
+        scales = scales.view(qparams_shape)
+        return weight, scales, zeros
+
+    def real_quant_weight_static(self, weight, args):
+        """quant.py:871-914 -> (int codes [R,K], scales [R,K/g], zeros [R,K/g] | None)"""
+        if 'output_scale_factor' in args:
+            raise NotImplementedError('output_scale_factor is outside the hot path')
+        org_w_shape = weight.shape
+        scales, zeros = args['scales'], args['zeros']
+        w = self.reshape_tensor(weight)
+        codes = self._static(w, scales, zeros, args['qmax'], args['qmin'], self._code_kind())
+        codes = self.restore_tensor(codes, org_w_shape)
+        return self._finish_real(codes, scales, zeros)
+
+    def real_quant_weight_dynamic(self, weight, args={}):
+        """quant.py:916-953"""
+        org_w_shape = weight.shape
+        w = self.reshape_tensor(weight)
+        codes, scales, zeros = self._dynamic(w, self._code_kind(), True)
+        codes = self.restore_tensor(codes, org_w_shape)
+        if self.sym:
+            zeros = torch.tensor(0.0)
+        return self._finish_real(codes, scales, zeros)
+
+    def __repr__(self):
+        return (f'IntegerQuantizer(bit={self.bit}, sym={self.sym},'
+                f'granularity={self.granularity},'
+                f'kwargs={self.kwargs}, qmin={self.qmin}, qmax={self.qmax})')
+
+
+def pack_lsb(codes, bits):
+    """VllmRealQuantLinear.pack's integer part on the GPU (module_utils.py:836-862)."""
+    _ffi.require_gpu(codes)
+    L = _ffi.lib()
+    codes = codes.contiguous()
+    if codes.dtype == torch.int32:
+        kind = _ffi.OUT_I32
+    elif codes.dtype == torch.int8:
+        kind = _ffi.OUT_I8
+    else:
+        raise ValueError(f'pack_lsb: codes must be int32 or int8, got {codes.dtype}')
+    R, K = codes.shape
+    pf = 32 // bits
+    packed = torch.empty((R, (K + pf - 1) // pf), dtype=torch.int32, device=codes.device)
+    _ffi.check(L.llmc_pack_lsb(_ffi.ptr(codes), kind, R, K, int(bits), _ffi.ptr(packed), _ffi.stream()),
+               'llmc_pack_lsb')
+    return packed

@@ -1,0 +1,136 @@
+"""HIP quantizer kernels (through the Python operator surface -> C ABI) vs the numpy oracle: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import quant_ref as Q
+
+pytestmark = pytest.mark.gpu
+
+TD = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}
+
+
+def dev(a, dt):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(TD[dt]).cuda()
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def make_quantizer(bit, sym, gran, gs):
+    from llmc_amd.compression.quantization import IntegerQuantizer
+    kw = dict(group_size=gs) if gs else {}
+    return IntegerQuantizer(int(bit), bool(sym), gran, **kw)
+
+
+def test_golden_cases_through_hip():
+    g = load_golden('quant')
+    for ci in range(int(g['n_cases'])):
+        p = f'c{ci}_'
+        bit, sym, gs, qmin, qmax = g[p + 'meta']
+        dt, gran = str(g[p + 'dt']), str(g[p + 'gran'])
+        q = make_quantizer(bit, sym, gran, int(gs))
+        w = dev(g[p + 'w'], dt)
+        tag = f'case {ci}: {dt} bit={bit} sym={sym} {gran} g={gs}'
+        _, s, z, _, _ = q.get_tensor_qparams(w)
+        assert s.dtype == TD[dt]
+        np.testing.assert_array_equal(bits(host(s).reshape(-1)), bits(g[p + 'scales']), err_msg=tag)
+        if not sym:
+            np.testing.assert_array_equal(host(z).reshape(-1), g[p + 'zeros'], err_msg=tag)
+        fq = q.fake_quant_weight_dynamic(w)
+        assert fq.dtype == TD[dt] and fq.shape == w.shape
+        np.testing.assert_array_equal(bits(host(fq)), bits(g[p + 'fake']), err_msg=tag)
+        codes, rs, rz = q.real_quant_weight_dynamic(w)
+        assert str(codes.dtype) == str(g[p + 'codes_dtype']), tag
+        np.testing.assert_array_equal(codes.cpu().numpy().astype(np.int32), g[p + 'codes'], err_msg=tag)
+        np.testing.assert_array_equal(bits(host(rs)), bits(g[p + 'rscales']), err_msg=tag)
+        if not sym:
+            np.testing.assert_array_equal(rz.cpu().numpy().astype(np.int32), g[p + 'rzeros'], err_msg=tag)
+        else:
+            assert rz is None
+
+
+def test_golden_static_through_hip():
+    g = load_golden('quant')
+    for ci in range(int(g['n_static'])):
+        p = f's{ci}_'
+        bit, sym, gs, qmin, qmax = g[p + 'meta']
+        wdt, sdt, zdt = [str(x) for x in g[p + 'dts']]
+        q = make_quantizer(bit, sym, 'per_group', int(gs))
+        w = dev(g[p + 'w'], wdt)
+        s = dev(g[p + 'scales'].reshape(-1, 1), sdt)
+        z = dev(g[p + 'zeros'].reshape(-1, 1), zdt) if zdt != 'none' else torch.tensor(0.0)
+        args = {'scales': s, 'zeros': z, 'qmax': torch.tensor(qmax), 'qmin': torch.tensor(qmin)}
+        fq = q.fake_quant_weight_static(w, dict(args))
+        assert str(fq.dtype) == str(g[p + 'fake_dtype'])
+        np.testing.assert_array_equal(bits(host(fq)), bits(g[p + 'fake']), err_msg=f'static {ci}')
+        codes, _, _ = q.real_quant_weight_static(w, dict(args))
+        np.testing.assert_array_equal(codes.cpu().numpy().astype(np.int32), g[p + 'codes'])
+
+
+@pytest.mark.parametrize('dt', ['f16', 'bf16', 'f32'])
+@pytest.mark.parametrize('cfg', [(4, False, 'per_group', 128), (4, True, 'per_group', 128),
+                                 (8, True, 'per_channel', 0), (8, True, 'per_tensor', 0),
+                                 (4, False, 'per_group', 64)])
+def test_llama_shape_vs_oracle(dt, cfg):
+    bit, sym, gran, gs = cfg
+    R, K = 1024, 4096
+    gen = torch.Generator().manual_seed(5 + bit)
+    w = (torch.randn(R, K, generator=gen) * 0.02)
+    w[:, ::97] *= 20
+    w = w.to(TD[dt])
+    wn = w.float().numpy()
+    q = make_quantizer(bit, sym, gran, gs)
+    qmin, qmax = Q.int_range(bit, sym)
+    w2 = Q.reshape_rows(wn, gran, gs or None)
+    fq_ref, s_ref, z_ref = Q.fake_quant_dynamic(w2, dt, sym, qmin, qmax)
+    wd = w.cuda()
+    fq = q.fake_quant_weight_dynamic(wd)
+    np.testing.assert_array_equal(bits(host(fq)), bits(fq_ref.reshape(R, K)))
+    codes_ref, _, _ = Q.real_quant_dynamic(w2, dt, sym, qmin, qmax)
+    codes, rs, rz = q.real_quant_weight_dynamic(wd)
+    np.testing.assert_array_equal(codes.cpu().numpy().astype(np.int32), codes_ref.reshape(R, K))
+    np.testing.assert_array_equal(bits(host(rs).reshape(-1)), bits(s_ref.reshape(-1)))
+
+
+def test_ragged_and_tiny_shapes():
+    # rows not a multiple of the wave's rows-per-wave, g not a multiple of the 16-B vector
+    for (R, K, gran, gs) in [(3, 130, 'per_channel', 0), (1, 8, 'per_channel', 0), (7, 96, 'per_group', 32),
+                             (5, 70000, 'per_channel', 0), (1, 200000, 'per_tensor', 0)]:
+        gen = torch.Generator().manual_seed(R * 1000 + K)
+        w = torch.randn(R, K, generator=gen).half()
+        q = make_quantizer(4, False if gran != 'per_tensor' else True, gran, gs)
+        sym = q.sym
+        qmin, qmax = Q.int_range(4, sym)
+        w2 = Q.reshape_rows(w.float().numpy(), gran, gs or None)
+        fq_ref, _, _ = Q.fake_quant_dynamic(w2, 'f16', sym, qmin, qmax)
+        fq = q.fake_quant_weight_dynamic(w.cuda())
+        np.testing.assert_array_equal(bits(host(fq)), bits(fq_ref.reshape(R, K)), err_msg=f'{R}x{K} {gran}')
+
+
+def test_pack_lsb_vs_golden_and_full_size():
+    from llmc_amd.compression.quantization import pack_lsb
+    g = load_golden('pack')
+    for ci in range(int(g['n_vllm'])):
+        codes = torch.from_numpy(g[f'v{ci}_codes']).cuda()
+        bit = int(g[f'v{ci}_bit'])
+        if bit == 8:
+            codes = codes.to(torch.int8)
+        packed = pack_lsb(codes, bit)
+        np.testing.assert_array_equal(packed.cpu().numpy(), g[f'v{ci}_packed'])
+    codes = torch.randint(-8, 8, (4096, 4096), dtype=torch.int32)
+    packed = pack_lsb(codes.cuda(), 4)
+    np.testing.assert_array_equal(packed.cpu().numpy(), Q.pack_lsb(codes.numpy(), 4))
+
+
+def test_cpu_tensor_is_refused():
+    from llmc_amd import _ffi
+    q = make_quantizer(4, True, 'per_group', 128)
+    with pytest.raises(_ffi.LlmcHipError):
+        q.fake_quant_weight_dynamic(torch.randn(4, 128).half())
