@@ -110,7 +110,7 @@ int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* 
  * full symmetric on output. n_before / n_after are the reference's `nsamples` before and after the call
  * (counts of sequences, not tokens). Products are exact (16-bit x 16-bit in fp32), accumulation is fp32
  * on the MFMA pipe in a fixed, launch-independent order (deterministic). */
-size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K);
+size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx);
 int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, int64_t K, int64_t ldx,
                        double n_before, double n_after, void* ws, llmc_stream_t stream);
 

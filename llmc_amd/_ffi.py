@@ -26,6 +26,8 @@ SIGNATURES = {
     'llmc_quant_dynamic_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_quant_dynamic': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'llmc_pack_lsb': (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp]),
+    'llmc_hessian_accum_ws_bytes': (_sz, [_i64, _i64, _i64]),
+    'llmc_hessian_accum': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _vp, _vp]),
 }
 
 _lib = None

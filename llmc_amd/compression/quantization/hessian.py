@@ -1,0 +1,42 @@
+"""Hessian accumulation for GPTQ on the MFMA pipe (GPTQ.add_batch, gptq.py:254-295)."""
+import torch
+
+from llmc_amd import _ffi
+
+
+class HessianAccumulator:
+    """Owns H [K,K] fp32 and the partial-tile workspace; `add(inp)` has add_batch's arithmetic:
+    H <- H * n/(n+b) + (2/(n+b)) * X^T X with b = number of sequences in `inp`."""
+
+    def __init__(self, columns, device):
+        self.K = int(columns)
+        self.H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
+        self.nsamples = 0
+        self._ws = None
+
+    def add(self, inp):
+        _ffi.require_gpu(inp)
+        L = _ffi.lib()
+        if inp.dim() == 2:
+            inp = inp.unsqueeze(0)
+        b = inp.shape[0]
+        x = inp.reshape(-1, inp.shape[-1])
+        if x.dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f'hessian: activations must be fp16/bf16 (model dtype), got {x.dtype}')
+        if x.stride(-1) != 1 or x.stride(0) % 8 != 0 or x.data_ptr() % 16 != 0:
+            x = x.contiguous()
+        T, K = x.shape
+        if K != self.K:
+            raise ValueError(f'hessian: expected {self.K} channels, got {K}')
+        ldx = x.stride(0)
+        need = L.llmc_hessian_accum_ws_bytes(T, K, ldx)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = _ffi.workspace(need, x.device)
+        _ffi.check(L.llmc_hessian_accum(
+            _ffi.ptr(self.H), _ffi.ptr(x), _ffi.dt(x), T, K, ldx, float(self.nsamples),
+            float(self.nsamples + b), _ffi.ptr(self._ws), _ffi.stream()), 'llmc_hessian_accum')
+        self.nsamples += b
+        return self.H
+
+    def release_workspace(self):
+        self._ws = None

@@ -1,0 +1,374 @@
+// hessian_syrk.hip — K1: H <- a*H + b*X^T X on the MFMA pipe (GPTQ.add_batch, gptq.py:254-295).
+//
+// X is [T tokens, K channels] 16-bit, channel-contiguous, so BOTH MFMA operands are strided along the
+// reduction (token) axis. Tiles are therefore staged token-major in LDS exactly as they lie in HBM
+// (LDS-DMA, 16 B per lane) and transposed on the way to the registers by ds_read_b64_tr_b16.
+//
+// Decomposition
+//   output tile   256 x 256 channels (lower triangle of the tile grid only), 8 waves as 2(M) x 4(N),
+//                 each wave 128 x 64 = 4 x 2 MFMA 32x32x16 accumulators (128 VGPRs)
+//   K-step        64 tokens: A panel [64][256] + B panel [64][256] 16-bit = 64 KiB, 2 stages = 128 KiB LDS
+//   unit          (tile, token chunk s of S); units are dealt round-robin to a persistent grid of one
+//                 workgroup per CU so that the 32 workgroups of an XCD sit on 32 consecutive tiles of a
+//                 4x4-superblock order (12 shared panels in the XCD's L2) at the SAME token position.
+//   partials      every unit writes its 256x256 fp32 partial in MFMA-fragment order (16-B stores) to the
+//                 workspace; k_syrk_fixup sums the S partials of a tile in chunk order (deterministic),
+//                 applies H <- a*H + b*sum and mirrors the tile to the upper triangle.
+// LDS bank layout: a 4-token x 64-B tr16 read by a 32-lane half hits 4 rows at a 512-B stride; the 64-B
+// unit index is XOR-ed with (token & 3) so the four rows land on four different bank quarters. The
+// swizzle is applied to the DMA's per-lane SOURCE address (LDS image stays lane-linear) and to the read.
+#include "common.h"
+
+namespace llmc {
+
+static constexpr int TM = 256;       // tile edge (channels)
+static constexpr int BK = 64;        // tokens per K-step
+static constexpr int PANEL_BYTES = BK * TM * 2;  // 32 KiB
+static constexpr int STAGE_BYTES = 2 * PANEL_BYTES;
+static constexpr int SYRK_THREADS = 512;
+static constexpr int SYRK_LDS = 2 * STAGE_BYTES;  // 128 KiB
+static constexpr int TILE_FLOATS = TM * TM;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define LDS_AS __attribute__((address_space(3)))
+
+struct TileIdx {
+    int bi, bj;
+    bool valid;
+};
+
+// tile order: 4x4 superblocks of the lower triangle, superblock rows top to bottom; inside an
+// off-diagonal superblock row-major 4x4, inside a diagonal superblock the 10 lower-triangular tiles.
+__host__ __device__ inline int tiles_padded(int nb) {
+    int sb = (nb + 3) / 4;
+    return 8 * sb * sb + 2 * sb;
+}
+__host__ __device__ inline TileIdx decode_tile(int ti, int nb) {
+    int sbi = (int)((sqrtf(4.0f + 32.0f * (float)ti) - 2.0f) / 16.0f);
+    while (8 * (sbi + 1) * (sbi + 1) + 2 * (sbi + 1) <= ti) ++sbi;
+    while (sbi > 0 && 8 * sbi * sbi + 2 * sbi > ti) --sbi;
+    int rem = ti - (8 * sbi * sbi + 2 * sbi);
+    int sbj, r, c;
+    if (rem < 16 * sbi) {
+        sbj = rem >> 4;
+        int pos = rem & 15;
+        r = pos >> 2;
+        c = pos & 3;
+    } else {
+        sbj = sbi;
+        int pos = rem - 16 * sbi;
+        r = pos < 1 ? 0 : (pos < 3 ? 1 : (pos < 6 ? 2 : 3));
+        c = pos - r * (r + 1) / 2;
+    }
+    TileIdx t;
+    t.bi = 4 * sbi + r;
+    t.bj = 4 * sbj + c;
+    t.valid = t.bi < nb;
+    return t;
+}
+
+template <int DT> struct Mfma;
+template <> struct Mfma<LLMC_BF16> {
+    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<LLMC_F16> {
+    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ s16x8 tr_frag(LDS_AS char* p, int imm0) {
+    // two 4-token transposed reads -> 8 consecutive tokens of one channel per lane
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p + imm0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p + imm0 + 4 * TM * 2));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// One LDS-DMA piece: 64 lanes x 16 B from buffer(rsrc)+voff[lane] to LDS lds_addr + 16*lane.
+// Issued from inline asm ON PURPOSE: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
+// ds_read that follows a compiler-visible LDS-DMA (it cannot prove the two do not alias), which would
+// serialise the prefetch of K-step k+1 with the MFMAs of K-step k. The asm form is invisible to that
+// pass; completion is waited for by hand (dma_wait_all) before the barrier that publishes the stage.
+// M0 (LDS base of the DMA) is written in the same statement and restored; s_nop covers the
+// SGPR->VMEM and M0->VMEM wait states that hipcc does not pad inside an asm string.
+__device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_addr)
+        : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct SyrkArgs {
+    const char* X;     // [T, K] 16-bit, row stride ldx elements
+    int64_t T;
+    int64_t ldx;       // elements
+    int K;
+    int nb;            // ceil(K / 256)
+    int ntiles_p;      // padded tile count (tiles_padded(nb))
+    int S;             // token chunks
+    int nk;            // ceil(T / 64)
+    float* part;       // [S * ntiles_p][256*256] fp32, fragment order
+};
+
+template <int DT>
+__global__ __launch_bounds__(SYRK_THREADS) void k_syrk(SyrkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+
+    // ---- DMA geometry: instruction q of wave wv fills LDS KiB-block (q*8 + wv) of a stage: blocks 0..31
+    // are the A panel (2 token rows each), 32..63 the B panel. Lane l -> row (l>>5), physical 16-B chunk (l&31).
+    const int lr = lane >> 5;
+    const int c16 = lane & 31;
+    const int row_lo = 2 * wv + lr;  // token row inside the 16-row slab this instruction group covers
+    const int u_log = (c16 >> 2) ^ (row_lo & 3);        // logical 64-B unit held by this physical slot
+    const int ch_off = (u_log * 4 + (c16 & 3)) * 8;      // logical channel offset inside the panel
+    const int64_t row_bytes = a.ldx * 2;
+
+    // ---- fragment read geometry (see file header and tools/probes/probe_mfma_tr16.hip, H1/H2)
+    const int p = lane & 15;
+    const int trow = 8 * (lane >> 5) + (p >> 2);              // + 16*kk (+4 for the second read)
+    const int sub = 32 * ((lane >> 4) & 1) + 8 * (p & 3);     // byte offset inside the 64-B unit
+    int offA[4], offB[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) offA[m] = trow * (TM * 2) + (((4 * wm + m) ^ (p >> 2)) << 6) + sub;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        offB[n] = trow * (TM * 2) + (((2 * wn + n) ^ (p >> 2)) << 6) + sub;
+
+    const int G = gridDim.x;
+    const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical id
+    const int nunits = a.S * a.ntiles_p;
+
+    for (int u = lw; u < nunits; u += G) {
+        const int s = u / a.ntiles_p;
+        const int ti = u - s * a.ntiles_p;
+        const TileIdx t = decode_tile(ti, a.nb);
+        if (!t.valid) continue;
+        const bool diag = t.bi == t.bj;
+        const int ks0 = (int)(((int64_t)s * a.nk) / a.S);
+        const int ks1 = (int)(((int64_t)(s + 1) * a.nk) / a.S);
+
+        // buffer descriptor over the chunk's rows: reads past row T return 0 (token tail), channel
+        // overrun past K only pollutes outputs that the fixup never stores.
+        const char* base = a.X + (int64_t)ks0 * BK * row_bytes;
+        int64_t rem_bytes = (a.T - (int64_t)ks0 * BK) * row_bytes;
+        const uint32_t nrec = rem_bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)rem_bytes;
+        i32x4 rsrc;
+        rsrc[0] = (int)(uint32_t)(uintptr_t)base;
+        rsrc[1] = (int)((uint32_t)((uintptr_t)base >> 32) & 0xffffu);  // stride 0
+        rsrc[2] = (int)nrec;
+        rsrc[3] = 0x00020000;
+        const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
+        const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
+        const uint32_t slab = (uint32_t)(16 * row_bytes);  // 16 token rows per instruction index q
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        auto stage = [&](int buf, int ks) {
+            const uint32_t koff = (uint32_t)((int64_t)(ks - ks0) * BK * row_bytes);
+            const uint32_t dst = lds_base + buf * STAGE_BYTES + wv * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma16(rsrc, vA + koff + q * slab, dst + q * 8192);
+            if (!diag) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma16(rsrc, vB + koff + q * slab, dst + PANEL_BYTES + q * 8192);
+            }
+        };
+
+        int cur = 0;
+        if (ks0 < ks1) stage(0, ks0);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            dma_wait_all();   // this wave's DMA pieces have landed
+            __syncthreads();  // everyone's pieces landed; previous stage fully read
+            if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);
+            LDS_AS char* pa = lds + cur * STAGE_BYTES;
+            LDS_AS char* pb = diag ? pa : pa + PANEL_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                s16x8 fa[4], fb[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) fa[m] = tr_frag(pa + offA[m], kk * 16 * TM * 2);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) fb[n] = tr_frag(pb + offB[n], kk * 16 * TM * 2);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = Mfma<DT>::run(fa[m], fb[n], acc[m][n]);
+            }
+            cur ^= 1;
+        }
+        __syncthreads();  // all waves done with LDS before the next unit's first stage
+
+        // ---- partial tile in fragment order: ((wv*4+m)*2+n)*4+q -> 64 lanes x float4
+        float* slot = a.part + (int64_t)u * TILE_FLOATS;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2],
+                               acc[m][n][4 * q + 3]};
+                    int idx = ((((wv * 4 + m) * 2 + n) * 4 + q) * 64 + lane);
+                    *reinterpret_cast<f32x4*>(slot + (int64_t)idx * 4) = v;
+                }
+    }
+}
+
+// Sum the S partials of each tile (chunk order), H <- alpha*H + beta*sum, mirror to the upper triangle.
+// One thread per float4 of the fragment-order tile: idx -> (wv,m,n,q,lane) -> rows i0..i0+3, column j.
+__global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ part, float* __restrict__ H,
+                                                    int K, int nb, int ntiles_p, int S, float alpha,
+                                                    float beta) {
+    const int ti = blockIdx.y;
+    const TileIdx t = decode_tile(ti, nb);
+    if (!t.valid) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // 0 .. 16383
+    const int lane = idx & 63;
+    const int q = (idx >> 6) & 3;
+    const int n = (idx >> 8) & 1;
+    const int m = (idx >> 9) & 3;
+    const int wv = idx >> 11;
+    const int wm = wv >> 2, wn = wv & 3;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float* slot = part + ((int64_t)s * ntiles_p + ti) * TILE_FLOATS;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slot + (int64_t)idx * 4);
+        sum += v;
+    }
+    const int i0 = t.bi * TM + wm * 128 + m * 32 + 8 * q + 4 * (lane >> 5);
+    const int j = t.bj * TM + wn * 64 + n * 32 + (lane & 31);
+    if (j >= K) return;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int i = i0 + r;
+        if (i < K) {
+            float h = beta * sum[r];
+            if (alpha != 0.0f) h += alpha * H[(int64_t)i * K + j];
+            o[r] = h;
+            H[(int64_t)i * K + j] = h;
+        }
+    }
+    if (t.bi != t.bj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i0 + r < K) H[(int64_t)j * K + i0 + r] = o[r];
+    }
+}
+
+static inline int choose_chunks(int ntiles_real, int nk, int64_t x_bytes, int ncu) {
+    // pick S in [Smin, 16]: maximise occupancy of the last round, prefer fewer chunks on ties
+    int smin = (int)(x_bytes / (1ll << 31)) + 1;
+    int best = smin;
+    double best_eff = -1.0;
+    for (int S = smin; S <= 16 || S == smin; ++S) {
+        if (S > nk && S > smin) break;
+        int64_t units = (int64_t)ntiles_real * S;
+        double eff = (double)units / (double)(ceil_div64(units, ncu) * ncu);
+        eff -= 0.004 * (S - 1);  // each extra chunk costs a partial tile write + read
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = S;
+        }
+    }
+    return best;
+}
+
+}  // namespace llmc
+
+using namespace llmc;
+
+static int syrk_geometry(int64_t T, int64_t K, int64_t ldx, int* nb, int* ntp, int* S, int* nk) {
+    *nb = (int)ceil_div64(K, TM);
+    *ntp = tiles_padded(*nb);
+    *nk = (int)ceil_div64(T, BK);
+    int real = (*nb) * (*nb + 1) / 2;
+    *S = choose_chunks(real, *nk, T * ldx * 2, 256);
+    if (*S > *nk) *S = *nk;
+    if (*S < 1) *S = 1;
+    return 0;
+}
+
+extern "C" size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx) {
+    if (T <= 0 || K <= 0 || ldx < K) return 0;
+    int nb, ntp, S, nk;
+    syrk_geometry(T, K, ldx, &nb, &ntp, &S, &nk);
+    return (size_t)S * ntp * TILE_FLOATS * sizeof(float);
+}
+
+extern "C" int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, int64_t K, int64_t ldx,
+                                  double n_before, double n_after, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_accum: X must be f16 or bf16");
+    LLMC_REQUIRE(H && X && ws && T > 0 && K > 0, "hessian_accum: null/empty argument");
+    LLMC_REQUIRE(ldx >= K && ldx % 8 == 0 && ((uintptr_t)X & 15) == 0, "hessian_accum: X rows must be 16-B aligned");
+    LLMC_REQUIRE(n_after > 0, "hessian_accum: n_after must be positive");
+    LLMC_REQUIRE(K < (1 << 30), "hessian_accum: K too large");
+    hipStream_t st = (hipStream_t)stream;
+    int nb, ntp, S, nk;
+    syrk_geometry(T, K, ldx, &nb, &ntp, &S, &nk);
+    SyrkArgs a;
+    a.X = (const char*)X;
+    a.T = T;
+    a.ldx = ldx;
+    a.K = (int)K;
+    a.nb = nb;
+    a.ntiles_p = ntp;
+    a.S = S;
+    a.nk = nk;
+    a.part = (float*)ws;
+    static bool attr_set[2] = {false, false};
+    if (dt == LLMC_BF16) {
+        if (!attr_set[0]) {
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL((k_syrk<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+    } else {
+        if (!attr_set[1]) {
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL((k_syrk<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+    }
+    LLMC_LAUNCH_CHECK();
+    float alpha = (float)(n_before / n_after);
+    float beta = (float)(2.0 / n_after);
+    hipLaunchKernelGGL(k_syrk_fixup, dim3(TILE_FLOATS / 4 / 256, ntp), dim3(256), 0, st, (const float*)ws, H,
+                       (int)K, nb, ntp, S, alpha, beta);
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
