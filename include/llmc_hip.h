@@ -203,6 +203,14 @@ int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_t R, int64_
 int llmc_clamp_groups(void* W, int dt, int64_t R, int64_t K, int64_t g, const void* min_val,
                       const void* max_val, llmc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Test hook (tests/test_sgemm_gpu.py only): the internal fp32-MFMA GEMM used by K3/K4.
+ * C (op) op(A)[M x Kd] . op(B)[Kd x N]; epilogue 0: C -= AB, 1: C = AB, 2: C = -AB.
+ * ---------------------------------------------------------------------------------------------- */
+int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M,
+                    int N, int Kd, int TA, int TB, int epilogue, int a_upper, int a_lower, int b_upper,
+                    int c_upper_only, llmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,15 @@ SIGNATURES = {
     'llmc_pack_lsb': (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp]),
     'llmc_hessian_accum_ws_bytes': (_sz, [_i64, _i64, _i64]),
     'llmc_hessian_accum': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _vp, _vp]),
+    'llmc_hessian_prep_ws_bytes': (_sz, [_i64]),
+    'llmc_hessian_prep': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
+    'llmc_chol_inv_upper_ws_bytes': (_sz, [_i64]),
+    'llmc_chol_inv_upper': (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    'llmc_gptq_quantize_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_gptq_quantize': (_i32, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
+                                  _i32, _vp, _vp]),
+    'llmc_test_sgemm': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                               _i32, _i32, _vp]),
 }
 
 _lib = None

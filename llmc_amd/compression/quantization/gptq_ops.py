@@ -1,0 +1,83 @@
+"""Functional wrappers over the GPTQ entry points of libllmc_hip.so (K2, K3, K4)."""
+import torch
+
+from llmc_amd import _ffi
+
+
+def hessian_prep(H, W, perm, percdamp):
+    """gptq.py:135-152,169-171. H [K,K] fp32 (dead diagonal fixed in place), W [R,K] any float dtype.
+    Returns (Hout fp32 [K,K] permuted + damped, Wout fp32 [R,K] permuted, dead columns zeroed)."""
+    _ffi.require_gpu(H, W, perm)
+    L = _ffi.lib()
+    R, K = W.shape
+    W = W.contiguous()
+    Hout = torch.empty_like(H)
+    Wout = torch.empty((R, K), dtype=torch.float32, device=W.device)
+    ws = _ffi.workspace(L.llmc_hessian_prep_ws_bytes(K), W.device)
+    if perm is not None:
+        perm = perm.to(torch.int64).contiguous()
+    _ffi.check(L.llmc_hessian_prep(_ffi.ptr(H), _ffi.ptr(W), _ffi.dt(W), R, K, _ffi.ptr(perm), float(percdamp),
+                                   _ffi.ptr(Hout), _ffi.ptr(Wout), _ffi.ptr(ws), _ffi.stream()),
+               'llmc_hessian_prep')
+    return Hout, Wout
+
+
+_chol_ws = {}
+
+
+def chol_inv_upper(H, check=True):
+    """gptq.py:172-174 in one call: returns U upper with H^-1 = U^T U. H is overwritten."""
+    _ffi.require_gpu(H)
+    L = _ffi.lib()
+    K = H.shape[0]
+    need = L.llmc_chol_inv_upper_ws_bytes(K)
+    key = (H.device, )
+    ws = _chol_ws.get(key)
+    if ws is None or ws.numel() < need + 256:
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=H.device)
+        _chol_ws[key] = ws
+    off = (-ws.data_ptr()) % 256
+    info = torch.zeros(1, dtype=torch.int32, device=H.device)
+    _ffi.check(L.llmc_chol_inv_upper(_ffi.ptr(H), K, ws.data_ptr() + off, _ffi.ptr(info), _ffi.stream()),
+               'llmc_chol_inv_upper')
+    if check:
+        i = int(info.item())
+        if i != 0:
+            raise RuntimeError(f'chol_inv_upper: matrix is not positive definite (leading minor {i})')
+    return H
+
+
+def release_workspaces():
+    _chol_ws.clear()
+
+
+def gptq_quantize(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, col_group=None, scales=None,
+                  zeros=None, want_losses=True, blocksize=128):
+    """gptq.py:199-244. W [R,K] fp32 (overwritten with the running weights), Hinv [K,K] fp32 upper.
+    Returns (tmp [R,K], losses [R,K] | None, scales [R,ng], zeros [R,ng] | None)."""
+    _ffi.require_gpu(W, Hinv)
+    L = _ffi.lib()
+    R, K = W.shape
+    per_channel = not group_size
+    ng = 1 if per_channel else (K + group_size - 1) // group_size
+    static_mode = static_groups or per_channel
+    dev = W.device
+    if static_mode:
+        scales = scales.to(device=dev, dtype=torch.float32).reshape(R, ng).contiguous()
+        if zeros is not None:
+            zeros = zeros.to(device=dev, dtype=torch.float32).reshape(R, ng).contiguous()
+        elif not sym:
+            raise ValueError('gptq_quantize: zeros required for asymmetric static qparams')
+    else:
+        scales = torch.empty((R, ng), dtype=torch.float32, device=dev)
+        zeros = torch.empty((R, ng), dtype=torch.float32, device=dev)
+    if col_group is not None:
+        col_group = col_group.to(device=dev, dtype=torch.int32).contiguous()
+    tmp = torch.empty_like(W)
+    losses = torch.empty_like(W) if want_losses else None
+    ws = _ffi.workspace(L.llmc_gptq_quantize_ws_bytes(R, K), dev)
+    _ffi.check(L.llmc_gptq_quantize(
+        _ffi.ptr(W), _ffi.ptr(Hinv), R, K, int(bool(sym)), float(qmin), float(qmax), int(group_size or 0),
+        int(bool(static_groups)), _ffi.ptr(col_group), _ffi.ptr(scales), _ffi.ptr(zeros), _ffi.ptr(tmp),
+        _ffi.ptr(losses), int(blocksize), _ffi.ptr(ws), _ffi.stream()), 'llmc_gptq_quantize')
+    return tmp, losses, scales, zeros

@@ -1,0 +1,245 @@
+// gptq_loop.hip — K4: GPTQ.weight_transform (gptq.py:199-244), the blocked column loop.
+//
+// Rows of W are independent given U (= Hinv, the upper factor), so the serial part is 128 dependent
+// column steps per 128-column block. In-block kernel: a wave owns 4 rows, 16 lanes per row, lane p owns
+// columns p, p+16, ..., p+112 of the block (interleaved so every lane has the same amount of trailing
+// work at every step). Step i: the owner's current w_i is broadcast inside the 16-lane group
+// (ds_swizzle), every lane evaluates the quantizer chain and err = (w - q) / d redundantly, then updates
+// its own later columns  w_j <- w_j - round(err * U[i][j])  (two roundings, like the reference's
+// `W1[:, i:] -= err1.unsqueeze(1).matmul(Hinv1[i, i:].unsqueeze(0))`). The U block lives in LDS in the
+// lanes' ownership order with its diagonal and lower part zeroed, so no predicate is needed and each
+// lane's registers end up holding exactly `tmp` (the weight of each column at the time it was visited).
+// Trailing update W[:, i2:] -= Err1 @ U[i1:i2, i2:] runs on the fp32 MFMA pipe (sgemm.hip) with the
+// k-ordered fma chain that reproduces the reference's CPU sgemm bit for bit.
+#include "common.h"
+#include "quant_math.h"
+#include "sgemm.h"
+
+namespace llmc {
+
+static constexpr int BS = 128;  // GPTQ blocksize
+
+template <int PO> __device__ __forceinline__ float group_bcast(float v) {
+    // lane' = (lane & 0x10) | PO inside each 32-lane half: broadcast of lane PO of every 16-lane group
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x10 | (PO << 5)));
+}
+
+struct GptqBlockArgs {
+    const float* W;       // [R, K] running weights (panel read at cols i1..i1+count)
+    const float* U;       // [K, K] upper factor
+    float* Wout;          // [R, K] tmp
+    float* losses;        // [R, K] or null
+    float* Err;           // [R, 128] err of this block
+    float* scales;        // [R, ng]
+    float* zeros;         // [R, ng] or null (sym static)
+    const int32_t* col_group;  // [K] group of processed column (static mode)
+    int64_t R;
+    int K;
+    int i1;
+    int count;            // columns in this block (<= 128)
+    int ng;               // groups per row in scales/zeros
+    int gsz;              // dynamic mode: group size (<= 128, divides 128); static mode: unused
+    int static_mode;      // 0: qparams from current W at group starts; 1: given, gathered by col_group
+    int sym;
+    float qmin, qmax;
+};
+
+template <int I> struct StepIdx {
+    static constexpr int PO = I & 15;
+    static constexpr int EO = I >> 4;
+};
+
+// one column step, I compile-time
+template <int I>
+__device__ __forceinline__ void gptq_step(float (&w)[8], const float (&w0)[8], float (&er)[8], float (&ls)[8],
+                                          float (&sc)[8], float (&zr)[8], const float* __restrict__ us,
+                                          float d, int p, float& s_cur, float& z_cur, const GptqBlockArgs& a) {
+    constexpr int PO = StepIdx<I>::PO, EO = StepIdx<I>::EO;
+    // ---- group start (dynamic mode). The reference takes min/max from W[:, i:i+g] (gptq.py:216), which
+    // inside a block still holds the values the block STARTED with (only the clone W1 receives the
+    // in-block updates), hence w0 and not w for groups that start mid-block (group_size < 128).
+    if (!a.static_mode && (I % 16 == 0)) {
+        if ((I % a.gsz) == 0) {
+            float mn = INFINITY, mx = -INFINITY;
+            const int e1 = (I + a.gsz) >> 4;  // gsz is a multiple of 16
+#pragma unroll
+            for (int e = EO; e < 8; ++e)
+                if (e < e1 && p + 16 * e < a.count) {
+                    mn = fminf(mn, w0[e]);
+                    mx = fmaxf(mx, w0[e]);
+                }
+            mn = wave_min(mn, 16);
+            mx = wave_max(mx, 16);
+            QParams q = qparams_from_minmax(mn, mx, LLMC_F32, a.sym, 1, a.qmin, a.qmax);
+            s_cur = q.s;
+            z_cur = q.z;
+        }
+    }
+    float wi = group_bcast<PO>(w[EO]);
+    float s = s_cur, z = z_cur;
+    if (a.static_mode) {
+        s = group_bcast<PO>(sc[EO]);
+        z = group_bcast<PO>(zr[EO]);
+    }
+    const float qc = quant_code(wi, s, z, LLMC_F32, LLMC_F32, a.qmin, a.qmax);
+    const float q = dequant_code(qc, s, z, LLMC_F32);
+    const float diff = wi - q;
+    const float err = diff / d;
+    if (p == PO) {
+        er[EO] = err;
+        ls[EO] = (diff * diff) / (2.0f * (d * d));
+    }
+#pragma unroll
+    for (int e = EO; e < 8; ++e) {
+        const float u = us[I * BS + e];
+        const float t = err * u;
+        w[e] = w[e] - t;
+    }
+}
+
+template <int I0>
+__device__ __forceinline__ void gptq_steps16(float (&w)[8], const float (&w0)[8], float (&er)[8], float (&ls)[8],
+                                             float (&sc)[8], float (&zr)[8], const float* __restrict__ us,
+                                             const float* __restrict__ dg, int p, float& s_cur, float& z_cur,
+                                             const GptqBlockArgs& a) {
+#define LLMC_STEP(J)                                                                         \
+    if (I0 + J < a.count) gptq_step<I0 + J>(w, w0, er, ls, sc, zr, us, dg[I0 + J], p, s_cur, z_cur, a);
+    LLMC_STEP(0) LLMC_STEP(1) LLMC_STEP(2) LLMC_STEP(3) LLMC_STEP(4) LLMC_STEP(5) LLMC_STEP(6) LLMC_STEP(7)
+    LLMC_STEP(8) LLMC_STEP(9) LLMC_STEP(10) LLMC_STEP(11) LLMC_STEP(12) LLMC_STEP(13) LLMC_STEP(14) LLMC_STEP(15)
+#undef LLMC_STEP
+}
+
+__global__ __launch_bounds__(256) void k_gptq_block(GptqBlockArgs a) {
+    // Us[i][p*8 + e] = U[i1+i][i1 + p + 16e] for p+16e > i, else 0 ; dg[i] = U[i1+i][i1+i]
+    __shared__ __attribute__((aligned(16))) float Us[BS * BS];
+    __shared__ float dg[BS];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < BS * BS; e += 256) {
+        const int i = e >> 7, c = e & 127;  // c = column inside the block
+        float v = 0.0f;
+        if (i < a.count && c < a.count) {
+            const float u = a.U[(int64_t)(a.i1 + i) * a.K + a.i1 + c];
+            if (c > i) v = u;
+            if (c == i) dg[i] = u;
+        }
+        Us[i * BS + (c & 15) * 8 + (c >> 4)] = v;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int p = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 4 + (lane >> 4);
+    const bool active = row < a.R;
+    const int64_t rr = active ? row : a.R - 1;
+
+    float w[8], w0[8], er[8], ls[8], sc[8], zr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = p + 16 * e;
+        w[e] = (c < a.count) ? a.W[rr * a.K + a.i1 + c] : 0.0f;
+        w0[e] = w[e];
+        er[e] = 0.0f;
+        ls[e] = 0.0f;
+        sc[e] = 1.0f;
+        zr[e] = 0.0f;
+        if (a.static_mode && c < a.count) {
+            const int g = a.col_group ? a.col_group[a.i1 + c] : 0;
+            sc[e] = a.scales[rr * a.ng + g];
+            zr[e] = a.zeros ? a.zeros[rr * a.ng + g] : 0.0f;
+        }
+    }
+    float s_cur = 1.0f, z_cur = 0.0f;
+    float s_grp[8], z_grp[8];  // dynamic mode: qparams captured at each 16-column boundary (group starts)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s_grp[e] = 0.0f;
+        z_grp[e] = 0.0f;
+    }
+    const float* us = Us + p * 8;
+
+#define LLMC_CHUNK(E)                                                             \
+    gptq_steps16<16 * E>(w, w0, er, ls, sc, zr, us, dg, p, s_cur, z_cur, a);  \
+    s_grp[E] = s_cur;                                                             \
+    z_grp[E] = z_cur;
+    LLMC_CHUNK(0) LLMC_CHUNK(1) LLMC_CHUNK(2) LLMC_CHUNK(3) LLMC_CHUNK(4) LLMC_CHUNK(5) LLMC_CHUNK(6) LLMC_CHUNK(7)
+#undef LLMC_CHUNK
+
+    if (!active) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = p + 16 * e;
+        if (c < a.count) {
+            a.Wout[row * a.K + a.i1 + c] = w[e];
+            if (a.losses) a.losses[row * a.K + a.i1 + c] = ls[e];
+        }
+        a.Err[row * BS + c] = (c < a.count) ? er[e] : 0.0f;
+    }
+    if (!a.static_mode && p == 0) {
+        // qparams of the groups that start in this block (gsz divides 128, multiple of 16)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = 16 * e;
+            if (i < a.count && (i % a.gsz) == 0) {
+                const int g = (a.i1 + i) / a.gsz;
+                a.scales[row * a.ng + g] = s_grp[e];
+                if (a.zeros) a.zeros[row * a.ng + g] = z_grp[e];
+            }
+        }
+    }
+}
+
+}  // namespace llmc
+
+using namespace llmc;
+
+extern "C" size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K) {
+    if (R <= 0 || K <= 0) return 0;
+    return (size_t)R * BS * sizeof(float);
+}
+
+extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
+                                  float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
+                                  float* scales, float* zeros, float* Wout, float* losses, int blocksize,
+                                  void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(W && Hinv && Wout && scales && ws && R > 0 && K > 0, "gptq_quantize: null/empty argument");
+    LLMC_REQUIRE(blocksize == BS, "gptq_quantize: blocksize must be 128");
+    LLMC_REQUIRE(K % 4 == 0 && K < (1 << 30), "gptq_quantize: K must be a multiple of 4");
+    LLMC_REQUIRE(sym || zeros, "gptq_quantize: zeros required for asymmetric");
+    const bool per_channel = group_size <= 0;
+    int static_mode = static_groups || per_channel;
+    int gsz = (int)group_size;
+    int ng = per_channel ? 1 : (int)ceil_div64(K, group_size);
+    if (!static_mode) {
+        if (!(gsz == 16 || gsz == 32 || gsz == 64 || gsz == 128)) {
+            set_last_error_msg("gptq_quantize: dynamic group qparams need group_size in {16,32,64,128}");
+            return LLMC_ENOTSUP;
+        }
+    } else if (!per_channel) {
+        LLMC_REQUIRE(col_group != nullptr, "gptq_quantize: col_group required with static groups");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* Err = (float*)ws;
+    for (int64_t i1 = 0; i1 < K; i1 += BS) {
+        const int count = (int)(K - i1 < BS ? K - i1 : BS);
+        GptqBlockArgs a;
+        a.W = W; a.U = Hinv; a.Wout = Wout; a.losses = losses; a.Err = Err;
+        a.scales = scales; a.zeros = zeros; a.col_group = per_channel ? nullptr : col_group;
+        a.R = R; a.K = (int)K; a.i1 = (int)i1; a.count = count; a.ng = ng; a.gsz = static_mode ? BS : gsz;
+        a.static_mode = static_mode; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
+        const int grid = (int)ceil_div64(R, 16);
+        hipLaunchKernelGGL(k_gptq_block, dim3(grid), dim3(256), 0, st, a);
+        LLMC_LAUNCH_CHECK();
+        const int64_t i2 = i1 + count;
+        if (i2 < K) {
+            SgemmArgs g{};
+            g.A = Err; g.lda = BS;
+            g.B = Hinv + i1 * K + i2; g.ldb = K;
+            g.C = W + i2; g.ldc = K;
+            g.M = g.M_last = (int)R; g.N = g.N_last = (int)(K - i2); g.Kd = g.Kd_last = count;
+            g.epilogue = SG_SUB; g.batch = 1;
+            int rc = sgemm_launch(g, false, false, st);
+            if (rc) return rc;
+        }
+    }
+    return LLMC_OK;
+}

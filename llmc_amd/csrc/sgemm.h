@@ -1,0 +1,36 @@
+// sgemm.h — internal fp32 GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32), used by the GPTQ
+// Cholesky / triangular inverse (K3) and the GPTQ trailing update (K4).
+//
+// Numerics contract (relied on by K4's bit-exact parity): every output element is ONE accumulator that
+// receives its products in ascending k order, acc = fma(a_k, b_k, acc) starting from +0 — exactly the
+// chain MKL's sgemm produces for the reference on CPU (tests/test_oracle_golden.py pins that) — and the
+// epilogue applies C = C - acc (or = acc / = -acc) as one further rounding.
+#pragma once
+#include "common.h"
+
+namespace llmc {
+
+enum SgemmEpilogue { SG_SUB = 0 /* C -= AB */, SG_SET = 1 /* C = AB */, SG_NEG = 2 /* C = -AB */ };
+
+struct SgemmArgs {
+    const float* A;  // op(A) is [M x Kd]; stored [M x Kd] (TA=false) or [Kd x M] (TA=true), row-major, ld = lda
+    const float* B;  // op(B) is [Kd x N]; stored [Kd x N] (TB=false) or [N x Kd] (TB=true)
+    float* C;        // [M x N], ldc
+    int64_t lda, ldb, ldc;
+    int M, N, Kd;
+    int epilogue;
+    // structure hints (skip work that multiplies known zeros; never changes a result bit)
+    int a_upper;     // op(A)[i][k] == 0 for k < i  -> start k at the tile's first row
+    int a_lower;     // op(A)[i][k] == 0 for k > i  -> stop k after the tile's last row
+    int b_upper;     // op(B)[k][j] == 0 for k > j  -> stop k after the tile's last column
+    int c_upper_only;  // only tiles that intersect j >= i are computed/stored (symmetric update, upper half)
+    // batch: blockIdx.z-th problem at A + z*sA etc.; dims of the LAST problem may be smaller
+    int64_t sA, sB, sC;
+    int batch;
+    int M_last, N_last, Kd_last;
+};
+
+// launches on `st`; returns LLMC_* status
+int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st);
+
+}  // namespace llmc

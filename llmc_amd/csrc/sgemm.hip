@@ -1,0 +1,219 @@
+// sgemm.hip — fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain). See sgemm.h.
+// Workgroup tile 128x128, 4 waves as 2x2 (64x64 each = 2x2 MFMA accumulators), K-step 16, operands
+// staged k-major in LDS ([k][row]) so that an MFMA operand read (32 consecutive rows at one k) is a
+// conflict-free ds_read_b32; a memory layout that is row-major along k is transposed by the staging
+// writes. Register-prefetched double buffering, one barrier per K-step.
+#include "sgemm.h"
+
+namespace llmc {
+
+static constexpr int GB = 128;   // tile edge
+static constexpr int GK = 16;    // K-step
+static constexpr int GLD = 132;  // LDS row stride (floats): 16-B aligned rows, 2-way at most on transposing writes
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct Stage {
+    float4 v[2];
+};
+
+// memory is k-major: src[k*ld + c]; tile rows k0..k0+15, cols c0..c0+127
+__device__ __forceinline__ Stage load_kmajor(const float* src, int64_t ld, int k0, int c0, int kmax, int cmax,
+                                             int tid) {
+    Stage s;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int idx = tid + 256 * h;
+        int k = k0 + (idx >> 5);
+        int c = c0 + 4 * (idx & 31);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kmax) {
+            const float* p = src + (int64_t)k * ld + c;
+            if (c + 3 < cmax) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (c < cmax) v.x = p[0];
+                if (c + 1 < cmax) v.y = p[1];
+                if (c + 2 < cmax) v.z = p[2];
+            }
+        }
+        s.v[h] = v;
+    }
+    return s;
+}
+__device__ __forceinline__ void store_kmajor(float* lds, const Stage& s, int tid) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int idx = tid + 256 * h;
+        *reinterpret_cast<float4*>(lds + (idx >> 5) * GLD + 4 * (idx & 31)) = s.v[h];
+    }
+}
+// memory is c-major: src[c*ld + k]; transposed by the LDS writes
+__device__ __forceinline__ Stage load_cmajor(const float* src, int64_t ld, int k0, int c0, int kmax, int cmax,
+                                             int tid) {
+    Stage s;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int idx = tid + 256 * h;
+        int c = c0 + (idx >> 2);
+        int k = k0 + 4 * (idx & 3);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cmax) {
+            const float* p = src + (int64_t)c * ld + k;
+            if (k + 3 < kmax) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k < kmax) v.x = p[0];
+                if (k + 1 < kmax) v.y = p[1];
+                if (k + 2 < kmax) v.z = p[2];
+            }
+        }
+        s.v[h] = v;
+    }
+    return s;
+}
+__device__ __forceinline__ void store_cmajor(float* lds, const Stage& s, int tid) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int idx = tid + 256 * h;
+        int c = idx >> 2, k = 4 * (idx & 3);
+        lds[(k + 0) * GLD + c] = s.v[h].x;
+        lds[(k + 1) * GLD + c] = s.v[h].y;
+        lds[(k + 2) * GLD + c] = s.v[h].z;
+        lds[(k + 3) * GLD + c] = s.v[h].w;
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * GK * GLD];  // [buf][A|B][k][row]
+    const int z = blockIdx.z;
+    const float* A = a.A + (int64_t)z * a.sA;
+    const float* B = a.B + (int64_t)z * a.sB;
+    float* C = a.C + (int64_t)z * a.sC;
+    const bool last = z == a.batch - 1;
+    const int M = last ? a.M_last : a.M, N = last ? a.N_last : a.N, Kd = last ? a.Kd_last : a.Kd;
+    const int i0 = blockIdx.y * GB, j0 = blockIdx.x * GB;
+    if (i0 >= M || j0 >= N) return;
+    if (a.c_upper_only && j0 + GB <= i0) return;  // tile strictly below the diagonal
+
+    int kb = 0, ke = Kd;
+    if (a.a_upper) kb = (i0 / GK) * GK;
+    if (a.a_lower) ke = min(ke, i0 + GB);
+    if (a.b_upper) ke = min(ke, j0 + GB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    auto loadA = [&](int k0) {
+        // op(A)[i][k]: TA -> stored [Kd x M] k-major ; else stored [M x Kd] row(i)-major
+        return TA ? load_kmajor(A, a.lda, k0, i0, ke, M, tid) : load_cmajor(A, a.lda, k0, i0, ke, M, tid);
+    };
+    auto loadB = [&](int k0) {
+        // op(B)[k][j]: !TB -> stored [Kd x N] k-major ; TB -> stored [N x Kd]
+        return TB ? load_cmajor(B, a.ldb, k0, j0, ke, N, tid) : load_kmajor(B, a.ldb, k0, j0, ke, N, tid);
+    };
+    auto storeA = [&](int buf, const Stage& s) {
+        float* p = lds + buf * (2 * GK * GLD);
+        if (TA) store_kmajor(p, s, tid); else store_cmajor(p, s, tid);
+    };
+    auto storeB = [&](int buf, const Stage& s) {
+        float* p = lds + buf * (2 * GK * GLD) + GK * GLD;
+        if (TB) store_cmajor(p, s, tid); else store_kmajor(p, s, tid);
+    };
+
+    if (kb < ke) {
+        Stage sa = loadA(kb), sb = loadB(kb);
+        storeA(0, sa);
+        storeB(0, sb);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = kb; k0 < ke; k0 += GK) {
+            const bool more = k0 + GK < ke;
+            if (more) {
+                sa = loadA(k0 + GK);
+                sb = loadB(k0 + GK);
+            }
+            const float* pa = lds + cur * (2 * GK * GLD) + (lane >> 5) * GLD + wm * 64 + (lane & 31);
+            const float* pb = lds + cur * (2 * GK * GLD) + GK * GLD + (lane >> 5) * GLD + wn * 64 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < GK / 2; ++kk) {
+                float fa[2], fb[2];
+                fa[0] = pa[2 * kk * GLD];
+                fa[1] = pa[2 * kk * GLD + 32];
+                fb[0] = pb[2 * kk * GLD];
+                fb[1] = pb[2 * kk * GLD + 32];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            }
+            if (more) {
+                storeA(cur ^ 1, sa);
+                storeB(cur ^ 1, sb);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // epilogue: acc[m][n][r] -> row i0 + wm*64 + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), col j0 + wn*64 + n*32 + (lane&31)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = j0 + wn * 64 + n * 32 + (lane & 31);
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                float* pc = C + (int64_t)row * a.ldc + col;
+                const float v = acc[m][n][r];
+                if (a.epilogue == SG_SUB) *pc = *pc - v;
+                else if (a.epilogue == SG_SET) *pc = v;
+                else *pc = -v;
+            }
+        }
+}
+
+int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return LLMC_OK;
+    LLMC_REQUIRE((a.lda % 4 == 0) && (a.ldb % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
+                     (((uintptr_t)a.B & 15) == 0) && (a.sA % 4 == 0) && (a.sB % 4 == 0),
+                 "sgemm: operands must be 16-B aligned with ld % 4 == 0");
+    dim3 grid((a.N + GB - 1) / GB, (a.M + GB - 1) / GB, a.batch);
+    if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false>), grid, dim3(256), 0, st, a);
+    else if (!TA && !TB) hipLaunchKernelGGL((k_sgemm<false, false>), grid, dim3(256), 0, st, a);
+    else if (TA && TB) hipLaunchKernelGGL((k_sgemm<true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_sgemm<false, true>), grid, dim3(256), 0, st, a);
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+}  // namespace llmc
+
+// C ABI test hook (not part of the product surface: exercised by tests/test_sgemm_gpu.py only)
+extern "C" int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc,
+                               int M, int N, int Kd, int TA, int TB, int epilogue, int a_upper, int a_lower,
+                               int b_upper, int c_upper_only, llmc_stream_t stream) {
+    llmc::SgemmArgs a{};
+    a.A = A; a.B = B; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.M = a.M_last = M; a.N = a.N_last = N; a.Kd = a.Kd_last = Kd;
+    a.epilogue = epilogue;
+    a.a_upper = a_upper; a.a_lower = a_lower; a.b_upper = b_upper; a.c_upper_only = c_upper_only;
+    a.batch = 1;
+    return llmc::sgemm_launch(a, TA != 0, TB != 0, (hipStream_t)stream);
+}

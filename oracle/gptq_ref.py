@@ -46,3 +46,95 @@ def hessian_exact(batches):
         g = x.T @ x
         acc = g if acc is None else acc + g
     return acc * (2.0 / n)
+
+
+# ---- K2/K3: prep + factorisation (tolerance-pinned: LAPACK order differs from the reference's MKL) ----
+def hessian_sorting(H):
+    """gptq.py:63 — argsort(diag(H), descending). Ties (dead columns) are interchangeable."""
+    return np.argsort(-np.diag(H), kind='stable')
+
+
+def process_hessian_and_weights(W, H, perm=None, percdamp=0.01):
+    """gptq.py:135-174 -> (W' fp32 [R,K] permuted/dead-fixed, U fp32 upper with H^-1 = U^T U)."""
+    import scipy.linalg
+    W = np.array(W, dtype=np.float32, copy=True)
+    H = np.array(H, dtype=np.float32, copy=True)
+    K = H.shape[0]
+    dead = np.diag(H) == 0
+    H[dead, dead] = 1
+    W[:, dead] = 0
+    if perm is not None:
+        W = W[:, perm]
+        H = H[perm][:, perm]
+    damp = np.float32(percdamp) * np.mean(np.diag(H), dtype=np.float32)
+    H[np.arange(K), np.arange(K)] += damp
+    L = np.linalg.cholesky(H.astype(np.float32))
+    Linv = scipy.linalg.solve_triangular(L, np.eye(K, dtype=np.float32), lower=True)
+    Hinv = (Linv.T @ Linv).astype(np.float32)
+    U = np.linalg.cholesky(Hinv).T.astype(np.float32)
+    return W, np.ascontiguousarray(U)
+
+
+# ---- K4: the column loop, C restatement (oracle/csrc/gptq_canon.c) ---------------------------------
+_lib = None
+
+
+def _clib():
+    global _lib
+    if _lib is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, '_build', 'liboracle_gptq.so')
+        src = os.path.join(here, 'csrc', 'gptq_canon.c')
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(['make', '-C', here, '-s'])
+        _lib = ctypes.CDLL(so)
+        _lib.gptq_weight_transform.restype = ctypes.c_int
+    return _lib
+
+
+def weight_transform(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, col_group=None,
+                     scales=None, zeros=None, blocksize=128, want_losses=True):
+    """gptq.py:199-244. W [R,K] fp32 (copied), Hinv [K,K] fp32 upper.
+    Returns dict(tmp, W (running), losses, scales [R,ng], zeros [R,ng])."""
+    import ctypes
+    L = _clib()
+    W = np.array(W, dtype=np.float32, copy=True, order='C')
+    Hinv = np.ascontiguousarray(Hinv, dtype=np.float32)
+    R, K = W.shape
+    per_channel = not group_size
+    ng = 1 if per_channel else -(-K // group_size)
+    static_mode = static_groups or per_channel
+    if static_mode:
+        scales = np.ascontiguousarray(np.asarray(scales, dtype=np.float32).reshape(R, ng))
+        zeros = None if zeros is None else np.ascontiguousarray(np.asarray(zeros, dtype=np.float32).reshape(R, ng))
+    else:
+        scales = np.zeros((R, ng), dtype=np.float32)
+        zeros = np.zeros((R, ng), dtype=np.float32)
+    cg = None if col_group is None else np.ascontiguousarray(col_group, dtype=np.int32)
+    tmp = np.zeros_like(W)
+    losses = np.zeros_like(W) if want_losses else None
+
+    def p(a):
+        return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+    rc = L.gptq_weight_transform(p(W), p(Hinv), ctypes.c_int64(R), ctypes.c_int64(K), int(bool(sym)),
+                                 ctypes.c_float(qmin), ctypes.c_float(qmax), ctypes.c_int64(group_size or 0),
+                                 int(bool(static_groups)), p(cg), p(scales), p(zeros), p(tmp), p(losses),
+                                 int(blocksize))
+    assert rc == 0
+    return dict(tmp=tmp, W=W, losses=losses, scales=scales, zeros=zeros)
+
+
+def mm_chain(a, b):
+    import ctypes
+    L = _clib()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty((a.shape[0], b.shape[1]), dtype=np.float32)
+    L.mm_chain(a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+               out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(a.shape[0]), ctypes.c_int64(a.shape[1]),
+               ctypes.c_int64(b.shape[1]))
+    return out

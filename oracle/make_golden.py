@@ -185,7 +185,132 @@ def suite_pack():
     save('pack', **out)
 
 
-SUITES = {'quant': suite_quant, 'pack': suite_pack}
+def _gptq_instance(wq, actorder, static_groups, percdamp=0.01, blocksize=128, dtype=torch.float16):
+    """A GPTQ object without the model plumbing: only what the numeric methods read."""
+    from llmc.compression.quantization.gptq import GPTQ
+    g = GPTQ.__new__(GPTQ)
+    g.dev = torch.device('cpu')
+    g.wquantizer = wq
+    g.actorder = actorder
+    g.static_groups = static_groups
+    g.percdamp = percdamp
+    g.blocksize = blocksize
+    g.chunk_num = 1
+    g.owq = False
+    g.layers_cache = {}
+    g.model_dtype = dtype
+    g.need_perm = (wq.granularity == 'per_group' and not static_groups and actorder)
+    g.act_static = False
+    return g
+
+
+def suite_gptq():
+    """GPTQ.add_batch / process_hessian_and_weights / weight_transform / update_model_qparams / w_q / w_qdq
+    on small seeded layers, several configurations."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29591', rank=0, world_size=1)
+    out = {}
+    cfgs = [
+        # (name, bit, sym, gran, gs, actorder, static_groups, dtype, R, K, dead)
+        ('asym_g128_act_dyn', 4, False, 'per_group', 128, True, False, 'bf16', 24, 384, True),
+        ('sym_g128_act_static', 4, True, 'per_group', 128, True, True, 'f16', 32, 256, False),
+        ('sym_pc_noact', 8, True, 'per_channel', None, False, False, 'f16', 32, 256, False),
+        ('asym_g64_act_dyn', 4, False, 'per_group', 64, True, False, 'f16', 32, 256, False),
+        ('asym_g128_noact_static', 4, False, 'per_group', 128, False, True, 'bf16', 32, 256, False),
+    ]
+    gen = torch.Generator().manual_seed(2024)
+    for (name, bit, sym, gran, gs, actorder, static_groups, dt, R, K, dead) in cfgs:
+        kw = dict(group_size=gs) if gs else {}
+        wq = IntegerQuantizer(bit, sym, gran, **kw)
+        g = _gptq_instance(wq, actorder, static_groups, dtype=DT[dt])
+        layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+        layer.weight.data = rand_weight(gen, R, K, dt)
+        # collect_block_qparams (base_blockwise_quantization.py:338-365)
+        _, s0, z0, qmax, qmin = wq.get_tensor_qparams(layer.weight.data)
+        layer.register_buffer('buf_scales', s0.detach())
+        layer.register_buffer('buf_zeros', z0.detach())
+        layer.register_buffer('buf_qmax', torch.tensor(qmax))
+        layer.register_buffer('buf_qmin', torch.tensor(qmin))
+        lname = 'fc'
+        g.layers_cache[lname] = {}
+        g.layer_init(layer, lname)
+        nb, T = 2, 96
+        xs = []
+        for b in range(nb):
+            z = torch.randn(1, T, K, generator=gen)
+            c = torch.exp(0.5 * torch.randn(K, generator=gen))
+            x = z * c
+            x[..., 5] *= 30
+            if dead:
+                x[..., 17] = 0
+                x[..., 200] = 0
+            x = x.to(DT[dt])
+            xs.append(x)
+            g.add_batch(layer, lname, x, None)
+        H = g.layers_cache[lname]['H'].clone()
+        g.initialize_qparams_and_prepare_weights(layer, lname)
+        perm = g.perm.clone() if actorder else None
+        W0 = layer.weight.data.clone()
+        Wp, U = g.process_hessian_and_weights(layer, lname)
+        Wp_in = Wp.clone()
+        Losses = torch.zeros_like(Wp)
+        tmp = torch.zeros_like(Wp)
+        Wrun = Wp.clone()
+        if wq.granularity == 'per_group' and not static_groups:
+            pass
+        g.weight_transform(Wrun, U, Losses, tmp)
+        p = name + '/'
+        if name in ('asym_g128_act_dyn', 'sym_g128_act_static'):
+            out[p + 'x'] = np.stack([f32(x[0]) for x in xs])
+            out[p + 'H'] = f32(H)
+        out[p + 'W0'] = f32(W0)
+        out[p + 'perm'] = perm.numpy().astype(np.int64) if perm is not None else np.zeros(0, np.int64)
+        out[p + 'Wp'] = f32(Wp_in)
+        out[p + 'U'] = f32(U)
+        out[p + 'tmp'] = f32(tmp)
+        out[p + 'losses'] = f32(Losses)
+        if wq.granularity == 'per_group':
+            out[p + 'g_scales'] = np.stack([f32(q['scale']).reshape(-1) for q in g.groups], axis=1)
+            if not sym:
+                out[p + 'g_zeros'] = np.stack([f32(q['zero']).reshape(-1) for q in g.groups], axis=1)
+        else:
+            out[p + 'g_scales'] = f32(g.qparams['scale']).reshape(-1, 1)
+        # finish the layer the way update_layer_with_transformed_weights does (gptq.py:186-196)
+        t2 = tmp.clone()
+        if actorder:
+            g.invperm = torch.argsort(g.perm)
+            t2 = t2[:, g.invperm]
+        layer.weight.data = t2.reshape(layer.weight.shape)
+        if wq.granularity == 'per_group' and not static_groups:
+            g.update_model_qparams(layer)
+        out[p + 'final_w'] = f32(layer.weight.data)
+        out[p + 'buf_scales'] = f32(layer.buf_scales).reshape(-1)
+        out[p + 'buf_scales_dtype'] = np.array(str(layer.buf_scales.dtype))
+        bz = layer.buf_zeros
+        out[p + 'buf_zeros'] = f32(bz).reshape(-1) if bz.dim() > 0 else np.zeros(0, np.float32)
+        fq = g.w_qdq(layer, wq)
+        out[p + 'w_qdq'] = f32(fq)
+        out[p + 'w_qdq_dtype'] = np.array(str(fq.dtype))
+        if not g.need_perm:
+            cw, cs, cz = g.w_q(layer, wq)
+            out[p + 'w_q_codes'] = cw.numpy().astype(np.int32)
+            out[p + 'w_q_scales'] = f32(cs)
+            out[p + 'w_q_zeros'] = cz.numpy().astype(np.int32) if cz is not None else np.zeros(0, np.int32)
+        out[p + 'meta'] = np.array([bit, int(sym), gs or 0, int(actorder), int(static_groups), R, K,
+                                    float(qmin), float(qmax)], dtype=np.float64)
+        out[p + 'dt'] = np.array(dt)
+        out[p + 'gran'] = np.array(gran)
+    out['names'] = np.array([c[0] for c in cfgs])
+
+    # sgemm order pin: MKL result of Err1.matmul(Hinv[i1:i2, i2:]) on a realistic block
+    a = torch.randn(96, 128, generator=gen) * 0.01
+    b = torch.randn(128, 200, generator=gen)
+    out['mm_a'], out['mm_b'], out['mm_out'] = f32(a), f32(b), f32(a.matmul(b))
+    save('gptq', **out)
+
+
+SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

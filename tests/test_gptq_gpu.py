@@ -1,0 +1,186 @@
+"""K2/K3/K4 on MI355X vs the oracle and the reference's golden vectors."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import gptq_ref as G
+from oracle import quant_ref as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def sgemm(A, B, C, M, N, Kd, TA, TB, epi, hints=(0, 0, 0, 0)):
+    from llmc_amd import _ffi
+    L = _ffi.lib()
+    _ffi.check(L.llmc_test_sgemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
+                                 M, N, Kd, int(TA), int(TB), epi, *hints, _ffi.stream()), 'sgemm')
+    return C
+
+
+@pytest.mark.parametrize('shape', [(96, 200, 128), (300, 260, 128), (128, 128, 16), (257, 513, 72), (1024, 3968, 128)])
+def test_sgemm_bitwise_chain(shape):
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, Kd, generator=gen) * 0.01)
+    b = torch.randn(Kd, (N + 3) // 4 * 4, generator=gen)[:, :N]
+    ref = G.mm_chain(a.numpy(), b.numpy())
+    ldn = (N + 3) // 4 * 4
+    bd = torch.zeros(Kd, ldn).cuda()
+    bd[:, :N] = b.cuda()
+    # NN: A stored [M x Kd]
+    Kp = (Kd + 3) // 4 * 4
+    ad = torch.zeros(M, Kp).cuda()
+    ad[:, :Kd] = a.cuda()
+    c0 = torch.randn(M, ldn, generator=gen)
+    C = c0.cuda()
+    sgemm(ad, bd, C, M, N, Kd, False, False, 0)
+    exp = c0.numpy()[:, :N] - ref
+    np.testing.assert_array_equal(bits(C.cpu().numpy()[:, :N]), bits(exp))
+    # TN: A stored [Kd x M]
+    Mp = (M + 3) // 4 * 4
+    at = torch.zeros(Kd, Mp).cuda()
+    at[:, :M] = a.t().cuda()
+    C2 = torch.zeros(M, ldn).cuda()
+    sgemm(at, bd, C2, M, N, Kd, True, False, 1)
+    np.testing.assert_array_equal(bits(C2.cpu().numpy()[:, :N]), bits(ref))
+    C3 = torch.zeros(M, ldn).cuda()
+    sgemm(at, bd, C3, M, N, Kd, True, False, 2)
+    np.testing.assert_array_equal(bits(C3.cpu().numpy()[:, :N]), bits(-ref))
+
+
+def test_sgemm_triangular_hints_do_not_change_bits():
+    n = 384
+    gen = torch.Generator().manual_seed(1)
+    A = torch.triu(torch.randn(n, n, generator=gen))
+    B = torch.triu(torch.randn(n, n, generator=gen))
+    X = torch.randn(n, n, generator=gen)
+    Ad, Bd, Xd = A.cuda(), B.cuda(), X.cuda()
+    full = sgemm(Ad, Xd, torch.zeros(n, n).cuda(), n, n, n, False, False, 1)
+    hint = sgemm(Ad, Xd, torch.zeros(n, n).cuda(), n, n, n, False, False, 1, (1, 0, 0, 0))
+    assert torch.equal(full, hint)
+    full = sgemm(Xd, Bd, torch.zeros(n, n).cuda(), n, n, n, False, False, 2)
+    hint = sgemm(Xd, Bd, torch.zeros(n, n).cuda(), n, n, n, False, False, 2, (0, 0, 1, 0))
+    assert torch.equal(full, hint)
+    # lower-triangular op(A) = V^T with V upper stored k-major
+    full = sgemm(Ad, Xd, torch.zeros(n, n).cuda(), n, n, n, True, False, 1)
+    hint = sgemm(Ad, Xd, torch.zeros(n, n).cuda(), n, n, n, True, False, 1, (0, 1, 0, 0))
+    assert torch.equal(full, hint)
+
+
+def test_column_loop_bit_exact_vs_reference_golden():
+    from llmc_amd.compression.quantization.gptq_ops import gptq_quantize
+    g = load_golden('gptq')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        bit, sym, gs, actorder, static_groups, R, K, qmin, qmax = g[p + 'meta']
+        sym, gs, static_groups, R, K = bool(sym), int(gs), bool(static_groups), int(R), int(K)
+        perm = g[p + 'perm']
+        scales = zeros = col_group = None
+        if static_groups or gs == 0:
+            ng = 1 if gs == 0 else K // gs
+            scales = cu(g[p + 'buf_scales'].reshape(R, ng))
+            zeros = cu(g[p + 'buf_zeros'].reshape(R, ng)) if g[p + 'buf_zeros'].size else None
+            if gs:
+                idx = perm if perm.size else np.arange(K)
+                col_group = torch.from_numpy((idx // gs).astype(np.int32)).cuda()
+        tmp, losses, s, z = gptq_quantize(cu(g[p + 'Wp']), cu(g[p + 'U']), sym, qmin, qmax, gs, static_groups,
+                                          col_group, scales, zeros)
+        np.testing.assert_array_equal(bits(tmp.cpu().numpy()), bits(g[p + 'tmp']), err_msg=name)
+        np.testing.assert_array_equal(bits(losses.cpu().numpy()), bits(g[p + 'losses']), err_msg=name)
+        if not static_groups and gs:
+            np.testing.assert_array_equal(bits(s.cpu().numpy()), bits(g[p + 'g_scales']), err_msg=name)
+            if not sym:
+                np.testing.assert_array_equal(z.cpu().numpy(), g[p + 'g_zeros'], err_msg=name)
+
+
+@pytest.mark.parametrize('cfg', [(1024, 1024, 4, False, 128, False), (512, 2048, 4, True, 128, True),
+                                 (333, 640, 4, False, 64, False), (256, 512, 8, True, 0, False)])
+def test_column_loop_bit_exact_vs_oracle_larger(cfg):
+    from llmc_amd.compression.quantization.gptq_ops import gptq_quantize
+    R, K, bit, sym, gs, static_groups = cfg
+    gen = torch.Generator().manual_seed(R + K)
+    W = (torch.randn(R, K, generator=gen) * 0.02).numpy()
+    X = torch.randn(2 * K, K, generator=gen).double()
+    H = (X.T @ X / K + 0.01 * torch.eye(K, dtype=torch.float64)).numpy()
+    Hinv = np.linalg.inv(H)
+    U = np.linalg.cholesky(Hinv).T.astype(np.float32).copy()
+    qmin, qmax = Q.int_range(bit, sym)
+    scales = zeros = col_group = None
+    ng = 1 if gs == 0 else K // gs
+    if static_groups or gs == 0:
+        w2 = W.reshape(-1, gs if gs else K)
+        s, z = Q.minmax_qparams(w2, 'f32', sym, qmin, qmax)
+        scales, zeros = s.reshape(R, ng), (None if sym else z.reshape(R, ng))
+        if gs:
+            perm = np.random.RandomState(0).permutation(K)
+            col_group = (perm // gs).astype(np.int32)
+    ref = G.weight_transform(W, U, sym, qmin, qmax, gs, static_groups, col_group, scales, zeros)
+    tmp, losses, s, z = gptq_quantize(
+        cu(W), cu(U), sym, qmin, qmax, gs, static_groups,
+        None if col_group is None else torch.from_numpy(col_group).cuda(),
+        None if scales is None else cu(scales), None if zeros is None else cu(zeros))
+    np.testing.assert_array_equal(bits(tmp.cpu().numpy()), bits(ref['tmp']))
+    np.testing.assert_array_equal(bits(losses.cpu().numpy()), bits(ref['losses']))
+    if not static_groups and gs:
+        np.testing.assert_array_equal(bits(s.cpu().numpy()), bits(ref['scales']))
+        np.testing.assert_array_equal(z.cpu().numpy(), ref['zeros'])
+
+
+@pytest.mark.parametrize('K', [128, 384, 1000, 4096])
+def test_chol_inv_upper_vs_fp64(K):
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
+    gen = torch.Generator().manual_seed(K)
+    X = torch.randn(3 * K, K, generator=gen, dtype=torch.float64)
+    X[:, ::7] *= 5
+    H = (X.T @ X) * (2.0 / 3)
+    H += 0.01 * H.diag().mean() * torch.eye(K, dtype=torch.float64)
+    Hd = H.float().cuda()
+    U = chol_inv_upper(Hd.clone()).double().cpu()
+    assert torch.equal(U, torch.triu(U))
+    # defining property: U^T U = H^-1  <=>  U H U^T = I
+    Hf = Hd.double().cpu()
+    E = U @ Hf @ U.T - torch.eye(K, dtype=torch.float64)
+    L = torch.linalg.cholesky(Hf)
+    Uref = torch.linalg.cholesky(torch.cholesky_inverse(L), upper=True)
+    # reference's own fp32 3-call route, for the error scale
+    Lf = torch.linalg.cholesky(Hf.float())
+    U32 = torch.linalg.cholesky(torch.cholesky_inverse(Lf), upper=True).double()
+    e_ref = (U32 - Uref).abs().max() / Uref.abs().max()
+    e_ours = (U - Uref).abs().max() / Uref.abs().max()
+    assert e_ours <= max(4 * e_ref, 1e-5), (float(e_ours), float(e_ref))
+    assert E.abs().max() < 5e-3
+
+
+def test_hessian_prep_vs_oracle():
+    from llmc_amd.compression.quantization.gptq_ops import hessian_prep
+    g = load_golden('gptq')
+    p = 'asym_g128_act_dyn/'
+    H = g[p + 'H']
+    perm = g[p + 'perm']
+    K = H.shape[0]
+    W0 = g[p + 'W0']
+    Hd = cu(H)
+    Hout, Wout = hessian_prep(Hd, cu(W0, torch.bfloat16), torch.from_numpy(perm).cuda(), 0.01)
+    np.testing.assert_array_equal(Wout.cpu().numpy(), g[p + 'Wp'])        # permuted + dead-zeroed weights
+    Href = H.copy()
+    dead = np.diag(Href) == 0
+    assert dead.sum() == 2
+    Href[dead, dead] = 1
+    Href = Href[perm][:, perm]
+    damp = 0.01 * np.mean(np.diag(Href).astype(np.float64))
+    ho = Hout.cpu().numpy()
+    off = ~np.eye(K, dtype=bool)
+    np.testing.assert_array_equal(ho[off], Href[off])
+    np.testing.assert_allclose(np.diag(ho), np.diag(Href) + damp, rtol=1e-6)
+    assert Hd.cpu().numpy()[dead, dead].tolist() == [1.0, 1.0]           # in-place dead fix like the reference

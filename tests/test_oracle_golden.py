@@ -74,3 +74,67 @@ def test_known_first_word_of_survey_probe():
     # nibbles (LSB first) 8,12,2,2,5,10,8,14 <=> word 0xe8a522c8 for codes+8
     codes = np.array([[0, 4, -6, -6, -3, 2, 0, 6]], dtype=np.int32)
     assert Q.pack_lsb(codes, 4).view(np.uint32)[0, 0] == 0xe8a522c8
+
+
+# ---- GPTQ -------------------------------------------------------------------------------------------
+from oracle import gptq_ref as G  # noqa: E402
+
+
+def _gptq_cases():
+    g = load_golden('gptq')
+    return g, [str(n) for n in g['names']]
+
+
+def test_sgemm_chain_model_matches_mkl_bitwise():
+    g, _ = _gptq_cases()
+    out = G.mm_chain(g['mm_a'], g['mm_b'])
+    np.testing.assert_array_equal(out.view(np.uint32), g['mm_out'].view(np.uint32))
+
+
+def test_gptq_column_loop_bit_exact_vs_reference():
+    """Given the reference's own permuted weights and Hinv, the C restatement reproduces tmp, Losses and
+    every group's scale/zero bit for bit."""
+    g, names = _gptq_cases()
+    for name in names:
+        p = name + '/'
+        bit, sym, gs, actorder, static_groups, R, K, qmin, qmax = g[p + 'meta']
+        sym, gs, static_groups, K = bool(sym), int(gs), bool(static_groups), int(K)
+        perm = g[p + 'perm']
+        scales = zeros = col_group = None
+        if static_groups or gs == 0:
+            ng = 1 if gs == 0 else K // gs
+            scales = g[p + 'buf_scales'].reshape(int(R), ng)
+            zeros = g[p + 'buf_zeros'].reshape(int(R), ng) if g[p + 'buf_zeros'].size else None
+            if gs:
+                idx = perm if perm.size else np.arange(K)
+                col_group = (idx // gs).astype(np.int32)
+        r = G.weight_transform(g[p + 'Wp'], g[p + 'U'], sym, qmin, qmax, gs, static_groups, col_group,
+                               scales, zeros)
+        np.testing.assert_array_equal(r['tmp'].view(np.uint32), g[p + 'tmp'].view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(r['losses'].view(np.uint32), g[p + 'losses'].view(np.uint32), err_msg=name)
+        if not static_groups and gs:
+            np.testing.assert_array_equal(r['scales'].view(np.uint32), g[p + 'g_scales'].view(np.uint32), err_msg=name)
+            if not sym:
+                np.testing.assert_array_equal(r['zeros'], g[p + 'g_zeros'], err_msg=name)
+
+
+def test_gptq_hessian_and_factor_within_tolerance():
+    g, names = _gptq_cases()
+    for name in ('asym_g128_act_dyn', 'sym_g128_act_static'):
+        p = name + '/'
+        K = int(g[p + 'meta'][6])
+        H = np.zeros((K, K), dtype=np.float32)
+        n = 0
+        for x in g[p + 'x']:
+            H, n = G.add_batch(H, n, x)
+        ref = g[p + 'H']
+        d = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-30
+        # dead columns have an exactly zero row/col in both
+        assert (np.abs(H - ref) / np.where(d > 0, d, 1)).max() < 1e-5
+        perm = g[p + 'perm'] if g[p + 'perm'].size else None
+        if perm is not None:
+            np.testing.assert_array_equal(np.sort(G.hessian_sorting(ref)), np.arange(K))
+        Wp, U = G.process_hessian_and_weights(g[p + 'W0'], ref, perm, 0.01)
+        np.testing.assert_array_equal(Wp, g[p + 'Wp'])
+        Uref = g[p + 'U']
+        assert np.abs(U - Uref).max() / np.abs(Uref).max() < 2e-4, name
