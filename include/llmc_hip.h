@@ -113,12 +113,21 @@ int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* 
 size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx);
 int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, int64_t K, int64_t ldx,
                        double n_before, double n_after, void* ws, llmc_stream_t stream);
+/* The two launches of llmc_hessian_accum, separately (same ws): the MFMA kernel that writes per-unit
+ * partial tiles, and the ordered reduction that folds them into H. Used by bench.py to time the MFMA
+ * kernel alone with HIP events, and by callers that overlap the reduction with other work. */
+int llmc_hessian_accum_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ldx, void* ws,
+                                llmc_stream_t stream);
+int llmc_hessian_accum_reduce(float* H, int64_t T, int64_t K, int64_t ldx, double n_before, double n_after,
+                              const void* ws, llmc_stream_t stream);
 
 /* GPTQ.process_hessian_and_weights, first half (gptq.py:135-152, 169-171):
  *   dead = diag(H) == 0 -> H[dead,dead] = 1, W[:,dead] = 0; optional symmetric gather by perm
  *   (Hout = H[perm][:,perm], Wout = W[:,perm]); damp = percdamp * mean(diag) ; Hout += damp * I.
  * W [R, K] dtype wdt (model dtype or f32) -> Wout [R, K] fp32. perm may be NULL (identity).
- * H is modified in place only for the dead-column fix; Hout must not alias H when perm != NULL. */
+ * H is modified in place only for the dead-column fix; Hout must not alias H.
+ * Hout may be NULL (only W is gathered: layers that share an input share the factor), and W/Wout may
+ * both be NULL (only H is prepared). */
 size_t llmc_hessian_prep_ws_bytes(int64_t K);
 int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
                       float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream);

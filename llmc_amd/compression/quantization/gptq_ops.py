@@ -4,21 +4,27 @@ import torch
 from llmc_amd import _ffi
 
 
-def hessian_prep(H, W, perm, percdamp):
-    """gptq.py:135-152,169-171. H [K,K] fp32 (dead diagonal fixed in place), W [R,K] any float dtype.
-    Returns (Hout fp32 [K,K] permuted + damped, Wout fp32 [R,K] permuted, dead columns zeroed)."""
+def hessian_prep(H, W, perm, percdamp, want_h=True, h_out=None):
+    """gptq.py:135-152,169-171. H [K,K] fp32 (dead diagonal fixed in place), W [R,K] any float dtype or None.
+    Returns (Hout fp32 [K,K] permuted + damped | None, Wout fp32 [R,K] permuted, dead columns zeroed | None)."""
     _ffi.require_gpu(H, W, perm)
     L = _ffi.lib()
-    R, K = W.shape
-    W = W.contiguous()
-    Hout = torch.empty_like(H)
-    Wout = torch.empty((R, K), dtype=torch.float32, device=W.device)
-    ws = _ffi.workspace(L.llmc_hessian_prep_ws_bytes(K), W.device)
+    K = H.shape[0]
+    Hout = None
+    if want_h:
+        Hout = h_out if h_out is not None else torch.empty_like(H)
+    Wout = None
+    R = 0
+    if W is not None:
+        R = W.shape[0]
+        W = W.contiguous()
+        Wout = torch.empty((R, K), dtype=torch.float32, device=W.device)
+    ws = _ffi.workspace(L.llmc_hessian_prep_ws_bytes(K), H.device)
     if perm is not None:
         perm = perm.to(torch.int64).contiguous()
-    _ffi.check(L.llmc_hessian_prep(_ffi.ptr(H), _ffi.ptr(W), _ffi.dt(W), R, K, _ffi.ptr(perm), float(percdamp),
-                                   _ffi.ptr(Hout), _ffi.ptr(Wout), _ffi.ptr(ws), _ffi.stream()),
-               'llmc_hessian_prep')
+    _ffi.check(L.llmc_hessian_prep(_ffi.ptr(H), _ffi.ptr(W), _ffi.dt(W) if W is not None else 2, R, K,
+                                   _ffi.ptr(perm), float(percdamp), _ffi.ptr(Hout), _ffi.ptr(Wout), _ffi.ptr(ws),
+                                   _ffi.stream()), 'llmc_hessian_prep')
     return Hout, Wout
 
 

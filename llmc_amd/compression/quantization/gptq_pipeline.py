@@ -1,0 +1,102 @@
+"""GPTQ for a set of Linear layers that share one input, on one GPU.
+
+The reference handles every Linear separately (one Hessian, one factorisation and one column loop per
+layer, gptq.py:97-117), although layers fed by the same activation (q/k/v, gate/up) have the same H.
+Rows of W are independent given Hinv, so the layers of a subset are stacked along the output dimension
+and go through ONE Hessian, ONE factorisation and ONE column loop; results are split per layer.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from llmc_amd import _ffi
+
+from . import gptq_ops
+from .hessian import HessianAccumulator
+
+
+@dataclass
+class GptqConfig:
+    bit: int = 4
+    symmetric: bool = False
+    group_size: int = 128          # 0 = per_channel
+    actorder: bool = True
+    static_groups: bool = False
+    percdamp: float = 0.01
+    blocksize: int = 128
+
+    @property
+    def qrange(self):
+        if self.symmetric:
+            return float(-(2 ** (self.bit - 1))), float(2 ** (self.bit - 1) - 1)
+        return 0.0, float(2 ** self.bit - 1)
+
+
+@dataclass
+class GptqResult:
+    weight: torch.Tensor           # [R, K] fp32, error-compensated (the reference leaves it fp32)
+    scales: torch.Tensor           # [R, ng] fp32 (dynamic groups: processing order)
+    zeros: torch.Tensor            # [R, ng] fp32 | None
+    perm: torch.Tensor             # [K] int64 | None
+    loss: torch.Tensor             # 0-dim fp32 on device: sum(Losses) (the reference logs it, gptq.py:184)
+
+
+def factor_from_hessian(H, cfg, h_work=None):
+    """perm (actorder), then prep + factorisation of H. Returns (perm | None, U). H's dead diagonal is fixed
+    in place like the reference does."""
+    perm = None
+    if cfg.actorder:
+        perm = torch.argsort(torch.diagonal(H), descending=True)   # gptq.py:63
+    Hp, _ = gptq_ops.hessian_prep(H, None, perm, cfg.percdamp, want_h=True, h_out=h_work)
+    U = gptq_ops.chol_inv_upper(Hp, check=False)
+    return perm, U
+
+
+def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_losses=True):
+    """W_list: weights [R_i, K] (model dtype or fp32) of layers sharing the input whose Hessian is H.
+    static_qparams: list of (scales [R_i, ng], zeros [R_i, ng] | None) in ORIGINAL column order, required
+    when cfg.static_groups or per_channel. Returns a list of GptqResult."""
+    _ffi.require_gpu(H, *W_list)
+    K = H.shape[0]
+    rows = [w.shape[0] for w in W_list]
+    Wcat = torch.cat([w.reshape(w.shape[0], -1) for w in W_list], dim=0) if len(W_list) > 1 else W_list[0]
+    # dead flags must come from the un-fixed diagonal, so W is gathered in the same call that fixes H
+    perm = None
+    if cfg.actorder:
+        perm = torch.argsort(torch.diagonal(H), descending=True)
+    Hp, Wp = gptq_ops.hessian_prep(H, Wcat, perm, cfg.percdamp, want_h=True, h_out=h_work)
+    U = gptq_ops.chol_inv_upper(Hp, check=False)
+    qmin, qmax = cfg.qrange
+    static_mode = cfg.static_groups or not cfg.group_size
+    scales = zeros = col_group = None
+    if static_mode:
+        scales = torch.cat([s.reshape(r, -1).float() for (s, _), r in zip(static_qparams, rows)], dim=0)
+        if not cfg.symmetric:
+            zeros = torch.cat([z.reshape(r, -1).float() for (_, z), r in zip(static_qparams, rows)], dim=0)
+        if cfg.group_size:
+            idx = perm if perm is not None else torch.arange(K, device=H.device)
+            col_group = (idx // cfg.group_size).to(torch.int32)    # gptq.py:225-227
+    tmp, losses, s, z = gptq_ops.gptq_quantize(Wp, U, cfg.symmetric, qmin, qmax, cfg.group_size,
+                                               cfg.static_groups, col_group, scales, zeros,
+                                               want_losses=want_losses, blocksize=cfg.blocksize)
+    if perm is not None:
+        invperm = torch.argsort(perm)
+        tmp = tmp.index_select(1, invperm)                          # gptq.py:188
+    out = []
+    r0 = 0
+    for r in rows:
+        sl = slice(r0, r0 + r)
+        out.append(GptqResult(weight=tmp[sl], scales=s[sl], zeros=None if z is None else z[sl], perm=perm,
+                              loss=losses[sl].sum() if losses is not None else None))
+        r0 += r
+    return out
+
+
+def hessian_from_activations(X, acc=None):
+    """X [n_seq, seq, K] (or [tokens, K]) 16-bit on the GPU -> H fp32 [K, K] with add_batch's scaling."""
+    K = X.shape[-1]
+    if acc is None:
+        acc = HessianAccumulator(K, X.device)
+    acc.reset()
+    acc.add(X)
+    return acc.H

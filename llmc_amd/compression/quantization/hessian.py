@@ -13,6 +13,7 @@ class HessianAccumulator:
         self.H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
         self.nsamples = 0
         self._ws = None
+        self.timing = None   # optional list of (start_event, end_event, T) around the MFMA kernel
 
     def add(self, inp):
         _ffi.require_gpu(inp)
@@ -32,11 +33,24 @@ class HessianAccumulator:
         need = L.llmc_hessian_accum_ws_bytes(T, K, ldx)
         if self._ws is None or self._ws.numel() < need:
             self._ws = _ffi.workspace(need, x.device)
-        _ffi.check(L.llmc_hessian_accum(
-            _ffi.ptr(self.H), _ffi.ptr(x), _ffi.dt(x), T, K, ldx, float(self.nsamples),
-            float(self.nsamples + b), _ffi.ptr(self._ws), _ffi.stream()), 'llmc_hessian_accum')
+        st = _ffi.stream()
+        if self.timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _ffi.check(L.llmc_hessian_accum_partials(_ffi.ptr(x), _ffi.dt(x), T, K, ldx, _ffi.ptr(self._ws), st),
+                   'llmc_hessian_accum_partials')
+        if self.timing is not None:
+            e1.record()
+            self.timing.append((e0, e1, T, K))
+        _ffi.check(L.llmc_hessian_accum_reduce(_ffi.ptr(self.H), T, K, ldx, float(self.nsamples),
+                                               float(self.nsamples + b), _ffi.ptr(self._ws), st),
+                   'llmc_hessian_accum_reduce')
         self.nsamples += b
         return self.H
+
+    def reset(self):
+        """Start a new Hessian in the same buffers (the first add() overwrites H: n_before = 0)."""
+        self.nsamples = 0
 
     def release_workspace(self):
         self._ws = None

@@ -172,7 +172,8 @@ extern "C" size_t llmc_hessian_prep_ws_bytes(int64_t K) {
 
 extern "C" int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
                                  float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream) {
-    LLMC_REQUIRE(H && W && Hout && Wout && ws && R > 0 && K > 0, "hessian_prep: null/empty argument");
+    LLMC_REQUIRE(H && ws && K > 0, "hessian_prep: null/empty argument");
+    LLMC_REQUIRE((W && Wout && R > 0) || (!W && !Wout), "hessian_prep: W and Wout go together");
     LLMC_REQUIRE(dtype_ok(wdt), "hessian_prep: bad dtype");
     LLMC_REQUIRE(Hout != H, "hessian_prep: Hout must not alias H");
     LLMC_REQUIRE(K < (1ll << 31) && R < 65536ll * 32768ll, "hessian_prep: shape too large");
@@ -182,11 +183,13 @@ extern "C" int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, in
     hipLaunchKernelGGL(k_diag_fix, dim3(1), dim3(1024), 0, st, H, (int)K, dead, diag_mean);
     LLMC_LAUNCH_CHECK();
     int gx = (int)ceil_div64(K, 256 * 4);
-    hipLaunchKernelGGL(k_gather_h, dim3(gx, (unsigned)K), dim3(256), 0, st, (const float*)H, (int)K, perm, percdamp,
-                       (const float*)diag_mean, Hout);
-    LLMC_LAUNCH_CHECK();
+    if (Hout) {
+        hipLaunchKernelGGL(k_gather_h, dim3(gx, (unsigned)K), dim3(256), 0, st, (const float*)H, (int)K, perm,
+                           percdamp, (const float*)diag_mean, Hout);
+        LLMC_LAUNCH_CHECK();
+    }
     // grid.y is limited to 65535: loop over row slabs
-    for (int64_t r0 = 0; r0 < R; r0 += 32768) {
+    for (int64_t r0 = 0; W && r0 < R; r0 += 32768) {
         int64_t rows = R - r0 < 32768 ? R - r0 : 32768;
         dim3 grid(gx, (unsigned)rows);
         if (wdt == LLMC_F16)
@@ -268,14 +271,16 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         SgemmArgs x{};
         x.A = Wk; x.lda = K; x.sA = stride;                 // A^-1 at (o, o), upper
         x.B = Wk + h; x.ldb = K; x.sB = stride;             // C at (o, o+h)
-        x.C = Xbuf; x.ldc = h; x.sC = h * h;
+        // X is [h x n2]: with one pair its leading dimension shrinks to n2 (keeps X within K^2/4 floats)
+        const int64_t ldX = npairs == 1 ? ((n2_last + 3) / 4) * 4 : h;
+        x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
         x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2_last; x.Kd = x.Kd_last = (int)h;
         x.epilogue = SG_SET; x.a_upper = 1; x.batch = npairs;
         int rc = sgemm_launch(x, false, false, st);
         if (rc) return rc;
         // C = -X B^-1
         SgemmArgs y{};
-        y.A = Xbuf; y.lda = h; y.sA = h * h;
+        y.A = Xbuf; y.lda = ldX; y.sA = h * h;
         y.B = Wk + h * ((int64_t)K + 1); y.ldb = K; y.sB = stride;   // B^-1 at (o+h, o+h), upper
         y.C = Wk + h; y.ldc = K; y.sC = stride;
         y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2_last; y.Kd = (int)h; y.Kd_last = n2_last;

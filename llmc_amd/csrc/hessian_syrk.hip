@@ -289,17 +289,20 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
 }
 
 static inline int choose_chunks(int ntiles_real, int nk, int64_t x_bytes, int ncu) {
-    // pick S in [Smin, 16]: maximise occupancy of the last round, prefer fewer chunks on ties
+    // pick S >= Smin minimising a simple time model (microseconds):
+    //   rounds * (K-steps per unit * t_step + t_unit) + fixup traffic (S partial tiles written + read)
+    const double t_step = 0.9, t_unit = 6.0, fix_us_per_tile = 0.13;  // 2 x 256 KiB at ~4 TB/s
     int smin = (int)(x_bytes / (1ll << 31)) + 1;
+    if (smin > nk) smin = nk;
+    if (smin < 1) smin = 1;
     int best = smin;
-    double best_eff = -1.0;
-    for (int S = smin; S <= 16 || S == smin; ++S) {
-        if (S > nk && S > smin) break;
+    double best_cost = 1e30;
+    for (int S = smin; S <= 32 && S <= nk; ++S) {
         int64_t units = (int64_t)ntiles_real * S;
-        double eff = (double)units / (double)(ceil_div64(units, ncu) * ncu);
-        eff -= 0.004 * (S - 1);  // each extra chunk costs a partial tile write + read
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
+        double rounds = (double)ceil_div64(units, ncu);
+        double cost = rounds * (((double)nk / S) * t_step + t_unit) + fix_us_per_tile * (double)units;
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
             best = S;
         }
     }
@@ -328,14 +331,13 @@ extern "C" size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx)
     return (size_t)S * ntp * TILE_FLOATS * sizeof(float);
 }
 
-extern "C" int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, int64_t K, int64_t ldx,
-                                  double n_before, double n_after, void* ws, llmc_stream_t stream) {
+static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ldx, void* ws, hipStream_t st,
+                         int* nb_o, int* ntp_o, int* S_o) {
     LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_accum: X must be f16 or bf16");
-    LLMC_REQUIRE(H && X && ws && T > 0 && K > 0, "hessian_accum: null/empty argument");
-    LLMC_REQUIRE(ldx >= K && ldx % 8 == 0 && ((uintptr_t)X & 15) == 0, "hessian_accum: X rows must be 16-B aligned");
-    LLMC_REQUIRE(n_after > 0, "hessian_accum: n_after must be positive");
+    LLMC_REQUIRE(X && ws && T > 0 && K > 0, "hessian_accum: null/empty argument");
+    LLMC_REQUIRE(ldx >= K && ldx % 8 == 0 && ((uintptr_t)X & 15) == 0,
+                 "hessian_accum: X rows must be 16-B aligned");
     LLMC_REQUIRE(K < (1 << 30), "hessian_accum: K too large");
-    hipStream_t st = (hipStream_t)stream;
     int nb, ntp, S, nk;
     syrk_geometry(T, K, ldx, &nb, &ntp, &S, &nk);
     SyrkArgs a;
@@ -365,10 +367,35 @@ extern "C" int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, in
         hipLaunchKernelGGL((k_syrk<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
     }
     LLMC_LAUNCH_CHECK();
+    *nb_o = nb;
+    *ntp_o = ntp;
+    *S_o = S;
+    return LLMC_OK;
+}
+
+extern "C" int llmc_hessian_accum_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ldx, void* ws,
+                                           llmc_stream_t stream) {
+    int nb, ntp, S;
+    return syrk_partials(X, dt, T, K, ldx, ws, (hipStream_t)stream, &nb, &ntp, &S);
+}
+
+extern "C" int llmc_hessian_accum_reduce(float* H, int64_t T, int64_t K, int64_t ldx, double n_before,
+                                         double n_after, const void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(H && ws && T > 0 && K > 0 && n_after > 0, "hessian_accum_reduce: bad argument");
+    int nb, ntp, S, nk;
+    syrk_geometry(T, K, ldx, &nb, &ntp, &S, &nk);
     float alpha = (float)(n_before / n_after);
     float beta = (float)(2.0 / n_after);
-    hipLaunchKernelGGL(k_syrk_fixup, dim3(TILE_FLOATS / 4 / 256, ntp), dim3(256), 0, st, (const float*)ws, H,
-                       (int)K, nb, ntp, S, alpha, beta);
+    hipLaunchKernelGGL(k_syrk_fixup, dim3(TILE_FLOATS / 4 / 256, ntp), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, H, (int)K, nb, ntp, S, alpha, beta);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
+}
+
+extern "C" int llmc_hessian_accum(float* H, const void* X, int dt, int64_t T, int64_t K, int64_t ldx,
+                                  double n_before, double n_after, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(H != nullptr, "hessian_accum: null H");
+    int rc = llmc_hessian_accum_partials(X, dt, T, K, ldx, ws, stream);
+    if (rc) return rc;
+    return llmc_hessian_accum_reduce(H, T, K, ldx, n_before, n_after, ws, stream);
 }

@@ -184,3 +184,18 @@ def test_hessian_prep_vs_oracle():
     np.testing.assert_array_equal(ho[off], Href[off])
     np.testing.assert_allclose(np.diag(ho), np.diag(Href) + damp, rtol=1e-6)
     assert Hd.cpu().numpy()[dead, dead].tolist() == [1.0, 1.0]           # in-place dead fix like the reference
+
+
+@pytest.mark.parametrize('K', [14336, 2560])
+def test_chol_inv_upper_large_property(K):
+    """Uneven doubling levels (14336 = 7 * 2048): U H U^T = I in fp32 on the GPU."""
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
+    gen = torch.Generator(device='cuda').manual_seed(K)
+    X = torch.randn(2 * K, K, generator=gen, device='cuda')
+    H = (X.T @ X) / K + 0.05 * torch.eye(K, device='cuda')
+    del X
+    U = chol_inv_upper(H.clone())
+    assert torch.equal(U, torch.triu(U))
+    E = U @ H @ U.T
+    E.diagonal().sub_(1.0)
+    assert E.abs().max().item() < 1e-3
