@@ -43,55 +43,170 @@ __global__ __launch_bounds__(256) void k_antitranspose(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// Diagonal block: U = chol_upper(D) in LDS, V = U^-1. One workgroup of 512 threads.
-//   W   : work matrix (ld), diagonal block at (k0,k0), size nb <= 128. U (upper, strict lower zeroed) is
-//         written back; Vout [128 x 128] (ld 128) receives U^-1 (zero padded).
+// Diagonal block (<= 128 x 128): U = chol_upper(D), V = U^-1, one workgroup of 4 waves, everything in LDS.
+// Blocked over 32 x 32 sub-blocks:
+//   - a sub-block is factored / inverted by ONE wave with lane j owning column j in 32 registers; pivots
+//     and multipliers travel by v_readlane (uniform lane index), no LDS, no barriers inside;
+//   - panel solves, trailing updates and the doubling steps of the inverse are 32x32x32 block products on
+//     the f32 MFMA pipe, spread over the 4 waves.
+// Replaces a 128-step barrier-synchronised kernel (396 us on MI355X, profiles/r01_a) on the critical path
+// of the blocked factorisation. Partial blocks are padded with the identity.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_potrf_inv(float* __restrict__ W, int64_t ld, int k0, int nb,
-                                                   float* __restrict__ Vout, int* __restrict__ info) {
-    __shared__ float S[NB][NB + 1];
-    __shared__ float V[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 512) {
-        int i = e >> 7, j = e & 127;
-        float v = 0.0f;
-        if (i < nb && j < nb && j >= i) v = W[(int64_t)(k0 + i) * ld + k0 + j];
-        S[i][j] = v;
-        V[i][j] = 0.0f;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        float d = S[j][j];
-        if (!(d > 0.0f) && tid == 0) atomicCAS(info, 0, k0 + j + 1);
-        float rj = sqrtf(d);
-        __syncthreads();
-        if (tid == 0) S[j][j] = rj;
-        for (int l = j + 1 + tid; l < nb; l += 512) S[j][l] = S[j][l] / rj;
-        __syncthreads();
-        // trailing rank-1 update of the upper triangle: rows i in (j, nb), cols l >= i
-        const int m = nb - j - 1;
-        for (int e = tid; e < m * m; e += 512) {
-            int i = j + 1 + e / m, l = j + 1 + e % m;
-            if (l >= i) S[i][l] -= S[j][i] * S[j][l];
-        }
-        __syncthreads();
-    }
-    // V = U^-1 by back substitution; thread j owns column j.
-    if (tid < nb) {
-        const int j = tid;
-        for (int i = j; i >= 0; --i) {
-            float s = (i == j) ? 1.0f : 0.0f;
-            for (int k = i + 1; k <= j; ++k) s -= S[i][k] * V[k][j];
-            V[i][j] = s / S[i][i];
+static constexpr int PLD = 132;  // LDS leading dimension (floats)
+typedef __attribute__((ext_vector_type(16))) float pf32x16;
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// wave-level: factor the 32x32 block at S (upper Cholesky, in place, strict lower zeroed) and write its
+// inverse to V. Lane j (and its twin j+32) owns column j.
+__device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* __restrict__ V, int lane,
+                                                 int kglobal, int* __restrict__ info) {
+#pragma clang fp contract(fast)
+    const int j = lane & 31;
+    float a[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a[i] = S[i * PLD + j];
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float d = rdlane(a[i], i);
+        if (!(d > 0.0f)) bad = true;
+        const float r = sqrtf(d);
+        const float ui = (j > i) ? a[i] / r : (j == i ? r : 0.0f);
+        a[i] = ui;
+#pragma unroll
+        for (int k = i + 1; k < 32; ++k) {
+            const float t = rdlane(ui, k);
+            a[k] -= t * ui;
         }
     }
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 512) {
-        int i = e >> 7, j = e & 127;
-        Vout[e] = V[i][j];
-        if (i < nb && j < nb) W[(int64_t)(k0 + i) * ld + k0 + j] = (j >= i) ? S[i][j] : 0.0f;
+    if (bad && lane == 0) atomicCAS(info, 0, kglobal + 1);
+    float v[32];
+#pragma unroll
+    for (int i = 31; i >= 0; --i) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = i + 1; k < 32; ++k) acc += rdlane(a[i], k) * v[k];
+        const float dii = rdlane(a[i], i);
+        v[i] = ((j == i ? 1.0f : 0.0f) - acc) / dii;
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            S[i * PLD + j] = a[i];
+            V[i * PLD + j] = v[i];
+        }
     }
 }
+
+// 32x32x32 block product on the f32 MFMA: acc += op(A) * B, op(A)[i][k] = TA ? A[k][i] : A[i][k]
+template <bool TA>
+__device__ __forceinline__ pf32x16 blk_mm(const float* __restrict__ A, const float* __restrict__ B, pf32x16 acc,
+                                          int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 2 * kk + h;
+        const float av = TA ? A[k * PLD + c] : A[c * PLD + k];
+        const float bv = B[k * PLD + c];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ void blk_store(float* __restrict__ C, const pf32x16& acc, int lane, float sign) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[((r & 3) + 8 * (r >> 2) + 4 * h) * PLD + c] = sign * acc[r];
+}
+__device__ __forceinline__ void blk_sub(float* __restrict__ C, const pf32x16& acc, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float* p = C + ((r & 3) + 8 * (r >> 2) + 4 * h) * PLD + c;
+        *p = *p - acc[r];
+    }
+}
+#define PBLK(M, bi, bj) ((M) + (bi) * 32 * PLD + (bj) * 32)
+
+__global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_t ld, int k0, int nb,
+                                                   float* __restrict__ Vout, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) float plds[];
+    float* S = plds;
+    float* V = plds + NB * PLD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const pf32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        float v = (i == j) ? 1.0f : 0.0f;
+        if (i < nb && j < nb) v = (j >= i) ? W[(int64_t)(k0 + i) * ld + k0 + j] : 0.0f;
+        S[i * PLD + j] = v;
+        V[i * PLD + j] = 0.0f;
+    }
+    __syncthreads();
+    // ---- blocked upper Cholesky over 4 block rows
+    for (int kb = 0; kb < 4; ++kb) {
+        if (wv == 0) wave_potrf32_inv(PBLK(S, kb, kb), PBLK(V, kb, kb), lane, k0 + kb * 32, info);
+        __syncthreads();
+        {   // panel: S(kb, jb) = V_kk^T * S(kb, jb)
+            const int jb = kb + 1 + wv;
+            if (jb < 4) {
+                pf32x16 acc = blk_mm<true>(PBLK(V, kb, kb), PBLK(S, kb, jb), zero, lane);
+                blk_store(PBLK(S, kb, jb), acc, lane, 1.0f);
+            }
+        }
+        __syncthreads();
+        {   // trailing: S(ib, jb) -= S(kb, ib)^T * S(kb, jb), kb < ib <= jb
+            int idx = 0;
+            for (int ib = kb + 1; ib < 4; ++ib)
+                for (int jb = ib; jb < 4; ++jb, ++idx)
+                    if ((idx & 3) == wv) {
+                        pf32x16 acc = blk_mm<true>(PBLK(S, kb, ib), PBLK(S, kb, jb), zero, lane);
+                        blk_sub(PBLK(S, ib, jb), acc, lane);
+                    }
+        }
+        __syncthreads();
+    }
+    // ---- U back to the work matrix (S becomes scratch afterwards)
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        if (i < nb && j < nb) W[(int64_t)(k0 + i) * ld + k0 + j] = (j >= i) ? S[i * PLD + j] : 0.0f;
+    }
+    // ---- V = U^-1 by doubling. Level 32 -> 64: pairs (0,1) and (2,3)
+    if (wv < 2) {
+        const int a = 2 * wv, b = a + 1;
+        pf32x16 x = blk_mm<false>(PBLK(V, a, a), PBLK(S, a, b), zero, lane);   // X = V_aa * U_ab
+        blk_store(PBLK(V, a, b), x, lane, 1.0f);
+        pf32x16 y = blk_mm<false>(PBLK(V, a, b), PBLK(V, b, b), zero, lane);   // Y = X * V_bb
+        blk_store(PBLK(V, a, b), y, lane, -1.0f);
+    }
+    __syncthreads();
+    // Level 64 -> 128: X = V[0:64,0:64] * U[0:64,64:128] (into V scratch), then -X * V[64:,64:] (into S scratch)
+    {
+        const int r = wv >> 1, c = 2 + (wv & 1);
+        pf32x16 x = blk_mm<false>(PBLK(V, r, r), PBLK(S, r, c), zero, lane);
+        if (r == 0) x = blk_mm<false>(PBLK(V, 0, 1), PBLK(S, 1, c), x, lane);
+        __syncthreads();  // everyone has read U[0:64,64:128] from S and the level-1 V blocks
+        blk_store(PBLK(V, r, c), x, lane, 1.0f);
+    }
+    __syncthreads();
+    {
+        const int r = wv >> 1, c = 2 + (wv & 1);
+        pf32x16 y = blk_mm<false>(PBLK(V, r, 2), PBLK(V, 2, c), zero, lane);
+        if (c == 3) y = blk_mm<false>(PBLK(V, r, 3), PBLK(V, 3, 3), y, lane);
+        blk_store(PBLK(S, r, c), y, lane, -1.0f);
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        const float* src = (i < 64 && j >= 64) ? S : V;
+        Vout[e] = (j >= i) ? src[i * PLD + j] : 0.0f;
+    }
+}
+#undef PBLK
 
 // copy the inverted diagonal blocks into the work matrix (upper), before the doubling levels
 __global__ __launch_bounds__(256) void k_place_diag_inv(float* __restrict__ W, int64_t ld, int K,
@@ -226,6 +341,12 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
     LLMC_HIP_CHECK(hipMemsetAsync(info_dev, 0, 4, st));
+    static bool potrf_attr = false;
+    if (!potrf_attr) {
+        LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_potrf_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * NB * PLD * (int)sizeof(float)));
+        potrf_attr = true;
+    }
 
     dim3 tgrid((K + 31) / 32, (K + 31) / 32);
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
@@ -237,7 +358,8 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         const int k0 = b * NB;
         const int nb = K - k0 < NB ? K - k0 : NB;
         float* Vb = Vbuf + (size_t)b * NB * NB;
-        hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(512), 0, st, Wk, (int64_t)K, k0, nb, Vb, info_dev);
+        hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 2 * NB * PLD * sizeof(float), st, Wk, (int64_t)K, k0, nb,
+                           Vb, info_dev);
         LLMC_LAUNCH_CHECK();
         const int nrem = K - k0 - nb;
         if (nrem <= 0) break;
