@@ -169,14 +169,16 @@ int llmc_awq_act_mean(const void* X, int dt, int64_t N, int64_t K, void* out, vo
                       llmc_stream_t stream);
 
 /* Awq.get_weight_scale (awq.py:48-72) for one layer: mean over rows of |W| / rowgroup-max(|W|).
- * W [R, K] dt, groups of g along K (g = K for per-channel). acc [K] fp32 accumulates the per-layer means
- * rounded to dt exactly as total_scale.add_ does (first != 0 overwrites). */
-int llmc_awq_weight_mean(const void* W, int dt, int64_t R, int64_t K, int64_t g, void* out_dt,
+ * W [R, K] dt, groups of g along K (g = K for per-channel) -> out [K] dt: the layer's `layer_scale.mean(0)`;
+ * the caller adds the layers' vectors and divides by their count (awq.py:66-72, [K]-sized torch ops). */
+size_t llmc_awq_weight_mean_ws_bytes(int64_t R, int64_t K);
+int llmc_awq_weight_mean(const void* W, int dt, int64_t R, int64_t K, int64_t g, void* out_dt, void* ws,
                          llmc_stream_t stream);
 
 /* Awq.get_scales (awq.py:88-108): v2: s = x_mean^ratio clamp(1e-4); v1: x^r / w^(1-r) clamp(1e-4);
- * then s /= sqrt(max(s) * min(s)). x_mean / w_mean / out: [K] dt. w_mean may be NULL for v2. */
-int llmc_awq_scales(const void* x_mean, const void* w_mean, int dt, int64_t K, float ratio, int version,
+ * then s /= sqrt(max(s) * min(s)). x_mean / w_mean / out: [K] dt. w_mean may be NULL for v2. The exponents
+ * ratio and 1-ratio are rounded to dt first, as ATen's CPU Tensor.pow(python_float) does. */
+int llmc_awq_scales(const void* x_mean, const void* w_mean, int dt, int64_t K, double ratio, int version,
                     void* out, llmc_stream_t stream);
 
 /* fake_quantize_weight + scaling_weight (awq.py:40-46,147-164): out = fakequant_dyn(W * s[None,:]) in dt. */

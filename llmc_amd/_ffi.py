@@ -37,6 +37,17 @@ SIGNATURES = {
     'llmc_gptq_quantize_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_gptq_quantize': (_i32, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                   _i32, _vp, _vp]),
+    'llmc_awq_act_mean_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_awq_act_mean': (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
+    'llmc_awq_weight_mean_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_awq_weight_mean': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'llmc_awq_scales': (_i32, [_vp, _vp, _i32, _i64, _f64, _i32, _vp, _vp]),
+    'llmc_awq_scale_fakequant': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _f32, _f32, _vp, _vp]),
+    'llmc_div_cols': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    'llmc_mul_cols': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp]),
+    'llmc_clamp_groups': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'llmc_linear_eval_ws_bytes': (_sz, [_i64, _i64, _i64]),
+    'llmc_linear_eval': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'llmc_test_sgemm': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i32, _vp]),
 }

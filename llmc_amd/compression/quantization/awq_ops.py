@@ -1,0 +1,119 @@
+"""Functional wrappers over the AWQ entry points of libllmc_hip.so (K8, K9)."""
+import torch
+
+from llmc_amd import _ffi
+
+
+def act_mean(x):
+    """Awq.get_act_scale (awq.py:74-76): x.abs().view(-1, K).mean(0) in the tensor dtype."""
+    _ffi.require_gpu(x)
+    L = _ffi.lib()
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    N, K = x2.shape
+    out = torch.empty(K, dtype=x.dtype, device=x.device)
+    ws = _ffi.workspace(L.llmc_awq_act_mean_ws_bytes(N, K), x.device)
+    _ffi.check(L.llmc_awq_act_mean(_ffi.ptr(x2), _ffi.dt(x2), N, K, _ffi.ptr(out), _ffi.ptr(ws), _ffi.stream()),
+               'llmc_awq_act_mean')
+    return out
+
+
+def weight_mean(w, group_size):
+    """one layer's `layer_scale.mean(0)` of Awq.get_weight_scale (awq.py:59-66)."""
+    _ffi.require_gpu(w)
+    L = _ffi.lib()
+    w = w.contiguous()
+    R, K = w.shape
+    out = torch.empty(K, dtype=w.dtype, device=w.device)
+    ws = _ffi.workspace(L.llmc_awq_weight_mean_ws_bytes(R, K), w.device)
+    _ffi.check(L.llmc_awq_weight_mean(_ffi.ptr(w), _ffi.dt(w), R, K, int(group_size or 0), _ffi.ptr(out),
+                                      _ffi.ptr(ws), _ffi.stream()), 'llmc_awq_weight_mean')
+    return out
+
+
+def awq_scales(x_mean, w_mean, ratio, version='v2'):
+    """Awq.get_scales (awq.py:98-108)."""
+    _ffi.require_gpu(x_mean, w_mean)
+    L = _ffi.lib()
+    out = torch.empty_like(x_mean)
+    v = 1 if version == 'v1' else 2
+    _ffi.check(L.llmc_awq_scales(_ffi.ptr(x_mean), _ffi.ptr(w_mean) if v == 1 else 0, _ffi.dt(x_mean), x_mean.numel(),
+                                 float(ratio), v, _ffi.ptr(out), _ffi.stream()), 'llmc_awq_scales')
+    return out
+
+
+def scale_fakequant(w, scales, wquantizer):
+    """fake_quant_weight_dynamic(w.mul_(scales)) (awq.py:147-164); returns a new tensor, w is untouched."""
+    _ffi.require_gpu(w, scales)
+    L = _ffi.lib()
+    w = w.contiguous()
+    R, K = w.shape
+    g = wquantizer.group_size if wquantizer.granularity == 'per_group' else K
+    out = torch.empty_like(w)
+    _ffi.check(L.llmc_awq_scale_fakequant(_ffi.ptr(w), _ffi.ptr(scales.contiguous()), _ffi.dt(w), R, K, g,
+                                          int(wquantizer.sym), float(wquantizer.qmin), float(wquantizer.qmax),
+                                          _ffi.ptr(out), _ffi.stream()), 'llmc_awq_scale_fakequant')
+    return out
+
+
+def div_cols(x, scales):
+    """scaling_input (base_blockwise_quantization.py:877-889): x / scales.view(1, -1)."""
+    _ffi.require_gpu(x, scales)
+    L = _ffi.lib()
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    out = torch.empty_like(x2)
+    _ffi.check(L.llmc_div_cols(_ffi.ptr(x2), _ffi.ptr(scales.contiguous()), _ffi.dt(x2), x2.shape[0], x2.shape[1],
+                               _ffi.ptr(out), _ffi.stream()), 'llmc_div_cols')
+    return out.reshape(x.shape)
+
+
+def mul_cols_(w, scales):
+    """fc.weight.mul_(scales.view(1, -1)) (base_blockwise_quantization.py:770)."""
+    _ffi.require_gpu(w, scales)
+    L = _ffi.lib()
+    assert w.is_contiguous()
+    _ffi.check(L.llmc_mul_cols(_ffi.ptr(w), _ffi.ptr(scales.contiguous()), _ffi.dt(w), w.shape[0], w.shape[1],
+                               _ffi.stream()), 'llmc_mul_cols')
+    return w
+
+
+def clamp_groups_(w, min_val, max_val, group_size):
+    """apply_clip v1 (auto_clip.py:194-212)."""
+    _ffi.require_gpu(w, min_val, max_val)
+    L = _ffi.lib()
+    assert w.is_contiguous()
+    _ffi.check(L.llmc_clamp_groups(_ffi.ptr(w), _ffi.dt(w), w.shape[0], w.shape[1], int(group_size or 0),
+                                   _ffi.ptr(min_val.contiguous()), _ffi.ptr(max_val.contiguous()), _ffi.stream()),
+               'llmc_clamp_groups')
+    return w
+
+
+def linear_out(x, wq):
+    """F.linear(x, wq) for the inspected Linear: [N, K] x [R, K]^T -> [N, R] in the model dtype."""
+    _ffi.require_gpu(x, wq)
+    L = _ffi.lib()
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    wq = wq.contiguous()
+    N, K = x2.shape
+    R = wq.shape[0]
+    y = torch.empty((N, R), dtype=x.dtype, device=x.device)
+    _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 0, _ffi.ptr(y), 0, 0, 0,
+                                  _ffi.stream()), 'llmc_linear_eval')
+    return y.reshape(*x.shape[:-1], R)
+
+
+def linear_loss_sum(x, wq, y0, loss_acc=None):
+    """sum((y0 - F.linear(x, wq))^2) with the difference formed in the model dtype; returns / accumulates into
+    a 1-element fp32 device tensor (no host sync)."""
+    _ffi.require_gpu(x, wq, y0)
+    L = _ffi.lib()
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    wq = wq.contiguous()
+    y0 = y0.reshape(-1, y0.shape[-1]).contiguous()
+    N, K = x2.shape
+    R = wq.shape[0]
+    if loss_acc is None:
+        loss_acc = torch.zeros(1, dtype=torch.float32, device=x.device)
+    ws = _ffi.workspace(L.llmc_linear_eval_ws_bytes(N, K, R), x.device)
+    _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 1, 0, _ffi.ptr(y0),
+                                  _ffi.ptr(loss_acc), _ffi.ptr(ws), _ffi.stream()), 'llmc_linear_eval')
+    return loss_acc

@@ -1,0 +1,49 @@
+"""AWQ scale search for a set of Linear layers that share one input, inspect = the layers themselves.
+
+Mirrors Awq.search_scale_subset (awq.py:179-278) for the shipped default of one calibration batch
+(calib.bs = -1): 20-point grid over ratio, s = get_scales(...), Wq = fakequant(W * s), out = (x / s) Wq^T,
+loss = mean((org_out - out)^2), argmin.  Differences in mechanics, not in arithmetic: nothing is copied to the
+host and restored (the reference reloads the module's state dict from a CPU copy every grid step), the
+activation mean is computed once instead of once per grid step, and the 20 losses stay on the device until
+the final argmin (one sync instead of 20 `.item()` calls).
+"""
+import torch
+
+from llmc_amd import _ffi
+
+from . import awq_ops
+
+
+@torch.no_grad()
+def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, return_losses=False):
+    """weights: list of [R_i, K] tensors (model dtype, untouched); x: [..., K] activations (model dtype).
+    Returns best_scales [K] (model dtype) (and the device tensor of the 20 mean losses)."""
+    _ffi.require_gpu(x, *weights)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    N = x2.shape[0]
+    wcat = torch.cat(weights, dim=0) if len(weights) > 1 else weights[0]
+    R = wcat.shape[0]
+    g = wquantizer.group_size if wquantizer.granularity == 'per_group' else 0
+    # get_weight_scale (awq.py:48-72): per-layer mean, summed in the model dtype, divided by the layer count
+    w_max = None
+    for w in weights:
+        m = awq_ops.weight_mean(w, g)
+        w_max = m if w_max is None else w_max.add_(m)
+    w_max = w_max.div_(len(weights))
+    x_mean = awq_ops.act_mean(x2)                       # get_act_scale (awq.py:74-76)
+    org_out = awq_ops.linear_out(x2, wcat)              # get_original_out (awq.py:128-132)
+    losses = torch.zeros(n_grid, dtype=torch.float32, device=x.device)
+    scales_all = []
+    for n in range(n_grid):
+        ratio = n * 1 / n_grid
+        s = awq_ops.awq_scales(x_mean, w_max, ratio, trans_version)
+        wq = awq_ops.scale_fakequant(wcat, s, wquantizer)
+        xs = awq_ops.div_cols(x2, s)
+        awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1])
+        scales_all.append(s)
+    losses /= float(N * R)                               # .pow(2).mean() (awq.py:136)
+    best = int(torch.argmin(losses).item())              # strict '<' keeps the first minimum (awq.py:245)
+    if return_losses:
+        return scales_all[best], losses, best
+    return scales_all[best]

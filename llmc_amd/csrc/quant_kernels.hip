@@ -473,6 +473,109 @@ extern "C" int llmc_quant_dynamic(const void* W, int dt, int64_t G, int64_t g, i
     return LLMC_OK;
 }
 
+// fake_quantize_weight of AWQ's search (awq.py:147-164): w' = rnd(w * s[col]) (the in-place mul_ in the
+// model dtype), then the dynamic fake-quant of the scaled row group. One pass over W.
+namespace llmc {
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_scale_fakequant(const T* __restrict__ W, const T* __restrict__ cs,
+                                                            int64_t G, int g, int gpr /*groups per row*/,
+                                                            int lpr, int sym, float qmin, float qmax,
+                                                            T* __restrict__ out) {
+    constexpr int DT = dt_of<T>::value;
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const int sub = lane / lpr, sl = lane % lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r0 = wave * rpw; r0 < G; r0 += nwaves * rpw) {
+        int64_t row = r0 + sub;
+        const bool valid = row < G;
+        const int64_t rr = valid ? row : G - 1;
+        const T* rp = W + rr * g;
+        const T* cp = cs + (rr % gpr) * g;
+        float mn = INFINITY, mx = -INFINITY;
+        RowVec<T, VEC> first;
+        bool hf = false;
+        for (int c = sl * VEC; c < g; c += lpr * VEC) {
+            RowVec<T, VEC> v = load_vec<T, VEC>(rp + c);
+            RowVec<T, VEC> sv = load_vec<T, VEC>(cp + c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float f = rndc<DT>(to_f32<T>(v.v[i]) * to_f32<T>(sv.v[i]));
+                v.v[i] = from_f32<T>(f);
+                mn = fminf(mn, f);
+                mx = fmaxf(mx, f);
+            }
+            if (!hf) {
+                first = v;
+                hf = true;
+            }
+        }
+        mn = wave_min(mn, lpr);
+        mx = wave_max(mx, lpr);
+        QParams q = qparams_from_minmax(mn, mx, DT, sym, 1, qmin, qmax);
+        if (!valid) continue;
+        bool use_first = true;
+        for (int c = sl * VEC; c < g; c += lpr * VEC) {
+            RowVec<T, VEC> v;
+            if (use_first) {
+                v = first;
+            } else {
+                v = load_vec<T, VEC>(rp + c);
+                RowVec<T, VEC> sv = load_vec<T, VEC>(cp + c);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v.v[i] = from_f32<T>(rndc<DT>(to_f32<T>(v.v[i]) * to_f32<T>(sv.v[i])));
+            }
+            use_first = false;
+            RowVec<T, VEC> o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float qq = quant_code(to_f32<T>(v.v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                o.v[k] = from_f32<T>(dequant_code(qq, q.s, q.z, DT));
+            }
+            store_vec<T, VEC>(out + rr * g + c, o);
+        }
+    }
+}
+
+template <typename T>
+static int scale_fakequant_t(const void* W, const void* s, int64_t R, int64_t K, int64_t g, int sym, float qmin,
+                             float qmax, void* out, hipStream_t st) {
+    constexpr int V16 = 16 / sizeof(T);
+    const int64_t G = R * (K / g);
+    const int gpr = (int)(K / g);
+    bool vec_ok = (g % V16 == 0) && (((uintptr_t)W & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
+                  (((uintptr_t)s & 15) == 0);
+    if (vec_ok) {
+        int lpr = choose_lpr(g, V16);
+        int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
+        hipLaunchKernelGGL((k_scale_fakequant<T, V16>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, (const T*)s, G,
+                           (int)g, gpr, lpr, sym, qmin, qmax, (T*)out);
+    } else {
+        int lpr = choose_lpr(g, 1);
+        int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
+        hipLaunchKernelGGL((k_scale_fakequant<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, (const T*)s, G,
+                           (int)g, gpr, lpr, sym, qmin, qmax, (T*)out);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+}  // namespace llmc
+
+extern "C" int llmc_awq_scale_fakequant(const void* W, const void* s, int dt, int64_t R, int64_t K, int64_t g,
+                                        int sym, float qmin, float qmax, void* out, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(dt), "awq_scale_fakequant: bad dtype");
+    LLMC_REQUIRE(W && s && out && R > 0 && K > 0, "awq_scale_fakequant: null/empty argument");
+    if (g <= 0) g = K;
+    LLMC_REQUIRE(K % g == 0 && g < (1ll << 31), "awq_scale_fakequant: K must be a multiple of the group size");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dt) {
+        case LLMC_F16: return scale_fakequant_t<f16_t>(W, s, R, K, g, sym, qmin, qmax, out, st);
+        case LLMC_BF16: return scale_fakequant_t<bf16_t>(W, s, R, K, g, sym, qmin, qmax, out, st);
+        default: return scale_fakequant_t<float>(W, s, R, K, g, sym, qmin, qmax, out, st);
+    }
+}
+
 extern "C" int llmc_pack_lsb(const void* codes, int code_kind, int64_t R, int64_t K, int bits,
                              int32_t* packed, llmc_stream_t stream) {
     LLMC_REQUIRE(codes && packed && R > 0 && K > 0, "pack_lsb: null/empty argument");

@@ -1,0 +1,96 @@
+"""Numpy restatement of llmc's AWQ scale search (llmc/compression/quantization/awq.py) and of the pieces of
+BaseBlockwiseQuantization it calls.
+
+  get_weight_scale        awq.py:48-72     mean over rows (and layers) of |W| / group-max(|W|)
+  get_act_scale           awq.py:74-85     mean over tokens of |x|
+  get_scales              awq.py:88-108    x_mean^ratio (v2) or x^r / w^(1-r) (v1), clamp 1e-4, / sqrt(max*min)
+  fake_quantize_weight    awq.py:147-164   fakequant_dyn(W * s) in the model dtype
+  scaling_input           base_blockwise_quantization.py:877-889   x / s
+  calculate_loss          awq.py:134-136   mean((org_out - out).float()^2)
+  search_scale_subset     awq.py:179-253   20-point grid, one calibration batch, argmin
+Test infrastructure only (see oracle/__init__.py). Reductions (mean over 10^4..10^5 tokens, the GEMM's k-sum)
+are fp32 sums whose order is the BLAS/ATen implementation's; they are pinned by tolerance (scales usually
+bit-equal after the rounding to 16 bit), the elementwise chains bit-exactly.
+"""
+import numpy as np
+
+from . import quant_ref as Q
+from .quant_ref import rnd
+
+
+def act_mean(x, dt):
+    x = np.asarray(x, dtype=np.float32).reshape(-1, x.shape[-1])
+    s = np.abs(x).sum(axis=0, dtype=np.float32)
+    return rnd(s / np.float32(x.shape[0]), dt)
+
+
+def weight_scale(weights, dt, group_size):
+    total = None
+    for w in weights:
+        w = np.asarray(w, dtype=np.float32)
+        g = group_size or w.shape[1]
+        a = np.abs(w.reshape(-1, g))
+        m = a.max(axis=1, keepdims=True)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            ls = rnd(a / m, dt).reshape(w.shape)
+        mean = rnd(ls.sum(axis=0, dtype=np.float32) / np.float32(w.shape[0]), dt)
+        total = mean if total is None else rnd(total + mean, dt)
+    return rnd(total / np.float32(len(weights)), dt)
+
+
+def get_scales(x_mean, w_mean, ratio, dt, version='v2'):
+    # Tensor.pow(python_float) on CPU casts the exponent to the tensor dtype first (0.6 -> 0.60009765625 in f16)
+    r = rnd(np.float32(ratio), dt)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        if version == 'v1':
+            a = rnd(np.power(x_mean, r, dtype=np.float32), dt)
+            b = rnd(np.power(w_mean, rnd(np.float32(1.0 - ratio), dt), dtype=np.float32), dt)
+            s = rnd(a / b, dt)
+        else:
+            s = rnd(np.power(x_mean, r, dtype=np.float32), dt)
+        s = np.maximum(s, rnd(np.float32(1e-4), dt))
+        den = rnd(np.sqrt(rnd(s.max() * s.min(), dt)), dt)
+        return rnd(s / den, dt)
+
+
+def fake_quantize_weight(w, s, dt, sym, qmin, qmax, group_size):
+    ws = rnd(np.asarray(w, dtype=np.float32) * s[None, :], dt)
+    g = group_size or w.shape[1]
+    fq, _, _ = Q.fake_quant_dynamic(ws.reshape(-1, g), dt, sym, qmin, qmax)
+    return fq.reshape(w.shape)
+
+
+def scaling_input(x, s, dt):
+    return rnd(np.asarray(x, dtype=np.float32) / s, dt)
+
+
+def linear(x, w, dt):
+    x2 = np.asarray(x, dtype=np.float32).reshape(-1, x.shape[-1])
+    return rnd(x2 @ np.asarray(w, dtype=np.float32).T, dt)
+
+
+def loss_mean(y0, y, dt):
+    d = rnd(y0 - y, dt)
+    return float(np.mean(d.astype(np.float32) ** 2, dtype=np.float32))
+
+
+def search_scale(weights, x, dt, sym, qmin, qmax, group_size, version='v2', n_grid=20):
+    """One calibration batch (the shipped default bs=-1), inspect = the Linear layers themselves (outputs
+    concatenated). Returns (best_scales [K], losses [n_grid], best_n)."""
+    x = np.asarray(x, dtype=np.float32)
+    wcat = np.concatenate([np.asarray(w, dtype=np.float32) for w in weights], axis=0)
+    w_max = weight_scale(weights, dt, group_size)
+    y0 = linear(x, wcat, dt)
+    x_mean = act_mean(x, dt)
+    best, best_s, best_n = float('inf'), None, -1
+    losses = []
+    for n in range(n_grid):
+        ratio = n * 1 / n_grid
+        s = get_scales(x_mean, w_max, ratio, dt, version)
+        wq = np.concatenate([fake_quantize_weight(w, s, dt, sym, qmin, qmax, group_size) for w in weights], axis=0)
+        y = linear(scaling_input(x, s, dt), wq, dt)
+        ls = loss_mean(y0, y, dt)
+        losses.append(ls)
+        if ls < best:
+            best, best_s, best_n = ls, s, n
+    return best_s, np.array(losses, dtype=np.float64), best_n

@@ -310,7 +310,98 @@ def suite_gptq():
     save('gptq', **out)
 
 
-SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq}
+def suite_awq():
+    """Awq.search_scale_subset (20-point grid, one batch) with inspect = the stacked Linear layers."""
+    import torch.distributed as dist
+    import types
+    from llmc.compression.quantization.awq import Awq
+    from llmc.compression.quantization.base_blockwise_quantization import BaseBlockwiseQuantization
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29592', rank=0, world_size=1)
+
+    class Stacked(torch.nn.Module):
+        def __init__(self, layers):
+            super().__init__()
+            self.layers = torch.nn.ModuleList(layers)
+
+        def forward(self, x):
+            return torch.cat([l(x) for l in self.layers], dim=-1)
+
+    # On a GPU `org_sd = {k: v.cpu() ...}` (awq.py:199) is a COPY of the weights; on CPU `.cpu()` aliases them and
+    # the in-place `mul_` of grid step 0 corrupts the saved originals whenever scales(ratio=0) != 1 (trans v1).
+    # Keep the GPU semantics the reference is written for: make .cpu() copy while this suite runs.
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()
+    out = {}
+    gen = torch.Generator().manual_seed(4242)
+    cfgs = [('bf16_sym_g128_v2', 'bf16', True, 128, 'v2', [64, 32]), ('f16_asym_g128_v2', 'f16', False, 128, 'v2', [48]),
+            ('bf16_sym_g64_v1', 'bf16', True, 64, 'v1', [32, 32])]
+    for (name, dt, sym, gs, ver, Rs) in cfgs:
+        K, N = 256, 192
+        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+        a = Awq.__new__(Awq)
+        a.wquantizer = wq
+        a.aquantizer = None
+        a.w_only = True
+        a.awq_bs = None
+        a.save_mem = False
+        a.padding_mask = None
+        a.trans_version = ver
+        a.n_samples = 2
+        a.has_gqa = False
+        a.do_gqa_trans = False
+        layers = []
+        for R in Rs:
+            l = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+            wt = torch.randn(R, K, generator=gen) * 0.02
+            wt[:, torch.randperm(K, generator=gen)[:4]] *= 20
+            l.weight.data = wt.to(DT[dt])
+            layers.append(l)
+        z = torch.randn(2, N // 2, K, generator=gen)
+        c = torch.exp(0.5 * torch.randn(K, generator=gen))
+        idx = torch.randperm(K, generator=gen)[:8]
+        c[idx] *= 100.0
+        x = (z * c).to(DT[dt])
+        losses = []
+        orig = a.calculate_loss
+
+        def rec(org_out, o, _orig=orig):
+            v = _orig(org_out, o)
+            losses.append(v)
+            return v
+        a.calculate_loss = rec
+        w0 = [l.weight.data.clone() for l in layers]
+        layers_dict = {f'l{i}': l for i, l in enumerate(layers)}
+        w_max = a.get_weight_scale(layers_dict)
+        a._bs = x.shape[0]
+        x_mean = a.get_act_scale(x)
+        s10 = a.get_scales(None, x, w_max, False, 0.5)
+        best = a.search_scale_subset(None, layers_dict, [x], Stacked(layers), False, {})
+        for l, w in zip(layers, w0):
+            assert torch.equal(l.weight.data, w), 'reference must restore the weights'
+        p = name + '/'
+        for i, w in enumerate(w0):
+            out[p + f'w{i}'] = f32(w)
+        out[p + 'x'] = f32(x)
+        out[p + 'w_max'] = f32(w_max)
+        out[p + 'x_mean'] = f32(x_mean)
+        out[p + 'scales_r050'] = f32(s10)
+        out[p + 'best_scales'] = f32(best)
+        out[p + 'losses'] = np.array(losses, dtype=np.float64)
+        # one explicit grid point for the elementwise chain
+        s = a.get_scales(None, x, w_max, False, 0.35)
+        wqs = torch.cat([wq.fake_quant_weight_dynamic(w.clone().mul_(s.view(1, -1))) for w in w0], dim=0)
+        xs = x / s.view(1, -1)
+        out[p + 'scales_r035'] = f32(s)
+        out[p + 'wq_r035'] = f32(wqs)
+        out[p + 'xs_r035'] = f32(xs)
+        out[p + 'meta'] = np.array([int(sym), gs, len(Rs), K], dtype=np.int64)
+        out[p + 'dt'] = np.array(dt)
+        out[p + 'ver'] = np.array(ver)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('awq', **out)
+
+
+SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

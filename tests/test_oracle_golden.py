@@ -138,3 +138,63 @@ def test_gptq_hessian_and_factor_within_tolerance():
         np.testing.assert_array_equal(Wp, g[p + 'Wp'])
         Uref = g[p + 'U']
         assert np.abs(U - Uref).max() / np.abs(Uref).max() < 2e-4, name
+
+
+# ---- AWQ --------------------------------------------------------------------------------------------
+from oracle import awq_ref as A  # noqa: E402
+
+
+def _ulp_close(a, b, dt, max_frac_diff=0.0, max_ulps=1):
+    """16-bit results of fp32 reductions: identical except where a different summation order flips the
+    final rounding; then they differ by one unit in the last place."""
+    a = np.asarray(a, dtype=np.float32).ravel()
+    b = np.asarray(b, dtype=np.float32).ravel()
+    ne = a != b
+    if ne.mean() > max_frac_diff:
+        return False
+    if not ne.any():
+        return True
+    shift = 16 if dt == 'bf16' else 13
+    ia = a.view(np.int32)[ne] >> shift
+    ib = b.view(np.int32)[ne] >> shift
+    return np.abs(ia - ib).max() <= max_ulps
+
+
+def test_awq_elementwise_chain_bit_exact():
+    g = load_golden('awq')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+        dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
+        ws = [g[p + f'w{i}'] for i in range(nl)]
+        qmin, qmax = Q.int_range(4, bool(sym))
+        s = g[p + 'scales_r035']
+        wq = np.concatenate([A.fake_quantize_weight(w, s, dt, bool(sym), qmin, qmax, gs) for w in ws], axis=0)
+        np.testing.assert_array_equal(wq.view(np.uint32), g[p + 'wq_r035'].view(np.uint32), err_msg=name)
+        xs = A.scaling_input(g[p + 'x'], s, dt)
+        np.testing.assert_array_equal(xs.view(np.uint32), g[p + 'xs_r035'].view(np.uint32), err_msg=name)
+        # get_scales from the reference's own means: powf may differ in the last fp32 bit between libms
+        s2 = A.get_scales(g[p + 'x_mean'], g[p + 'w_max'], 0.5, dt, ver)
+        assert _ulp_close(s2, g[p + 'scales_r050'], dt, max_frac_diff=0.02), name
+
+
+def test_awq_reductions_and_search_match_reference():
+    g = load_golden('awq')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+        dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
+        ws = [g[p + f'w{i}'] for i in range(nl)]
+        assert _ulp_close(A.act_mean(g[p + 'x'], dt), g[p + 'x_mean'], dt, max_frac_diff=0.02), name
+        assert _ulp_close(A.weight_scale(ws, dt, gs), g[p + 'w_max'], dt, max_frac_diff=0.05, max_ulps=2), name
+        qmin, qmax = Q.int_range(4, bool(sym))
+        best, losses, n = A.search_scale(ws, g[p + 'x'], dt, bool(sym), qmin, qmax, gs, ver)
+        ref_losses = g[p + 'losses']
+        assert len(ref_losses) == 20
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-2, err_msg=name)
+        assert n == int(np.argmin(ref_losses)), name
+        # a 1-ulp difference of the token mean at the max/min channel moves the normaliser sqrt(max*min) and
+        # with it every scale by one unit in the last place: same grid point, scales within 2 ulp of the dtype
+        assert _ulp_close(best, g[p + 'best_scales'], dt, max_frac_diff=0.01, max_ulps=1), name
+        # the search must be non-trivial on this data (interior argmin)
+        assert 0 < n < 19
