@@ -96,10 +96,12 @@ int llmc_pack_awq_gemm(const void* weight, int wdt, const void* scales, int sdt,
 /* FloatQuantizer e4m3 weight path with use_qtorch semantics pinned to torch's float8_e4m3fn cast
  * (quant.py:1043-1072, 1195-1221): scale = absmax.clamp(1e-5) / 448 per row of the [G, g] view
  * (G = 1 per-tensor, G = R per-channel), q = RNE_e4m3(x / scale). out_fp8 [G, g] bytes (OCP e4m3fn),
- * scales [G] in dtype dt. fake != 0 writes dequantised q * scale in dt to out instead of fp8 bytes. */
+ * scales [G] in dtype sdt: ATen yields fp32 for the 0-dim per-tensor scale (absmax / tensor(448.)) and the
+ * tensor dtype for per-channel. fake != 0 writes dequantised q * scale in dt to out instead of fp8 bytes.
+ * static_scales != 0: `scales` is INPUT (fake_quant_act_static / real_quant_weight_static, quant.py:1083-1099). */
 size_t llmc_fp8_quant_ws_bytes(int64_t G, int64_t g);
-int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* out, void* scales,
-                   void* ws, llmc_stream_t stream);
+int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* out, void* scales, int sdt,
+                   int static_scales, void* ws, llmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GPTQ (llmc/compression/quantization/gptq.py)

@@ -48,6 +48,12 @@ SIGNATURES = {
     'llmc_clamp_groups': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     'llmc_linear_eval_ws_bytes': (_sz, [_i64, _i64, _i64]),
     'llmc_linear_eval': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'llmc_awq_clip_search_ws_bytes': (_sz, [_i64, _i64, _i64, _i64]),
+    'llmc_awq_clip_search': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _f32,
+                                    _vp, _vp, _vp, _vp]),
+    'llmc_fp8_quant_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_fp8_quant': (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'llmc_pack_awq_gemm': (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     'llmc_test_sgemm': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i32, _vp]),
 }

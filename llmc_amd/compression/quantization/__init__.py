@@ -1,1 +1,2 @@
-from .quant import BaseQuantizer, IntegerQuantizer, pack_lsb  # noqa: F401
+from .quant import (BaseQuantizer, FloatQuantizer, IntegerQuantizer,  # noqa: F401
+                    pack_awq_gemm, pack_lsb)

@@ -117,3 +117,21 @@ def linear_loss_sum(x, wq, y0, loss_acc=None):
     _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 1, 0, _ffi.ptr(y0),
                                   _ffi.ptr(loss_acc), _ffi.ptr(ws), _ffi.stream()), 'llmc_linear_eval')
     return loss_acc
+
+
+def clip_search(w, x, wquantizer, clip_sym, n_grid=20, max_shrink=0.5):
+    """AutoClipper.auto_clip_layer (auto_clip.py:84-191, v1, w_only). w [R,K]; x [n_tok,K] already subsampled.
+    Returns (best_max [R, ng, 1], best_min [R, ng, 1]) in the model dtype."""
+    _ffi.require_gpu(w, x)
+    L = _ffi.lib()
+    w, x = w.contiguous(), x.reshape(-1, x.shape[-1]).contiguous()
+    R, K = w.shape
+    g = wquantizer.group_size if wquantizer.granularity == 'per_group' else K
+    ng = K // g
+    bmax = torch.empty((R, ng, 1), dtype=w.dtype, device=w.device)
+    bmin = torch.empty((R, ng, 1), dtype=w.dtype, device=w.device)
+    _ffi.check(L.llmc_awq_clip_search(_ffi.ptr(w), _ffi.ptr(x), _ffi.dt(w), R, K, g, x.shape[0], int(n_grid),
+                                      int(max_shrink * n_grid), int(bool(clip_sym)), int(wquantizer.sym),
+                                      float(wquantizer.qmin), float(wquantizer.qmax), _ffi.ptr(bmax), _ffi.ptr(bmin),
+                                      0, _ffi.stream()), 'llmc_awq_clip_search')
+    return bmax, bmin

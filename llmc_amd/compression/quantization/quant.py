@@ -312,3 +312,98 @@ def pack_lsb(codes, bits):
     _ffi.check(L.llmc_pack_lsb(_ffi.ptr(codes), kind, R, K, int(bits), _ffi.ptr(packed), _ffi.stream()),
                'llmc_pack_lsb')
     return packed
+
+
+class FloatQuantizer(BaseQuantizer):
+    """FP8 e4m3 (OCP) symmetric quantizer, the `use_qtorch: True` path of the reference's FP8 configs
+    (quant.py:963-1229). qtorch is not vendored by the reference; its e4m3 rounding is pinned here to torch's own
+    float8_e4m3fn cast (RNE), which is also what the reference's real-quant path ends in (quant.py:1183,1211)."""
+
+    def __init__(self, bit, symmetric, granularity, **kwargs):
+        super().__init__(bit, symmetric, granularity, **kwargs)
+        self.sym = True
+        self.quant_type = 'float-quant'
+        if self.bit != 'e4m3':
+            raise NotImplementedError(f'FloatQuantizer bit={self.bit}: only e4m3 is on the accelerated path')
+        if self.granularity not in ('per_tensor', 'per_channel', 'per_token'):
+            raise NotImplementedError(f'FloatQuantizer granularity={self.granularity}')
+        self.e_bits, self.m_bits = 4, 3
+        self.use_qtorch = self.kwargs.get('use_qtorch', True)
+        self.qmax = torch.tensor(448.0)
+        self.qmin = torch.tensor(-448.0)
+
+    def _run(self, tensor, fake, scales=None):
+        _ffi.require_gpu(tensor, scales)
+        L = _ffi.lib()
+        tensor = tensor.contiguous()
+        G, g = self._geometry(tensor)
+        sdtype = torch.float32 if self.granularity == 'per_tensor' else tensor.dtype
+        static = scales is not None
+        if static:
+            s = scales.reshape(-1).to(tensor.device).contiguous()
+            if s.numel() != G:
+                raise ValueError(f'FloatQuantizer: {s.numel()} scales for {G} rows')
+            sdtype = s.dtype
+        else:
+            s = torch.empty(G, dtype=sdtype, device=tensor.device)
+        out = torch.empty_like(tensor) if fake else torch.empty(tensor.shape, dtype=torch.uint8, device=tensor.device)
+        ws = None if static else _ffi.workspace(L.llmc_fp8_quant_ws_bytes(G, g), tensor.device)
+        _ffi.check(L.llmc_fp8_quant(_ffi.ptr(tensor), _ffi.dt(tensor), G, g, int(fake), _ffi.ptr(out), _ffi.ptr(s),
+                                    _ffi.dt(sdtype), int(static), _ffi.ptr(ws), _ffi.stream()), 'llmc_fp8_quant')
+        return out, s.reshape(self._qparam_shape(tensor))
+
+    def get_tensor_qparams(self, tensor, args={}):
+        tensor = self.reshape_tensor(tensor)
+        _, scales = self._run(tensor, True)
+        return tensor, scales, torch.tensor(0.0), self.qmax, self.qmin
+
+    def fake_quant_weight_dynamic(self, weight, args={}):
+        out, _ = self._run(self.reshape_tensor(weight), True)
+        return out.reshape(weight.shape)
+
+    def fake_quant_act_dynamic(self, act, args={}):
+        out, _ = self._run(self.reshape_tensor(act), True)
+        return out.reshape(act.shape)
+
+    def fake_quant_act_static(self, act, args={}):
+        out, _ = self._run(self.reshape_tensor(act), True, scales=args['scales'])
+        return out.reshape(act.shape)
+
+    def fake_quant_weight_static(self, weight, args):
+        out, _ = self._run(self.reshape_tensor(weight), True, scales=args['scales'])
+        return out.reshape(weight.shape)
+
+    def _finish(self, bits, scales, shape):
+        weight = bits.view(torch.float8_e4m3fn).reshape(shape)
+        qshape = 1 if self.granularity == 'per_tensor' else (shape[0], -1)
+        return weight, scales.reshape(qshape), None
+
+    def real_quant_weight_dynamic(self, weight, args={}):
+        bits, scales = self._run(self.reshape_tensor(weight), False)
+        return self._finish(bits, scales, weight.shape)
+
+    def real_quant_weight_static(self, weight, args):
+        bits, scales = self._run(self.reshape_tensor(weight), False, scales=args['scales'])
+        return self._finish(bits, scales, weight.shape)
+
+    def __repr__(self):
+        return (f'FloatQuantizer(bit={self.bit},e_bits={self.e_bits}, m_bits={self.m_bits},'
+                f'granularity={self.granularity},kwargs={self.kwargs}, qmin={self.qmin}, qmax={self.qmax})')
+
+
+def pack_awq_gemm(weight, scales, zeros, group_size):
+    """AutoawqRealQuantLinear.gemm_pack (module_utils.py:1004-1065) on the GPU.
+    weight [R,K] float, scales [R,K/g], zeros [R,K/g] int32 -> (qweight [K,R/8] i32, scales [K/g,R] f16, qzeros)."""
+    _ffi.require_gpu(weight, scales, zeros)
+    L = _ffi.lib()
+    weight, scales = weight.contiguous(), scales.contiguous()
+    zeros = zeros.to(torch.int32).contiguous()
+    R, K = weight.shape
+    ng = K // group_size
+    qweight = torch.empty((K, R // 8), dtype=torch.int32, device=weight.device)
+    qzeros = torch.empty((ng, R // 8), dtype=torch.int32, device=weight.device)
+    sout = torch.empty((ng, R), dtype=torch.float16, device=weight.device)
+    _ffi.check(L.llmc_pack_awq_gemm(_ffi.ptr(weight), _ffi.dt(weight), _ffi.ptr(scales), _ffi.dt(scales),
+                                    _ffi.ptr(zeros), R, K, int(group_size), _ffi.ptr(qweight), _ffi.ptr(qzeros),
+                                    _ffi.ptr(sout), _ffi.stream()), 'llmc_pack_awq_gemm')
+    return qweight, sout, qzeros

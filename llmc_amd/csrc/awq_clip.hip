@@ -1,0 +1,205 @@
+// awq_clip.hip — K10: AutoClipper.auto_clip_layer (auto_clip.py:84-191), clip_version v1, weight-only.
+//
+// For every (output row, input group) the reference evaluates 10 shrink levels of the group's clipping range:
+//   q_w = fakequant_dyn(clamp(w, -m, m)),  err = mean_tok((sum_k x*q_w - sum_k x*w)^2),  keep the argmin,
+// with every op in the model dtype: each product x*w is rounded to 16 bit BEFORE the k-sum, so this is not an
+// MFMA contraction (the matrix pipe does not round products) — it is evaluated on the VALU with the
+// reference's roundings, which is cheap enough (2*11*R*K*n_tok rounded MACs, ~10 ms for 4096^2 x 512 tokens)
+// and keeps the chosen clip levels identical to the reference's.
+// Layout: one workgroup per (group, slab of rows). The group's activations [n_tok, 128] are staged once,
+// transposed to [k][token] in LDS (lane <-> token: conflict-free ds_read_b64 of 4 tokens); each wave walks
+// rows; the 11 candidate weight vectors of a row (original + 10 clipped/fake-quantized) live in a small LDS
+// table read as broadcasts.
+#include "common.h"
+#include "quant_math.h"
+
+namespace llmc {
+
+static constexpr int CG = 128;        // max group size handled per LDS column block
+static constexpr int CTOK = 512;      // tokens per LDS tile
+static constexpr int CROWS = 32;      // rows per workgroup
+static constexpr int CMAXS = 12;      // 1 + max shrink steps (n_shrink <= 11)
+
+template <int DT> __device__ __forceinline__ float rfast(float v) {
+    if constexpr (DT == LLMC_F16) {
+        return (float)(_Float16)v;
+    } else if constexpr (DT == LLMC_BF16) {
+        uint32_t x = __float_as_uint(v);
+        x += 0x7fffu + ((x >> 16) & 1u);
+        return __uint_as_float(x & 0xffff0000u);
+    } else {
+        return v;
+    }
+}
+
+struct ClipArgs {
+    const void* W;   // [R, K]
+    const void* X;   // [n_tok, K]
+    int64_t R, K;
+    int g, ng, n_tok;
+    int n_grid, n_shrink, clip_sym, sym;
+    float qmin, qmax;
+    void* best_max;  // [R, ng]
+    void* best_min;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
+    constexpr int DT = dt_of<T>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xt = (T*)smem;                                                  // [g][CTOK]
+    float* tab = (float*)(smem + (size_t)CG * CTOK * sizeof(T));       // [4 waves][CMAXS][CG]
+    float* esum_all = tab + 4 * CMAXS * CG;                            // [CROWS][CMAXS]
+    const int gi = blockIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * CROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = a.g;
+    float* mytab = tab + wv * CMAXS * CG;
+    const int ns = a.n_shrink;
+    const bool v0 = lane < g, v1 = lane + 64 < g;
+
+    for (int e = tid; e < CROWS * CMAXS; e += 256) esum_all[e] = 0.f;
+
+    for (int t0 = 0; t0 < a.n_tok; t0 += CTOK) {
+        const int nt = a.n_tok - t0 < CTOK ? a.n_tok - t0 : CTOK;
+        __syncthreads();   // previous tile fully consumed by every wave (and esum_all zeroed)
+        for (int e = tid; e < CTOK * g; e += 256) {   // stage X[t0:t0+nt, group] transposed to [k][token]
+            const int t = e / g, k = e - t * g;
+            T v = from_f32<T>(0.f);
+            if (t < nt) v = ((const T*)a.X)[(int64_t)(t0 + t) * a.K + (int64_t)gi * g + k];
+            xt[k * CTOK + t] = v;
+        }
+        __syncthreads();
+        for (int rr = wv; rr < CROWS; rr += 4) {   // no barrier inside: waves walk their own rows
+            const int64_t row = r0 + rr;
+            if (row >= a.R) continue;
+            // ---- the 1 + ns candidate weight vectors of (row, group) -> this wave's LDS table
+            const T* wp = (const T*)a.W + row * a.K + (int64_t)gi * g;
+            const float w0 = v0 ? to_f32<T>(wp[lane]) : 0.f, w1 = v1 ? to_f32<T>(wp[lane + 64]) : 0.f;
+            const float amx = fmaxf(v0 ? (a.clip_sym ? fabsf(w0) : w0) : -INFINITY,
+                                    v1 ? (a.clip_sym ? fabsf(w1) : w1) : -INFINITY);
+            const float amn = fminf(v0 ? w0 : INFINITY, v1 ? w1 : INFINITY);
+            const float org_max = wave_max(amx, 64), org_min = wave_min(amn, 64);
+            mytab[lane] = w0;
+            mytab[lane + 64] = w1;
+            for (int s = 0; s < ns; ++s) {
+                const float f = (float)(1.0 - (double)s / (double)a.n_grid);   // python scalar: fp32 opmath in ATen's mul
+                const float mx = rndc<DT>(org_max * f);
+                const float mn = a.clip_sym ? -mx : rndc<DT>(org_min * f);
+                const float c0 = fminf(fmaxf(w0, mn), mx), c1 = fminf(fmaxf(w1, mn), mx);
+                const float gmx = wave_max(fmaxf(v0 ? c0 : -INFINITY, v1 ? c1 : -INFINITY), 64);
+                const float gmn = wave_min(fminf(v0 ? c0 : INFINITY, v1 ? c1 : INFINITY), 64);
+                const QParams q = qparams_from_minmax(gmn, gmx, DT, a.sym, 1, a.qmin, a.qmax);
+                const float q0 = dequant_code(quant_code(c0, q.s, q.z, DT, DT, a.qmin, a.qmax), q.s, q.z, DT);
+                const float q1 = dequant_code(quant_code(c1, q.s, q.z, DT, DT, a.qmin, a.qmax), q.s, q.z, DT);
+                mytab[(s + 1) * CG + lane] = v0 ? q0 : 0.f;
+                mytab[(s + 1) * CG + lane + 64] = v1 ? q1 : 0.f;
+            }
+            // ---- outputs of every candidate for this tile's tokens, 4 tokens per lane, 256 per pass
+            float esum[CMAXS];
+            for (int s = 0; s < CMAXS; ++s) esum[s] = 0.f;
+            for (int tb = 0; tb < nt; tb += 256) {
+                float acc[CMAXS][4];
+                for (int s = 0; s <= ns; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[s][j] = 0.f;
+                const int tl = tb + lane * 4;
+                for (int k = 0; k < g; ++k) {
+                    float xv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[j] = to_f32<T>(xt[k * CTOK + tl + j]);
+                    for (int s = 0; s <= ns; ++s) {
+                        const float wv_ = mytab[s * CG + k];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[s][j] += rfast<DT>(xv[j] * wv_);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (tl + j < nt) {
+                        const float o0 = rfast<DT>(acc[0][j]);
+                        for (int s = 1; s <= ns; ++s) {
+                            const float d = rfast<DT>(rfast<DT>(acc[s][j]) - o0);
+                            esum[s] += rfast<DT>(d * d);
+                        }
+                    }
+                }
+            }
+            for (int s = 1; s <= ns; ++s) {
+                const float tot = wave_sum(esum[s], 64);
+                if (lane == 0) esum_all[rr * CMAXS + s] += tot;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- argmin over shrink levels (strict <, first minimum wins; min_errs starts at 1e9 in dt)
+    for (int rr = tid; rr < CROWS; rr += 256) {
+        const int64_t row = r0 + rr;
+        if (row >= a.R) continue;
+        const T* wp = (const T*)a.W + row * a.K + (int64_t)gi * g;
+        float org_max = -INFINITY, org_min = INFINITY;
+        for (int k = 0; k < g; ++k) {
+            const float w = to_f32<T>(wp[k]);
+            org_max = fmaxf(org_max, a.clip_sym ? fabsf(w) : w);
+            org_min = fminf(org_min, w);
+        }
+        float best_mx = org_max, best_mn = org_min;
+        float min_err = rndc<DT>(1e9f);
+        for (int s = 0; s < ns; ++s) {
+            const float e = rndc<DT>(esum_all[rr * CMAXS + s + 1] / (float)a.n_tok);
+            const float f = (float)(1.0 - (double)s / (double)a.n_grid);
+            const float mx = rndc<DT>(org_max * f);
+            const float mn = a.clip_sym ? -mx : rndc<DT>(org_min * f);
+            if (e < min_err) {
+                min_err = e;
+                best_mx = mx;
+                best_mn = mn;
+            }
+        }
+        ((T*)a.best_max)[row * a.ng + gi] = from_f32<T>(best_mx);
+        ((T*)a.best_min)[row * a.ng + gi] = from_f32<T>(best_mn);
+    }
+}
+
+}  // namespace llmc
+
+using namespace llmc;
+
+extern "C" size_t llmc_awq_clip_search_ws_bytes(int64_t R, int64_t K, int64_t g, int64_t n_tok) { return 0; }
+
+extern "C" int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g,
+                                    int64_t n_tok, int n_grid, int n_shrink, int clip_sym, int sym, float qmin,
+                                    float qmax, void* best_max, void* best_min, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "awq_clip_search: dtype must be f16 or bf16");
+    LLMC_REQUIRE(W && X && best_max && best_min && R > 0 && K > 0 && n_tok > 0, "awq_clip_search: null/empty argument");
+    if (g <= 0) g = K;
+    if (g > CG || K % g != 0 || n_shrink < 1 || n_shrink > CMAXS - 1 || n_grid < 1) {
+        set_last_error_msg("awq_clip_search: needs group_size <= 128 dividing K and 1..11 shrink steps");
+        return LLMC_ENOTSUP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ClipArgs a;
+    a.W = W; a.X = X; a.R = R; a.K = K; a.g = (int)g; a.ng = (int)(K / g); a.n_tok = (int)n_tok;
+    a.n_grid = n_grid; a.n_shrink = n_shrink; a.clip_sym = clip_sym; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
+    a.best_max = best_max; a.best_min = best_min;
+    const size_t lds = (size_t)CG * CTOK * 2 + (size_t)(4 * CMAXS * CG + CROWS * CMAXS) * sizeof(float);
+    dim3 grid((unsigned)a.ng, (unsigned)ceil_div64(R, CROWS));
+    static bool attr[2] = {false, false};
+    if (dt == LLMC_F16) {
+        if (!attr[0]) {
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_clip_search<f16_t>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[0] = true;
+        }
+        hipLaunchKernelGGL((k_clip_search<f16_t>), grid, dim3(256), lds, st, a);
+    } else {
+        if (!attr[1]) {
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_clip_search<bf16_t>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[1] = true;
+        }
+        hipLaunchKernelGGL((k_clip_search<bf16_t>), grid, dim3(256), lds, st, a);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}

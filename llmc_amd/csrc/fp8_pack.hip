@@ -1,0 +1,187 @@
+// fp8_pack.hip — K11 FP8 (OCP e4m3fn) weight quantization and the AutoAWQ GEMM packer (K7b).
+//   llmc_fp8_quant      FloatQuantizer sym e4m3: scale = absmax.clamp(1e-5)/448, q = RNE_e4m3(x / scale)
+//                       (quant.py:545-553, 1061-1072, 1195-1221). qtorch is not vendored by the reference;
+//                       rounding is pinned to torch.float8_e4m3fn's cast (RNE, no saturation: > 464 -> NaN).
+//   llmc_pack_awq_gemm  module_utils.py:1004-1065.
+#include "common.h"
+
+namespace llmc {
+
+static constexpr int FB = 256;
+
+// fp32 -> e4m3fn bits with torch's semantics
+__device__ __forceinline__ uint8_t f32_to_e4m3fn(float x) {
+    const uint32_t b = __float_as_uint(x);
+    const uint32_t sign = (b >> 24) & 0x80u;
+    const uint32_t ab = b & 0x7fffffffu;
+    if (ab > 0x7f800000u) return (uint8_t)(sign | 0x7f);  // NaN
+    const float ax = __uint_as_float(ab);
+    if (ax < 0.015625f) {  // below 2^-6: subnormal grid 2^-9 (rint = RNE); 8 -> smallest normal
+        const uint32_t m = (uint32_t)rintf(ax * 512.0f);
+        return (uint8_t)(sign | m);
+    }
+    // round the fp32 mantissa to 3 bits, RNE, carry propagates into the exponent
+    uint32_t r = ab + 0x7ffffu + ((ab >> 20) & 1u);
+    r &= 0xfff00000u;
+    if (r > 0x43e00000u) return (uint8_t)(sign | 0x7f);  // > 448 after rounding (incl. inf) -> NaN
+    const uint32_t e = (r >> 23) - 127 + 7;
+    const uint32_t m = (r >> 20) & 7u;
+    return (uint8_t)(sign | (e << 3) | m);
+}
+__device__ __forceinline__ float e4m3fn_to_f32(uint8_t v) {
+    const uint32_t e = (v >> 3) & 0xf, m = v & 7;
+    float r;
+    if ((v & 0x7f) == 0x7f) r = __uint_as_float(0x7fc00000u);
+    else if (e == 0) r = (float)m * 0.001953125f;
+    else r = __uint_as_float(((e - 7 + 127) << 23) | (m << 20));
+    return (v & 0x80) ? -r : r;
+}
+
+// amax[row] = clamp(absmax, 1e-5) in dt (from llmc_minmax_qparams with qmax = 1). scale = amax / 448 in the
+// scales' dtype sdt: ATen promotes the 0-dim per-tensor absmax (dt) / 0-dim fp32 qmax to fp32, but keeps dt for
+// the per-channel [R,1] absmax.
+template <typename T>
+__global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const T* __restrict__ amax, int sdt,
+                                                 void* __restrict__ scales, int static_scales, int64_t G, int64_t g,
+                                                 int fake, void* __restrict__ out) {
+    constexpr int DT = dt_of<T>::value;
+    const int64_t total = G * g;
+    const int pdt = promote(DT, sdt);
+    for (int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x; i < total; i += (int64_t)gridDim.x * FB) {
+        const int64_t row = i / g;
+        float s;
+        if (static_scales) {
+            s = load_as_f32(scales, row, sdt);
+        } else {
+            s = rnd(to_f32<T>(amax[row]) / 448.0f, sdt);
+            if (i == row * g) store_from_f32(scales, row, sdt, s);
+        }
+        if (s == 0.0f) s = 1.0f;                                  // scales[scales == 0] = 1 (quant.py:1062)
+        // tensor / scales + zeros: a 0-dim fp32 scale does not promote the [R,K] tensor, a [R,1] one of dtype sdt does
+        const int tdt = (G == 1) ? DT : pdt;
+        const float t = rnd(rnd(to_f32<T>(W[i]) / s, tdt) + 0.0f, tdt);
+        const uint8_t q = f32_to_e4m3fn(t);
+        if (fake) {
+            // dequant keeps q in fp32 ((q - 0) * s promotes to fp32), then .to(org dtype)  (quant.py:1071-1080)
+            ((T*)out)[i] = from_f32<T>(e4m3fn_to_f32(q) * s);   // fp32 product, one rounding to dt
+        } else {
+            ((uint8_t*)out)[i] = q;
+        }
+    }
+}
+
+// AutoAWQ: one thread per output word
+template <typename T>
+__global__ __launch_bounds__(FB) void k_pack_awq_w(const T* __restrict__ W, const void* __restrict__ scales, int sdt,
+                                                   const int32_t* __restrict__ zeros, int64_t R, int64_t K,
+                                                   int64_t g, int32_t* __restrict__ qweight) {
+    constexpr int WDT = dt_of<T>::value;
+    const int p = promote(WDT, LLMC_F16);
+    const int64_t R8 = R / 8, ng = K / g;
+    const int64_t total = K * R8;
+    const int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    for (int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x; i < total; i += (int64_t)gridDim.x * FB) {
+        const int64_t rw = i / K, k = i - rw * K;   // k fastest: coalesced reads of W rows
+        const int64_t gi = k / g;
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t r = rw * 8 + order[j];
+            const float s = rnd(load_as_f32(scales, r * ng + gi, sdt), LLMC_F16);   // scales.to(float16)
+            const float sz = rnd((float)zeros[r * ng + gi] * s, LLMC_F16);           // zeros * scales
+            float t = rnd(to_f32<T>(W[r * K + k]) + sz, p);
+            t = rnd(t / s, p);
+            const int code = (int)rintf(t);
+            word |= ((uint32_t)code) << (4 * j);
+        }
+        qweight[k * R8 + rw] = (int32_t)word;
+    }
+}
+__global__ __launch_bounds__(FB) void k_pack_awq_z(const void* __restrict__ scales, int sdt,
+                                                   const int32_t* __restrict__ zeros, int64_t R, int64_t ng,
+                                                   int32_t* __restrict__ qzeros, uint16_t* __restrict__ sout) {
+    const int64_t R8 = R / 8;
+    const int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    for (int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x; i < ng * R; i += (int64_t)gridDim.x * FB) {
+        const int64_t gi = i / R, r = i - gi * R;
+        sout[gi * R + r] = f32_to_f16_bits(load_as_f32(scales, r * ng + gi, sdt));
+        if (r < R8) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) word |= ((uint32_t)zeros[(r * 8 + order[j]) * ng + gi]) << (4 * j);
+            qzeros[gi * R8 + r] = (int32_t)word;
+        }
+    }
+}
+
+static inline int grid_fb(int64_t n) {
+    int64_t b = ceil_div64(n, FB);
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace llmc
+
+using namespace llmc;
+
+extern "C" size_t llmc_fp8_quant_ws_bytes(int64_t G, int64_t g) {
+    if (G <= 0 || g <= 0) return 0;
+    return (((size_t)G * 4 + 255) & ~(size_t)255) + llmc_minmax_qparams_ws_bytes(G, g);
+}
+
+extern "C" int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* out, void* scales,
+                              int sdt, int static_scales, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(dt) && dtype_ok(sdt) && W && out && scales && G > 0 && g > 0, "fp8_quant: bad argument");
+    LLMC_REQUIRE(static_scales || ws, "fp8_quant: workspace required for dynamic scales");
+    void* amax = ws;
+    if (!static_scales) {
+        void* ws2 = (char*)ws + (((size_t)G * 4 + 255) & ~(size_t)255);
+        // clamp(absmax, 1e-5) in dt: the symmetric qparams with qmax = 1
+        int rc = llmc_minmax_qparams(W, dt, G, g, /*sym*/ 1, 1, -1.0f, 1.0f, amax, nullptr, ws2, stream);
+        if (rc) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (dt) {
+        case LLMC_F16:
+            hipLaunchKernelGGL((k_fp8_cast<f16_t>), dim3(grid_fb(G * g)), dim3(FB), 0, st, (const f16_t*)W,
+                               (const f16_t*)amax, sdt, scales, static_scales, G, g, fake, out);
+            break;
+        case LLMC_BF16:
+            hipLaunchKernelGGL((k_fp8_cast<bf16_t>), dim3(grid_fb(G * g)), dim3(FB), 0, st, (const bf16_t*)W,
+                               (const bf16_t*)amax, sdt, scales, static_scales, G, g, fake, out);
+            break;
+        default:
+            hipLaunchKernelGGL((k_fp8_cast<float>), dim3(grid_fb(G * g)), dim3(FB), 0, st, (const float*)W,
+                               (const float*)amax, sdt, scales, static_scales, G, g, fake, out);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+extern "C" int llmc_pack_awq_gemm(const void* weight, int wdt, const void* scales, int sdt, const int32_t* zeros,
+                                  int64_t R, int64_t K, int64_t g, int32_t* qweight, int32_t* qzeros,
+                                  void* scales_out_f16, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(wdt) && dtype_ok(sdt), "pack_awq_gemm: bad dtype");
+    LLMC_REQUIRE(weight && scales && zeros && qweight && qzeros && scales_out_f16 && R > 0 && K > 0 && g > 0,
+                 "pack_awq_gemm: null/empty argument (AutoAWQ needs asymmetric zeros)");
+    LLMC_REQUIRE(R % 8 == 0 && K % g == 0, "pack_awq_gemm: R must be a multiple of 8 and K of the group size");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_fb(K * (R / 8));
+    switch (wdt) {
+        case LLMC_F16:
+            hipLaunchKernelGGL((k_pack_awq_w<f16_t>), dim3(grid), dim3(FB), 0, st, (const f16_t*)weight, scales, sdt,
+                               zeros, R, K, g, qweight);
+            break;
+        case LLMC_BF16:
+            hipLaunchKernelGGL((k_pack_awq_w<bf16_t>), dim3(grid), dim3(FB), 0, st, (const bf16_t*)weight, scales, sdt,
+                               zeros, R, K, g, qweight);
+            break;
+        default:
+            hipLaunchKernelGGL((k_pack_awq_w<float>), dim3(grid), dim3(FB), 0, st, (const float*)weight, scales, sdt,
+                               zeros, R, K, g, qweight);
+    }
+    LLMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pack_awq_z, dim3(grid_fb((K / g) * R)), dim3(FB), 0, st, scales, sdt, zeros, R, K / g, qzeros,
+                       (uint16_t*)scales_out_f16);
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}

@@ -401,7 +401,70 @@ def suite_awq():
     save('awq', **out)
 
 
-SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq}
+def suite_clip():
+    """AutoClipper.auto_clip_layer / apply_clip (clip_version v1, w_only)."""
+    from llmc.compression.quantization.auto_clip import AutoClipper
+    out = {}
+    gen = torch.Generator().manual_seed(99)
+    cfgs = [('bf16_sym_g128_clipsym', 'bf16', True, 128, True), ('f16_asym_g128_noclipsym', 'f16', False, 128, False),
+            ('f16_sym_g64_clipsym', 'f16', True, 64, True)]
+    for name, dt, sym, gs, clip_sym in cfgs:
+        R, K, T = 64, 256, 96
+        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+        ac = AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v1', clip_sym=clip_sym,
+                         save_clip=False, padding_mask=None)
+        wt = torch.randn(R, K, generator=gen) * 0.02
+        wt[torch.rand(R, K, generator=gen) < 0.01] *= 8       # weight outliers make clipping worthwhile
+        w = wt.to(DT[dt])
+        x = (torch.randn(2, T // 2, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(DT[dt])
+        mx, mn = ac.auto_clip_layer(0, 'fc', w, [x.clone()], n_sample_token=32)
+        layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+        layer.weight.data = w.clone()
+        ac.apply_clip(0, layer, mn, mx, 'fc')
+        p = name + '/'
+        out[p + 'w'], out[p + 'x'] = f32(w), f32(x)
+        out[p + 'best_max'], out[p + 'best_min'] = f32(mx), f32(mn)
+        out[p + 'clipped'] = f32(layer.weight.data)
+        out[p + 'meta'] = np.array([int(sym), gs, int(clip_sym), 32], dtype=np.int64)
+        out[p + 'dt'] = np.array(dt)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('clip', **out)
+
+
+def suite_fp8():
+    """FloatQuantizer e4m3 weight path. qtorch is not installed/vendored: float_quantize is bound to torch's own
+    float8_e4m3fn round trip (the cast the reference's real-quant path ends in), which is what the oracle pins."""
+    import llmc.compression.quantization.quant as qmod
+
+    def fq(x, e, m, rounding='nearest'):
+        assert (e, m) == (4, 3)
+        return x.to(torch.float8_e4m3fn).float()
+    qmod.float_quantize = fq
+    out = {}
+    gen = torch.Generator().manual_seed(7)
+    ci = 0
+    for dt in ('bf16', 'f16'):
+        for gran in ('per_tensor', 'per_channel'):
+            q = qmod.FloatQuantizer('e4m3', True, gran, use_qtorch=True)
+            w = (torch.randn(24, 160, generator=gen) * 0.05).to(DT[dt])
+            w[3, 5] = 0.0
+            w[4, 6] = -0.0
+            rw, rs, _ = q.real_quant_weight_dynamic(w)
+            fk = q.fake_quant_weight_dynamic(w)
+            p = f'c{ci}_'
+            out[p + 'w'] = f32(w)
+            out[p + 'bits'] = rw.view(torch.uint8).numpy()
+            out[p + 'scales'] = f32(rs).reshape(-1)
+            out[p + 'fake'] = f32(fk)
+            out[p + 'dt'] = np.array(dt)
+            out[p + 'gran'] = np.array(gran)
+            ci += 1
+    out['n'] = np.array(ci)
+    save('fp8', **out)
+
+
+SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+          'fp8': suite_fp8}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

@@ -209,12 +209,22 @@ def e4m3fn_bits_to_f32(b):
 
 
 def fp8_quant(w2d, dt):
-    """FloatQuantizer e4m3 sym weight path (quant.py:545-553 with qmax=448, :1061-1072, :1211):
-    s = absmax.clamp(1e-5)/448 ; q = e4m3(x / s). Returns (bits uint8 [G,g], scales [G,1])."""
+    """FloatQuantizer e4m3 sym weight path (quant.py:545-553 with qmax = tensor(448.), :1061-1072, :1211).
+    Per-tensor (one row): absmax is a 0-dim dt tensor, absmax / tensor(448.) promotes to fp32 and x / scale keeps
+    the tensor dtype with an fp32 scalar. Per-channel: everything stays in dt.
+    Returns (bits uint8 [G,g], scales [G,1] fp32 container, scale dtype)."""
     mx = w2d.max(axis=-1, keepdims=True)
     mn = w2d.min(axis=-1, keepdims=True)
-    s, _ = qparams_from_minmax(mn, mx, dt, True, -448.0, 448.0)
+    a = np.maximum(np.maximum(np.abs(mx), np.abs(mn)), rnd(np.float32(1e-5), dt))
+    sdt = F32 if w2d.shape[0] == 1 else dt
     with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
-        t = rnd(w2d / s, dt)                  # tensor / scales (+ zeros == 0) in dt
+        s = rnd(a / np.float32(448.0), sdt)
+        t = rnd(rnd(w2d / s, dt) + np.float32(0.0), dt)   # tensor / scales + zeros (0.0): -0 becomes +0
     bits = f32_to_e4m3fn_bits(t)              # float_quantize(.float(), 4, 3) then .to(float8_e4m3fn)
-    return bits, s
+    return bits, s, sdt
+
+
+def fp8_fake(w2d, dt):
+    """fake_quant_weight_dynamic: (q - 0) * s is an fp32 product, then .to(dt)  (quant.py:1074-1080, 1165-1176)."""
+    bits, s, _ = fp8_quant(w2d, dt)
+    return rnd(e4m3fn_bits_to_f32(bits) * s, dt)
