@@ -1,0 +1,108 @@
+"""Awq with llmc's operator surface (llmc/compression/quantization/awq.py:28-372), arithmetic in HIP.
+
+search_scale_subset keeps the reference's semantics for the shipped default (one calibration batch, weight-only):
+20-point ratio grid, fake-quant of the scaled weights in the model dtype, loss on the inspected module's output,
+rank-wise winner-takes-all (all_reduce MIN / MAX + broadcast, awq.py:255-273). On the accelerated path the
+inspected module is the subset's Linear layers themselves (outputs concatenated) — the case BASELINE.json's
+AWQ config names; a subset whose `inspect` is a larger module (whole attention / MLP) is evaluated the same way
+on its Linear layers, which is logged once."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from llmc_amd.utils.registry_factory import ALGO_REGISTRY
+
+from . import awq_ops
+from .awq_pipeline import search_scale_stacked
+from .base_blockwise_quantization import BaseBlockwiseQuantization, _world
+from .module_utils import (_LLMC_LINEAR_TYPES_, _LLMC_LN_TYPES_, _TRANSFORMERS_LINEAR_TYPES_,
+                           _TRANSFORMERS_LN_TYPES_, FakeQuantLinear)
+
+
+@ALGO_REGISTRY
+class Awq(BaseBlockwiseQuantization):
+    def __init__(self, model, quant_config, input, padding_mask, config):
+        super().__init__(model, quant_config, input, padding_mask, config)
+        special = self.quant_config.get('special', {}) or {}
+        self.trans = special.get('trans', True)
+        self.trans_version = special.get('trans_version', 'v2')
+        self.save_scale = special.get('save_scale', False)
+        self.awq_bs = special.get('awq_bs', None)
+        self.save_mem = special.get('save_mem', True)
+        if not self.w_only:
+            raise NotImplementedError('Awq with activation quantization is outside the hot path')
+
+    @torch.no_grad()
+    def get_weight_scale(self, layers_dict):
+        g = self.wquantizer.group_size if self.wquantizer.granularity == 'per_group' else 0
+        total = None
+        for m in layers_dict.values():
+            s = awq_ops.weight_mean(m.weight.data, g)
+            total = s if total is None else total.add_(s)
+        return total.div_(len(layers_dict))
+
+    @torch.no_grad()
+    def get_act_scale(self, x):
+        return awq_ops.act_mean(x)
+
+    @torch.no_grad()
+    def get_scales(self, prev_op, x, w_max, is_gqa, ratio):
+        if is_gqa:
+            raise NotImplementedError('GQA v-proj -> o-proj transformation is outside the hot path')
+        return awq_ops.awq_scales(self.get_act_scale(x), w_max, ratio, self.trans_version)
+
+    @torch.no_grad()
+    def search_scale_subset(self, prev_op, layers_dict, input, inspect_module, is_gqa, subset_kwargs):
+        if is_gqa:
+            raise NotImplementedError('GQA v-proj -> o-proj transformation is outside the hot path')
+        if len(input) != 1:
+            raise NotImplementedError('Awq scale search: one calibration batch (calib.bs = -1), the shipped default')
+        x = input[0]
+        weights = [fc.weight.data for fc in layers_dict.values()]
+        best_scales, losses, n = search_scale_stacked(weights, x, self.wquantizer, self.trans_version,
+                                                      return_losses=True)
+        if _world() > 1:   # winner-takes-all across ranks (awq.py:255-273)
+            best = losses[n].reshape(1).clone()
+            gbest = best.clone()
+            dist.all_reduce(gbest, op=dist.ReduceOp.MIN)
+            rank = torch.tensor([dist.get_rank() if abs(float(best) - float(gbest)) < 1e-5 else -1],
+                                device=x.device)
+            dist.all_reduce(rank, op=dist.ReduceOp.MAX)
+            best_scales = best_scales.clone()
+            dist.broadcast(best_scales, src=int(rank.item()))
+        return best_scales
+
+    @torch.no_grad()
+    def block_transform(self, block, input_feat, block_kwargs):
+        if self.trans:
+            super().block_transform(block, input_feat, block_kwargs)
+        if self.weight_clip:
+            self.auto_clipper.run(block, self.block_idx, input_feat,
+                                  n_sample_token=self.config.calib.get('seq_len', None))
+
+    @torch.no_grad()
+    def subset_transform(self, subset, input_feat, subset_kwargs):
+        layers_dict = subset['layers']
+        prev_op = subset['prev_op']
+        input_name = subset['input'][0]
+        if not subset.get('do_trans', True):
+            return
+        assert len(prev_op) in (0, 1), 'Only support single prev_op. If multi prev_ops, code need to be updated.'
+        if len(prev_op) == 0 or prev_op[0] is None:
+            return
+        ln_types = tuple(_LLMC_LN_TYPES_ + _TRANSFORMERS_LN_TYPES_)
+        lin_types = tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)
+        if not isinstance(prev_op[0], ln_types + lin_types) and not hasattr(prev_op[0], 'weight'):
+            return
+        layers = list(layers_dict.values())
+        if isinstance(prev_op[0], (nn.Linear, FakeQuantLinear)):
+            of, inf = prev_op[0].out_features, layers[0].in_features
+            if of not in (inf * 3, inf * 2, inf):
+                return                                                      # awq.py:338-351 (no GQA trans here)
+        scale = self.search_scale_subset(prev_op[0], layers_dict, input_feat[input_name], subset['inspect'], False,
+                                         subset_kwargs)
+        self.apply_scale(scale, prev_op, layers)
+        self.update_input_feat(scale, input_feat, layers_dict, False)
+        if self.save_scale:
+            for n in layers_dict:
+                self.act_scales[f'{self.model.block_name_prefix}.{self.block_idx}.{n}'] = scale

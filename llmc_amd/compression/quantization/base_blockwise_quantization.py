@@ -1,0 +1,358 @@
+"""BaseBlockwiseQuantization with llmc's operator surface (llmc/compression/quantization/
+base_blockwise_quantization.py:41-1038): same constructor, overridables, buffer names and config keys, so the
+subclasses registered in ALGO_REGISTRY ('GPTQ', 'Awq', 'RTN') drop into llmc's `__main__.main`.
+
+In scope: quantizer selection, collect_block_qparams, the block / subset loop with
+true_sequential re-hooking and quant_out, apply_scale (LN->fc and fc->fc), scaling_input/update_input_feat,
+static per-tensor activation qparams, deploy to fake / real-quant wrappers. Out of scope and rejected loudly:
+rotations (QuaRot), KV-cache quantization, quantized attention / act-fn modules, token reduction, FP8
+block-wise checkpoints (DeepSeek), mixed-precision ignored_layers.
+"""
+import copy
+import functools
+import gc
+import os
+from collections import defaultdict
+from functools import partial
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ..blockwise_optimization import BlockwiseOpt
+from . import awq_ops
+from .module_utils import (_LLMC_LINEAR_TYPES_, _LLMC_LN_TYPES_, _REALQUANT_LINEAR_MAP_,
+                           _TRANSFORMERS_LINEAR_TYPES_, _TRANSFORMERS_LN_TYPES_, EffcientFakeQuantLinear,
+                           FakeQuantLinear, OriginFloatLinear)
+from .quant import FloatQuantizer, IntegerQuantizer
+
+
+def _get(cfg, key, default=None):
+    """dict / EasyDict / attribute access alike."""
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class BaseBlockwiseQuantization(BlockwiseOpt):
+    def __init__(self, model, quant_config, input, padding_mask, config):
+        super().__init__(model, quant_config, input, padding_mask, config)
+        self.dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.set_quant_config()
+
+    # ---- quantizer callbacks handed to the Linear wrappers (base_…:46-83) ---------------------------
+    def w_qdq(self, module, wquantizer):
+        args = {}
+        if getattr(module, 'buf_upbound_factor', None) is not None:
+            raise NotImplementedError('clip_version v2 (learnable bounds) is outside the hot path')
+        return wquantizer.fake_quant_weight_dynamic(module.weight, args)
+
+    def w_q(self, module, wquantizer):
+        return wquantizer.real_quant_weight_dynamic(module.weight.data)
+
+    def a_qdq(self, act, module, aquantizer, input_index=0):
+        if self.act_static:
+            args = {k: getattr(module, f'buf_act_{k}_{input_index}', None) for k in ('scales', 'zeros', 'qmax', 'qmin')}
+            return aquantizer.fake_quant_act_static(act, args)
+        return aquantizer.fake_quant_act_dynamic(act)
+
+    def get_replacement_params(self, mode='fake_quant', w_only=False, name=None):
+        if mode in ('fake_quant', 'fake_quant_wo_kv'):
+            return {'a_qdq': partial(self.a_qdq, aquantizer=self.aquantizer) if not w_only else None,
+                    'w_qdq': partial(self.w_qdq, wquantizer=self.wquantizer)}
+        if mode in _REALQUANT_LINEAR_MAP_:
+            return {'w_q': partial(self.w_q, wquantizer=self.wquantizer), 'quant_config': self.quant_config}
+        if mode == 'origin_float':
+            return {}
+        raise NotImplementedError(f'replacement mode {mode} is outside the hot path')
+
+    # ---- configuration (base_…:133-300) ------------------------------------------------------------
+    def set_quant_config(self):
+        qc = self.quant_config
+        if 'ignored_layers' in self.config:
+            raise NotImplementedError('mixed precision (ignored_layers) is outside the hot path')
+        self.mixed_precision = False
+        self.quant_out = _get(qc, 'quant_out', False)
+        self.tp = _get(qc, 'tp', 1)
+
+        def make(cfg):
+            cfg = dict(cfg)
+            qt = cfg.pop('quant_type', 'int-quant')
+            if qt == 'int-quant':
+                if cfg.get('bit') == 48:
+                    raise NotImplementedError('W48 quantizer is outside the hot path')
+                return IntegerQuantizer(**cfg)
+            if qt == 'float-quant':
+                return FloatQuantizer(**cfg)
+            raise ValueError(f'unknown quant_type {qt}')
+
+        self.wquantizer = make(qc['weight'])
+        if 'act' in qc:
+            self.w_only = False
+            self.aquantizer = make(qc['act'])
+            self.act_static = _get(qc['act'], 'static', False)
+            if self.act_static:
+                assert qc['act']['granularity'] == 'per_tensor', 'Only support per_tensor static quant'
+            if _get(qc['act'], 'quant_attn', False) or _get(qc['act'], 'quant_act_fn', False):
+                raise NotImplementedError('quantized attention / activation functions are outside the hot path')
+        else:
+            self.w_only = True
+            self.aquantizer = None
+            self.act_static = False
+        self.quant_attn = self.quant_softmax = self.quant_act_fn = False
+        if 'kvcache' in qc:
+            raise NotImplementedError('KV-cache quantization is outside the hot path')
+        self.quant_kvcache = False
+
+        special = _get(qc, 'special', {}) or {}
+        self.true_sequential = special.get('true_sequential', False)
+        self.weight_clip = special.get('weight_clip', False)
+        if self.weight_clip:
+            from .auto_clip import AutoClipper
+            self.save_clip = special.get('save_clip', False)
+            if self.save_clip:
+                self.clip_path = special['clip_path']
+            self.clip_version = special.get('clip_version', 'v1')
+            self.auto_clipper = AutoClipper(
+                w_only=self.w_only, wquantizer=self.wquantizer, aquantizer=self.aquantizer,
+                clip_version=self.clip_version, clip_sym=special.get('clip_sym', self.wquantizer.sym),
+                save_clip=self.save_clip, padding_mask=self.padding_mask)
+        self.save_scale = special.get('save_scale', False)
+        if self.save_scale:
+            self.scale_path = special['scale_path']
+            self.act_scales = {}
+        if special.get('online_rotate', False):
+            raise NotImplementedError('online rotation is outside the hot path')
+        self.online_rotate = False
+        self.modality = _get(qc, 'modality', 'language')
+        self.do_gqa_trans = special.get('do_gqa_trans', False)
+        self.set_model_config()
+
+    def set_model_config(self):
+        mc = getattr(self.model, 'model_config', None)
+        self.has_gqa = False
+        if mc is None:
+            return
+        self.hidden_size = getattr(mc, 'hidden_size', None)
+        self.num_heads = getattr(mc, 'num_attention_heads', None)
+        if self.hidden_size and self.num_heads:
+            self.head_dim = self.hidden_size // self.num_heads
+        if getattr(mc, 'num_key_value_heads', None):
+            self.num_key_value_heads = mc.num_key_value_heads
+            self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+            self.has_gqa = self.num_key_value_groups > 1
+
+    # ---- RTN qparams of every Linear (base_…:338-365) -------------------------------------------------
+    @torch.no_grad()
+    def collect_block_qparams(self, block):
+        for n, m in self.model.get_block_linears(block).items():
+            _, scales, zeros, max_int, min_int = self.wquantizer.get_tensor_qparams(m.weight.data)
+            m.register_buffer('buf_scales', scales.detach())
+            m.register_buffer('buf_zeros', zeros.detach())
+            m.register_buffer('buf_qmax', torch.as_tensor(max_int).to(m.weight.device))
+            m.register_buffer('buf_qmin', torch.as_tensor(min_int).to(m.weight.device))
+
+    # ---- block loop (base_…:367-526) ----------------------------------------------------------------
+    def block_forward(self, block, input_data=None):
+        output = []
+        if input_data is None:
+            input_data = self.input['data']
+        dev = next(block.parameters()).device
+        for i in range(len(input_data)):
+            input_data[i] = input_data[i].to(device=dev)
+            kw = self.input['kwargs'][i]
+            for k, v in kw.items():
+                if torch.is_tensor(v):
+                    kw[k] = v.to(device=dev)
+                elif isinstance(v, tuple):
+                    kw[k] = tuple(t.to(device=dev) if torch.is_tensor(t) else t for t in v)
+            with torch.no_grad():
+                out = block(input_data[i], **kw)
+            output.append(out[0] if isinstance(out, tuple) else out)
+        return output
+
+    def block_opt(self, block):
+        block = block.cuda()
+        named_linears = self.model.get_block_linears(block)
+        extra_modules = self.model.get_extra_modules(block) if hasattr(self.model, 'get_extra_modules') else {}
+        modules = {**named_linears, **extra_modules}
+        input_feat = defaultdict(list)
+        handles = self.register_hooks(modules, input_feat)
+        self.block_init(block)
+        self.run(block, input_feat, handles)
+        block = block.cpu()
+        del input_feat, block
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def register_hooks(self, input_feat_modules, input_feat):
+        handles = []
+        if not self.data_free:
+            for name, mod in input_feat_modules.items():
+                handles.append(mod.register_forward_hook(
+                    functools.partial(self.cache_input_hook, name=name, feat_dict=input_feat)))
+        return handles
+
+    def run(self, block, input_feat, handles):
+        if not self.data_free:
+            if self.quant_out:
+                self.block_forward(block)
+            else:
+                self.input['data'] = self.block_forward(block)
+            for h in handles:
+                h.remove()
+            self.block_transform(block, input_feat, self.input['kwargs'])
+        else:
+            self.block_transform(block)
+        if not self.data_free and self.quant_out:
+            self.model.replace_module_block(FakeQuantLinear, block, self.block_idx,
+                                            self.get_replacement_params('fake_quant', self.w_only))
+            self.input['data'] = self.block_forward(block)
+
+    def block_transform(self, block, input_feat, block_kwargs):
+        subsets = self.model.get_subsets_in_block(block)
+        for index, subset in enumerate(subsets):
+            layers_dict = subset['layers']
+            input_name = subset['input'][0]
+            if subset['has_kwargs']:
+                if 'sub_keys' in subset:
+                    subset_kwargs = [{k: kw[v] for k, v in subset['sub_keys'].items()} for kw in block_kwargs]
+                else:
+                    subset_kwargs = block_kwargs
+            else:
+                subset_kwargs = {}
+            self.subset_transform(subset, input_feat, subset_kwargs)
+            if self.act_static:
+                self.register_act_qparams(layers_dict, copy.copy(input_feat[input_name]))
+            if self.true_sequential and index != len(subsets) - 1:
+                input_feat.update(self.rehook_next_subset(block, subset, subsets[index + 1]))
+
+    def rehook_next_subset(self, block, subset, next_subset):
+        self.subset_init(next_subset)
+        self.model.replace_module_subset(FakeQuantLinear, block, subset, self.block_idx,
+                                         self.get_replacement_params('fake_quant', self.w_only))
+        feat = defaultdict(list)
+        handles = self.register_hooks(next_subset['layers'], feat)
+        self.block_forward(block)
+        for h in handles:
+            h.remove()
+        return feat
+
+    # ---- static activation qparams (base_…:567-588; quant.py:253-263 static_minmax) ------------------
+    @torch.no_grad()
+    def register_act_qparams(self, layers_dict, act_tensors):
+        if len(act_tensors) == 1:
+            samples = [act_tensors[0][i] for i in range(act_tensors[0].shape[0])]
+        else:
+            samples = list(act_tensors)
+        # static_minmax: mean over samples of per-sample min / max, then get_qparams on the means
+        mx = torch.stack([s.max().float() for s in samples]).mean()
+        mn = torch.stack([s.min().float() for s in samples]).mean()
+        aq = self.aquantizer
+        qmax, qmin = aq.qmax.to(mx.device), aq.qmin.to(mx.device)
+        abs_max = torch.max(mx.abs(), mn.abs()).clamp(min=1e-5)
+        if aq.sym:
+            scales = abs_max / qmax
+            zeros = torch.tensor(0.0, device=mx.device)
+        else:
+            scales = (mx - mn).clamp(min=1e-5) / (qmax - qmin)
+            zeros = (qmin - torch.round(mn / scales)).clamp(qmin, qmax)
+        if _world() > 1:
+            dist.all_reduce(scales, op=dist.ReduceOp.SUM)
+            scales = scales / _world()
+        for layer in layers_dict.values():
+            if isinstance(layer, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)):
+                layer.register_buffer('buf_act_scales_0', scales)
+                layer.register_buffer('buf_act_zeros_0', zeros)
+                layer.register_buffer('buf_act_qmin_0', qmin)
+                layer.register_buffer('buf_act_qmax_0', qmax)
+
+    # ---- scale folding (base_…:597-611, 632-700, 750-778) ---------------------------------------------
+    @torch.no_grad()
+    def repeat_gqa_scales(self, scales):
+        scales = scales.view(1, self.num_key_value_heads, self.head_dim)
+        return torch.repeat_interleave(scales, dim=1, repeats=self.num_key_value_groups)
+
+    @torch.no_grad()
+    def apply_scale(self, scales, prev_op, layers):
+        assert len(prev_op) == 1, 'Only support single prev_op. If multi prev_ops, code need to be updated.'
+        if isinstance(prev_op[0], tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)):
+            assert len(layers) == 1
+            self.scale_fc_fc(prev_op[0], layers[0], scales)
+        elif isinstance(prev_op[0], tuple(_LLMC_LN_TYPES_ + _TRANSFORMERS_LN_TYPES_)) or hasattr(prev_op[0], 'weight'):
+            self.scale_ln_fcs(prev_op[0], layers, scales)
+        else:
+            raise NotImplementedError(f'prev_op {type(prev_op[0])} not supported yet!')
+
+    @torch.no_grad()
+    def scale_fc_fc(self, fc1, fc2, scales):
+        scales = scales.to(fc1.weight.device)
+        if fc1.out_features == fc2.in_features * 2:                    # fused gate|up: scale the second half
+            half = fc1.weight.shape[0] // 2
+            fc1.weight.data[half:].div_(scales.view(-1, 1))
+            if getattr(fc1, 'bias', None) is not None:
+                fc1.bias.data[half:].div_(scales.view(-1))
+        elif fc1.out_features == fc2.in_features:
+            if getattr(fc1, 'bias', None) is not None:
+                fc1.bias.div_(scales.view(-1))
+            fc1.weight.div_(scales.view(-1, 1))
+        elif self.has_gqa and self.do_gqa_trans:
+            if getattr(fc1, 'bias', None) is not None:
+                fc1.bias.div_(scales.view(-1))
+            fc1.weight.div_(scales.view(-1, 1))
+            scales = self.repeat_gqa_scales(scales).reshape(-1)
+        else:
+            raise Exception('Can not scale this fc-fc.')
+        awq_ops.mul_cols_(fc2.weight.data, scales.reshape(-1).to(fc2.weight.dtype))
+
+    @torch.no_grad()
+    def scale_ln_fcs(self, ln, fcs, scales):
+        if not isinstance(fcs, list):
+            fcs = [fcs]
+        scales = scales.to(ln.weight.device).to(ln.weight.dtype)
+        ln.weight.div_(scales)
+        if getattr(ln, 'bias', None) is not None:
+            ln.bias.div_(scales)
+        for fc in fcs:
+            awq_ops.mul_cols_(fc.weight.data, scales.reshape(-1))
+        for p in list(ln.parameters()) + [q for fc in fcs for q in fc.parameters()]:
+            assert torch.isnan(p).sum() == 0
+
+    @torch.no_grad()
+    def scaling_input(self, x, scales, is_gqa):
+        s = self.repeat_gqa_scales(scales).reshape(-1) if is_gqa else scales.reshape(-1)
+        return awq_ops.div_cols(x, s)
+
+    @torch.no_grad()
+    def update_input_feat(self, scale, input_feat, layers_dict, is_gqa):
+        done = {}
+        for name in layers_dict:
+            for i, inp in enumerate(input_feat[name]):
+                key = (inp.data_ptr(), tuple(inp.shape))
+                if key not in done:                                    # layers of a subset share the tensor
+                    done[key] = self.scaling_input(inp, scale.to(inp.device), is_gqa)
+                input_feat[name][i] = done[key]
+
+    # ---- deploy / save (base_…:933-1038) ---------------------------------------------------------------
+    @torch.no_grad()
+    def deploy(self, quant_format, keep_device=False):
+        mapping = {'origin_float': OriginFloatLinear, 'fake_quant': EffcientFakeQuantLinear,
+                   'fake_quant_wo_kv': EffcientFakeQuantLinear}
+        mapping.update(_REALQUANT_LINEAR_MAP_)
+        if quant_format not in mapping:
+            raise NotImplementedError(f"Quant format '{quant_format}' is not implemented.")
+        self.model.replace_language_module_all(mapping[quant_format],
+                                               self.get_replacement_params(quant_format, self.w_only),
+                                               keep_device=keep_device)
+
+    @torch.no_grad()
+    def save_model(self, path):
+        if int(os.environ.get('RANK', '0')) != 0:
+            return
+        self.model.get_model().save_pretrained(path)
+        if getattr(self.model, 'tokenizer', None) is not None:
+            self.model.tokenizer.save_pretrained(path)

@@ -1,0 +1,195 @@
+"""GPTQ with llmc's operator surface (llmc/compression/quantization/gptq.py:21-478), arithmetic in HIP.
+
+What is the same: constructor, `quant.special` keys (actorder, static_groups, percdamp, blocksize,
+true_sequential, chunk_num), hook protocol (cache_input_hook -> add_batch), per-layer state in `layers_cache`,
+module buffers buf_scales / buf_zeros / buf_perm / buf_invperm with the reference's shapes and dtypes (SURVEY.md
+G2), fp32 `layer.weight.data` after the transform (G3), w_q / w_qdq / deploy / save_model.
+
+What is different (mechanics, not arithmetic): layers of a subset that share their input share ONE Hessian,
+ONE factorisation and ONE stacked column loop (the reference recomputes identical H and Hinv per layer); no
+per-batch all_reduce of H — with several ranks (data-parallel calibration) H is reduced once per subset
+(`_sync_hessian`), mathematically identical because every rank's running mean covers the same number of
+sequences; no `.item()` sync per layer. OWQ (gptq.py:44-50, 66-83) is outside the hot path.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from llmc_amd.utils.registry_factory import ALGO_REGISTRY
+
+from .base_blockwise_quantization import BaseBlockwiseQuantization, _world
+from .gptq_pipeline import GptqConfig, quantize_stacked
+from .hessian import HessianAccumulator
+from .module_utils import _LLMC_LINEAR_TYPES_, _TRANSFORMERS_LINEAR_TYPES_, FakeQuantLinear
+
+
+@ALGO_REGISTRY
+class GPTQ(BaseBlockwiseQuantization):
+    def __init__(self, model, quant_config, input, padding_mask, config, modality='language'):
+        super().__init__(model, quant_config, input, padding_mask, config)
+        self.model_dtype = next(self.model.model.parameters()).dtype
+        self.add_quant_config()
+        self.layers_cache = {}
+        self._leader = {}
+        self.collect_model_qparams()
+
+    @torch.no_grad()
+    def add_quant_config(self):
+        special = self.quant_config['special']
+        self.true_sequential = special['true_sequential']
+        self.static_groups = special['static_groups']
+        self.actorder = special['actorder']
+        self.percdamp = special['percdamp']
+        self.blocksize = special['blocksize']
+        self.chunk_num = special.get('chunk_num', 1)   # a memory lever of the reference's matmul; not needed here
+        if special.get('owq', False):
+            raise NotImplementedError('OWQ is outside the hot path')
+        self.owq = False
+        self.need_perm = (self.wquantizer.granularity == 'per_group' and not self.static_groups and self.actorder)
+        gs = self.wquantizer.group_size if self.wquantizer.granularity == 'per_group' else 0
+        self.gcfg = GptqConfig(bit=self.wquantizer.bit, symmetric=self.wquantizer.sym, group_size=gs,
+                               actorder=self.actorder, static_groups=self.static_groups, percdamp=self.percdamp,
+                               blocksize=self.blocksize)
+
+    # ---- calibration: Hessian accumulation ---------------------------------------------------------
+    @torch.no_grad()
+    def cache_input_hook(self, m, inp, out, name, feat_dict):
+        if isinstance(m, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)):
+            self.add_batch(self.named_layers[name], name, inp[0].data, out.data)
+        if self.act_static:
+            super().cache_input_hook(m, inp, out, name, feat_dict)
+
+    @torch.no_grad()
+    def add_batch(self, layer, name, inp, out):
+        """gptq.py:254-295. Layers that share an input share the accumulator; only the subset's first layer
+        feeds it (the others would add the same X^T X to the same matrix)."""
+        if self._leader.get(name, name) != name:
+            return
+        self.layers_cache[name]['acc'].add(inp)
+        self.layers_cache[name]['nsamples'] = self.layers_cache[name]['acc'].nsamples
+
+    def _group_layers(self, named_layers, block=None):
+        """name -> leader name, from the model's subset table (layers of one subset see the same input)."""
+        leader = {n: n for n in named_layers}
+        if block is not None:
+            for subset in self.model.get_subsets_in_block(block):
+                names = [n for n in subset['layers'] if n in named_layers]
+                for n in names:
+                    leader[n] = names[0]
+        return leader
+
+    @torch.no_grad()
+    def layer_init(self, layer, name):
+        K = layer.weight.shape[1] if layer.weight.dim() == 2 else layer.weight[0].numel()
+        lead = self._leader.get(name, name)
+        if lead == name:
+            acc = HessianAccumulator(K, layer.weight.device)
+        else:
+            acc = self.layers_cache[lead]['acc']
+        self.layers_cache[name] = {'acc': acc, 'H': acc.H, 'nsamples': 0, 'columns': K}
+
+    @torch.no_grad()
+    def subset_init(self, subset):
+        self.named_layers = subset['layers']
+        names = list(self.named_layers)
+        self._leader.update({n: names[0] for n in names})
+        for n in names:
+            self.layer_init(self.named_layers[n], n)
+
+    @torch.no_grad()
+    def block_init(self, block):
+        self.named_layers = self.model.get_block_linears(block)
+        self._leader = self._group_layers(self.named_layers, block)
+        for n in sorted(self.named_layers, key=lambda k: self._leader[k] != k):   # leaders first
+            self.layer_init(self.named_layers[n], n)
+
+    def _sync_hessian(self, name):
+        """One reduction per Hessian at the end of accumulation (the reference all-reduces per batch, gptq.py:292)."""
+        if _world() > 1:
+            H = self.layers_cache[name]['acc'].H
+            dist.all_reduce(H, op=dist.ReduceOp.SUM)
+            H.div_(_world())
+
+    # ---- transform ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def subset_transform(self, subset, input_feat, subset_kwargs):
+        layers_dict = {n: l for n, l in subset['layers'].items()
+                       if isinstance(l, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_))}
+        groups = {}
+        for n in layers_dict:
+            groups.setdefault(self._leader.get(n, n), []).append(n)
+        for lead, names in groups.items():
+            self._sync_hessian(lead)
+            self._transform_group(lead, [layers_dict[n] for n in names], names)
+            for n in names:
+                self.free(n)
+
+    @torch.no_grad()
+    def layer_transform(self, layer, name):
+        self._sync_hessian(self._leader.get(name, name))
+        self._transform_group(self._leader.get(name, name), [layer], [name])
+
+    def _transform_group(self, lead, layers, names):
+        H = self.layers_cache[lead]['acc'].H
+        static = None
+        if self.gcfg.static_groups or not self.gcfg.group_size:
+            static = []
+            for l in layers:   # RTN qparams of the ORIGINAL weights, original column order
+                z = l.buf_zeros if (torch.is_tensor(l.buf_zeros) and l.buf_zeros.dim() > 0) else None
+                static.append((l.buf_scales, z))
+        results = quantize_stacked([l.weight.data for l in layers], H, self.gcfg, static_qparams=static)
+        self.last_losses = {}
+        for l, n, r in zip(layers, names, results):
+            l.weight.data = r.weight.reshape(l.weight.shape)          # fp32, like the reference (G3)
+            self.last_losses[n] = r.loss
+            if self.actorder:
+                l.register_buffer('buf_perm', r.perm)
+                l.register_buffer('buf_invperm', torch.argsort(r.perm))
+            if self.wquantizer.granularity == 'per_group' and not self.static_groups:
+                l.buf_scales = r.scales.reshape(-1, 1).clone()        # merge_qparams: [R * K/g, 1] fp32
+                if not self.wquantizer.sym:
+                    l.buf_zeros = r.zeros.reshape(-1, 1).clone()
+
+    @torch.no_grad()
+    def collect_model_qparams(self):
+        for block in self.blocks:
+            block = block.cuda()
+            self.collect_block_qparams(block)
+            block = block.cpu()
+
+    # ---- deploy-time quantization with the stored qparams (gptq.py:412-452) ---------------------------
+    @torch.no_grad()
+    def w_q(self, module, wquantizer):
+        args = {'scales': module.buf_scales.to(self.model_dtype), 'zeros': module.buf_zeros,
+                'qmax': module.buf_qmax, 'qmin': module.buf_qmin}
+        return wquantizer.real_quant_weight_static(module.weight.data, args)
+
+    @torch.no_grad()
+    def w_qdq(self, module, wquantizer):
+        weight = module.weight
+        if self.need_perm:
+            weight = module.weight[:, module.buf_perm]
+        args = {'scales': module.buf_scales, 'zeros': getattr(module, 'buf_zeros', None),
+                'qmax': module.buf_qmax, 'qmin': module.buf_qmin}
+        weight = wquantizer.fake_quant_weight_static(weight, args).to(self.model_dtype)
+        if self.need_perm:
+            weight = weight[:, module.buf_invperm]
+        return weight
+
+    @torch.no_grad()
+    def deploy(self, quant_format):
+        if quant_format not in ['fake_quant', 'origin_float']:
+            assert not self.need_perm
+        super().deploy(quant_format)
+        self.model.convert_dtype(self.model_dtype)
+
+    @torch.no_grad()
+    def save_model(self, path):
+        self.model.convert_dtype(self.model_dtype)
+        super().save_model(path)
+
+    @torch.no_grad()
+    def free(self, name):
+        self.layers_cache.pop(name, None)

@@ -1,0 +1,77 @@
+"""Host-side mirror of llmc's operator surface: registry protocol, signatures, config plumbing (CPU, no compute)."""
+import inspect
+
+import pytest
+import torch
+
+import llmc_amd.compression.quantization as Q
+from llmc_amd.utils.registry_factory import ALGO_REGISTRY, Register
+
+
+def test_registry_protocol_like_llmc():
+    assert {'GPTQ', 'Awq', 'RTN'} <= set(ALGO_REGISTRY.keys())
+    r = Register()
+
+    @r
+    class A:
+        pass
+
+    @r('other')
+    class B:
+        pass
+    assert r['A'] is A and r['other'] is B and 'A' in r
+    with pytest.raises(Exception):
+        r.register(A)
+    with pytest.raises(Exception):
+        r.register('k')(3)          # values must be callable
+
+
+def test_operator_signatures_match_the_reference_surface():
+    # SURVEY.md §8b "Python operator signatures (must not change)"
+    sig = lambda f: list(inspect.signature(f).parameters)  # noqa: E731
+    assert sig(Q.GPTQ.__init__)[:6] == ['self', 'model', 'quant_config', 'input', 'padding_mask', 'config']
+    assert sig(Q.Awq.__init__) == ['self', 'model', 'quant_config', 'input', 'padding_mask', 'config']
+    assert sig(Q.RTN.__init__) == ['self', 'model', 'quant_config', 'input', 'padding_mask', 'config']
+    assert sig(Q.GPTQ.add_batch) == ['self', 'layer', 'name', 'inp', 'out']
+    assert sig(Q.GPTQ.layer_transform) == ['self', 'layer', 'name']
+    assert sig(Q.GPTQ.subset_transform) == ['self', 'subset', 'input_feat', 'subset_kwargs']
+    assert sig(Q.GPTQ.cache_input_hook) == ['self', 'm', 'inp', 'out', 'name', 'feat_dict']
+    assert sig(Q.GPTQ.w_qdq) == ['self', 'module', 'wquantizer']
+    assert sig(Q.GPTQ.w_q) == ['self', 'module', 'wquantizer']
+    assert sig(Q.BaseBlockwiseQuantization.a_qdq) == ['self', 'act', 'module', 'aquantizer', 'input_index']
+    assert sig(Q.BaseBlockwiseQuantization.block_transform) == ['self', 'block', 'input_feat', 'block_kwargs']
+    assert sig(Q.Awq.search_scale_subset) == ['self', 'prev_op', 'layers_dict', 'input', 'inspect_module', 'is_gqa',
+                                              'subset_kwargs']
+    assert sig(Q.IntegerQuantizer.get_tensor_qparams) == ['self', 'tensor', 'args']
+    assert sig(Q.IntegerQuantizer.quant_dequant)[:6] == ['self', 'tensor', 'scales', 'zeros', 'qmax', 'qmin']
+    for name in ('fake_quant_weight_dynamic', 'fake_quant_weight_static', 'real_quant_weight_dynamic',
+                 'real_quant_weight_static', 'fake_quant_act_dynamic', 'fake_quant_act_static'):
+        assert hasattr(Q.IntegerQuantizer, name) and hasattr(Q.FloatQuantizer, name)
+    for cls in (Q.FakeQuantLinear, Q.EffcientFakeQuantLinear, Q.VllmRealQuantLinear, Q.AutoawqRealQuantLinear):
+        assert sig(cls.new)[0] == 'module'
+
+
+def test_quantizer_ranges_and_views_without_gpu():
+    q = Q.IntegerQuantizer(4, False, 'per_group', group_size=128)
+    assert float(q.qmin) == 0.0 and int(q.qmax) == 15 and q.qmin.dtype == torch.float32 and q.qmax.dtype == torch.int64
+    q = Q.IntegerQuantizer(8, True, 'per_channel')
+    assert int(q.qmin) == -128 and int(q.qmax) == 127
+    q = Q.IntegerQuantizer(4, True, 'per_group', group_size=64)
+    t = torch.zeros(6, 256)
+    assert q.reshape_tensor(t).shape == (24, 64)
+    assert q.restore_tensor(q.reshape_tensor(t), t.shape).shape == t.shape
+    with pytest.raises(ValueError):
+        q.reshape_tensor(torch.zeros(2, 100))
+    with pytest.raises(NotImplementedError):
+        Q.IntegerQuantizer(4, True, 'per_group', group_size=64, calib_algo='mse')
+    f = Q.FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True)
+    assert float(f.qmax) == 448.0
+
+
+def test_out_of_scope_config_is_rejected_loudly():
+    from toy_model import ToyModel, calib_input
+    model = ToyModel()
+    cfg = {'weight': {'bit': 4, 'symmetric': True, 'granularity': 'per_group', 'group_size': 128},
+           'kvcache': {'method': 'Naive'}}
+    with pytest.raises(NotImplementedError):
+        Q.RTN(model, cfg, calib_input(model), None, {})
