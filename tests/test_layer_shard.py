@@ -1,0 +1,71 @@
+"""Multi-rank orchestration of the layer-sharded path, world_size 2 over Gloo on CPU. The compute callback is a
+stand-in (the product's kernels need a GPU); what is checked is ownership, the broadcast and the ordered gather."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from llmc_amd.dist import layer_shard as LS
+    assert LS.world_info() == (rank, world)
+    # independent units: every unit exactly once, in order, on rank 0
+    res = LS.run_independent(7, lambda u: {'unit': u, 'rank': rank, 'w': torch.full((2, 2), float(u))})
+    if rank == 0:
+        assert [r['unit'] for r in res] == list(range(7))
+        assert [r['rank'] for r in res] == [u % world for u in range(7)]
+        assert all(float(r['w'][0, 0]) == r['unit'] for r in res)
+    # cooperative subset: rank 1 owns the activations, everybody receives the same tensor
+    x = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4) if rank == 1 else None
+    meta = ((2, 3, 4), torch.float32, 'cpu')
+    out = LS.run_block_cooperative(['q', 'k', 'v'], x, 1, lambda name, xs: (name, float(xs.sum()), rank), meta)
+    if rank == 0:
+        assert [o[0] for o in out] == ['q', 'k', 'v'] and all(o[1] == 276.0 for o in out)
+        assert [o[2] for o in out] == [0, 1, 0]
+    # share the Hessian instead of the activations
+    out = LS.run_block_cooperative(['gate', 'up'], x, 1, lambda name, h: (name, tuple(h.shape), float(h.trace())), meta,
+                                   share='hessian', hessian_fn=lambda t: t.reshape(-1, 4).T @ t.reshape(-1, 4))
+    if rank == 0:
+        xr = torch.arange(24, dtype=torch.float32).reshape(-1, 4)
+        assert all(o[1] == (4, 4) and abs(o[2] - float((xr.T @ xr).trace())) < 1e-3 for o in out)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, 'ok'))
+
+
+def test_layer_shard_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, 'ok'), (1, 'ok')]
+
+
+def test_ownership_is_a_partition():
+    from llmc_amd.dist.layer_shard import owner_of, units_of
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 224):
+            seen = sorted(u for r in range(world) for u in units_of(r, n, world))
+            assert seen == list(range(n))
+            assert all(owner_of(u, world) == r for r in range(world) for u in units_of(r, n, world))
+            sizes = [len(units_of(r, n, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
