@@ -353,35 +353,59 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     LLMC_LAUNCH_CHECK();
 
     const int nblk = (K + NB - 1) / NB;
-    // ---- blocked upper Cholesky Wk = U'^T U'
-    for (int b = 0; b < nblk; ++b) {
-        const int k0 = b * NB;
-        const int nb = K - k0 < NB ? K - k0 : NB;
-        float* Vb = Vbuf + (size_t)b * NB * NB;
-        hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 2 * NB * PLD * sizeof(float), st, Wk, (int64_t)K, k0, nb,
-                           Vb, info_dev);
-        LLMC_LAUNCH_CHECK();
-        const int nrem = K - k0 - nb;
-        if (nrem <= 0) break;
-        float* P = Wk + (size_t)k0 * K + k0 + nb;  // panel rows k0..k0+nb, cols k0+nb..K
-        SgemmArgs g{};
-        // panel solve: P = V^T P  (op(A)[i][k] = V[k][i], lower triangular)
-        g.A = Vb; g.lda = NB; g.B = P; g.ldb = K; g.C = P; g.ldc = K;
-        g.M = g.M_last = nb; g.N = g.N_last = nrem; g.Kd = g.Kd_last = nb;
-        g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
-        int rc = sgemm_launch(g, true, false, st);
-        if (rc) return rc;
-        // trailing update: T -= P^T P on the upper tiles
-        SgemmArgs u{};
-        u.A = P; u.lda = K; u.B = P; u.ldb = K;
-        u.C = Wk + (size_t)(k0 + nb) * K + k0 + nb; u.ldc = K;
-        u.M = u.M_last = nrem; u.N = u.N_last = nrem; u.Kd = u.Kd_last = nb;
-        u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
-        rc = sgemm_launch(u, true, false, st);
-        if (rc) return rc;
+    // ---- blocked upper Cholesky Wk = U'^T U', two-level: 128-wide factor steps inside 512-wide outer blocks.
+    // Inside an outer block every step updates only the rows of that block (Kd = 128, few rows); the rows
+    // beyond it receive ONE symmetric update with Kd = 512 per outer block, which is where the flops are and
+    // runs the fp32-MFMA GEMM at its long-K efficiency instead of its short-K one (tools/bench_sgemm.py).
+    const int NBO = 4 * NB;
+    for (int k0 = 0; k0 < K; k0 += NBO) {
+        const int nbo = K - k0 < NBO ? K - k0 : NBO;
+        const int oend = k0 + nbo;
+        for (int c0 = k0; c0 < oend; c0 += NB) {
+            const int b = c0 / NB;
+            const int nb = K - c0 < NB ? K - c0 : NB;
+            float* Vb = Vbuf + (size_t)b * NB * NB;
+            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 2 * NB * PLD * sizeof(float), st, Wk, (int64_t)K, c0,
+                               nb, Vb, info_dev);
+            LLMC_LAUNCH_CHECK();
+            const int nrem = K - c0 - nb;
+            if (nrem <= 0) break;
+            float* P = Wk + (size_t)c0 * K + c0 + nb;  // panel rows c0..c0+nb, cols c0+nb..K
+            SgemmArgs g{};
+            // panel solve: P = V^T P  (op(A)[i][k] = V[k][i], lower triangular)
+            g.A = Vb; g.lda = NB; g.B = P; g.ldb = K; g.C = P; g.ldc = K;
+            g.M = g.M_last = nb; g.N = g.N_last = nrem; g.Kd = g.Kd_last = nb;
+            g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
+            int rc = sgemm_launch(g, true, false, st);
+            if (rc) return rc;
+            // in-block trailing update: rows c0+nb .. oend only
+            const int mrows = oend - (c0 + nb);
+            if (mrows > 0) {
+                SgemmArgs u{};
+                u.A = P; u.lda = K; u.B = P; u.ldb = K;
+                u.C = Wk + (size_t)(c0 + nb) * K + c0 + nb; u.ldc = K;
+                u.M = u.M_last = mrows; u.N = u.N_last = nrem; u.Kd = u.Kd_last = nb;
+                u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
+                rc = sgemm_launch(u, true, false, st);
+                if (rc) return rc;
+            }
+        }
+        const int nfar = K - oend;
+        if (nfar > 0) {
+            // far trailing update: T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo)
+            float* P = Wk + (size_t)k0 * K + oend;
+            SgemmArgs u{};
+            u.A = P; u.lda = K; u.B = P; u.ldb = K;
+            u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
+            u.M = u.M_last = nfar; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
+            u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
+            int rc = sgemm_launch(u, true, false, st);
+            if (rc) return rc;
+        }
     }
+    (void)nblk;
     // ---- V = U'^-1: inverted diagonal blocks, then doubling levels
-    hipLaunchKernelGGL(k_place_diag_inv, dim3(nblk), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf);
+    hipLaunchKernelGGL(k_place_diag_inv, dim3((K + NB - 1) / NB), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf);
     LLMC_LAUNCH_CHECK();
     for (int64_t h = NB; h < K; h *= 2) {
         const int npairs = (int)((K - h + 2 * h - 1) / (2 * h));  // pairs with a non-empty right block

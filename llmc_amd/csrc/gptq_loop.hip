@@ -29,7 +29,8 @@ struct GptqBlockArgs {
     const float* U;       // [K, K] upper factor
     float* Wout;          // [R, K] tmp
     float* losses;        // [R, K] or null
-    float* Err;           // [R, 128] err of this block
+    float* Err;           // err of this block: Err[row * err_ld + c], c < 128
+    int err_ld;
     float* scales;        // [R, ng]
     float* zeros;         // [R, ng] or null (sym static)
     const int32_t* col_group;  // [K] group of processed column (static mode)
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void k_gptq_block(GptqBlockArgs a) {
             a.Wout[row * a.K + a.i1 + c] = w[e];
             if (a.losses) a.losses[row * a.K + a.i1 + c] = ls[e];
         }
-        a.Err[row * BS + c] = (c < a.count) ? er[e] : 0.0f;
+        a.Err[row * a.err_ld + c] = (c < a.count) ? er[e] : 0.0f;
     }
     if (!a.static_mode && p == 0) {
         // qparams of the groups that start in this block (gsz divides 128, multiple of 16)
@@ -192,9 +193,11 @@ __global__ __launch_bounds__(256) void k_gptq_block(GptqBlockArgs a) {
 
 using namespace llmc;
 
+static constexpr int GRP = 4;  // 128-column blocks per outer group (far updates are applied once per group)
+
 extern "C" size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K) {
     if (R <= 0 || K <= 0) return 0;
-    return (size_t)R * BS * sizeof(float);
+    return (size_t)R * BS * GRP * sizeof(float);
 }
 
 extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
@@ -218,25 +221,44 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
         LLMC_REQUIRE(col_group != nullptr, "gptq_quantize: col_group required with static groups");
     }
     hipStream_t st = (hipStream_t)stream;
-    float* Err = (float*)ws;
-    for (int64_t i1 = 0; i1 < K; i1 += BS) {
-        const int count = (int)(K - i1 < BS ? K - i1 : BS);
-        GptqBlockArgs a;
-        a.W = W; a.U = Hinv; a.Wout = Wout; a.losses = losses; a.Err = Err;
-        a.scales = scales; a.zeros = zeros; a.col_group = per_channel ? nullptr : col_group;
-        a.R = R; a.K = (int)K; a.i1 = (int)i1; a.count = count; a.ng = ng; a.gsz = static_mode ? BS : gsz;
-        a.static_mode = static_mode; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
-        const int grid = (int)ceil_div64(R, 16);
-        hipLaunchKernelGGL(k_gptq_block, dim3(grid), dim3(256), 0, st, a);
-        LLMC_LAUNCH_CHECK();
-        const int64_t i2 = i1 + count;
-        if (i2 < K) {
+    float* Err = (float*)ws;   // [R, GRP*128]: the err columns of the current outer group
+    const int ELD = BS * GRP;
+    // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as
+    // "W -= chain over the block's 128 k" (gptq.py:244). Columns inside the current outer group get them right
+    // after each block (the next block needs them); columns beyond the group get the group's GRP updates in one
+    // phased GEMM that keeps the C tile in registers — same arithmetic, one pass over the far columns per group.
+    for (int64_t g0 = 0; g0 < K; g0 += (int64_t)BS * GRP) {
+        const int64_t gend = g0 + (int64_t)BS * GRP < K ? g0 + (int64_t)BS * GRP : K;
+        for (int64_t i1 = g0; i1 < gend; i1 += BS) {
+            const int count = (int)(K - i1 < BS ? K - i1 : BS);
+            GptqBlockArgs a;
+            a.W = W; a.U = Hinv; a.Wout = Wout; a.losses = losses;
+            a.Err = Err + (i1 - g0); a.err_ld = ELD;
+            a.scales = scales; a.zeros = zeros; a.col_group = per_channel ? nullptr : col_group;
+            a.R = R; a.K = (int)K; a.i1 = (int)i1; a.count = count; a.ng = ng; a.gsz = static_mode ? BS : gsz;
+            a.static_mode = static_mode; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
+            const int grid = (int)ceil_div64(R, 16);
+            hipLaunchKernelGGL(k_gptq_block, dim3(grid), dim3(256), 0, st, a);
+            LLMC_LAUNCH_CHECK();
+            const int64_t i2 = i1 + count;
+            if (i2 < gend) {   // near columns of the group
+                SgemmArgs g{};
+                g.A = Err + (i1 - g0); g.lda = ELD;
+                g.B = Hinv + i1 * K + i2; g.ldb = K;
+                g.C = W + i2; g.ldc = K;
+                g.M = g.M_last = (int)R; g.N = g.N_last = (int)(gend - i2); g.Kd = g.Kd_last = count;
+                g.epilogue = SG_SUB; g.batch = 1;
+                int rc = sgemm_launch(g, false, false, st);
+                if (rc) return rc;
+            }
+        }
+        if (gend < K) {        // far columns: GRP phases of 128
             SgemmArgs g{};
-            g.A = Err; g.lda = BS;
-            g.B = Hinv + i1 * K + i2; g.ldb = K;
-            g.C = W + i2; g.ldc = K;
-            g.M = g.M_last = (int)R; g.N = g.N_last = (int)(K - i2); g.Kd = g.Kd_last = count;
-            g.epilogue = SG_SUB; g.batch = 1;
+            g.A = Err; g.lda = ELD;
+            g.B = Hinv + g0 * K + gend; g.ldb = K;
+            g.C = W + gend; g.ldc = K;
+            g.M = g.M_last = (int)R; g.N = g.N_last = (int)(K - gend); g.Kd = g.Kd_last = (int)(gend - g0);
+            g.epilogue = SG_SUB; g.batch = 1; g.phase_len = BS;
             int rc = sgemm_launch(g, false, false, st);
             if (rc) return rc;
         }

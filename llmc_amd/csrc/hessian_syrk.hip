@@ -17,6 +17,7 @@
 // LDS bank layout: a 4-token x 64-B tr16 read by a 32-lane half hits 4 rows at a 512-B stride; the 64-B
 // unit index is XOR-ed with (token & 3) so the four rows land on four different bank quarters. The
 // swizzle is applied to the DMA's per-lane SOURCE address (LDS image stays lane-linear) and to the read.
+#include <stdlib.h>
 #include "common.h"
 #include "mfma_common.h"
 
@@ -82,6 +83,7 @@ struct SyrkArgs {
     int S;             // token chunks
     int nk;            // ceil(T / 64)
     float* part;       // [S * ntiles_p][256*256] fp32, fragment order
+    unsigned* sync;    // round barrier counter (zeroed before the launch), or null
 };
 
 template <int DT>
@@ -119,7 +121,26 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk(SyrkArgs a) {
     const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical id
     const int nunits = a.S * a.ntiles_p;
 
-    for (int u = lw; u < nunits; u += G) {
+    const int nrounds = (nunits + G - 1) / G;
+    for (int round = 0; round < nrounds; ++round) {
+        // Re-align the grid once per round: the workgroups of an XCD share their A/B panels through the XCD's
+        // L2 only while they sit at the same token position; without this they drift apart over a ~450-step
+        // unit and re-fetch the panels from the fabric (measured: L2 hit 57 %, 7x the algorithmic HBM bytes).
+        if (a.sync && round > 0) {
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = (unsigned)round * (unsigned)G;
+                int spins = 0;
+                while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                }
+            }
+            __syncthreads();
+        }
+        const int u = lw + round * G;
+        if (u >= nunits) continue;
         const int s = u / a.ntiles_p;
         const int ti = u - s * a.ntiles_p;
         const TileIdx t = decode_tile(ti, a.nb);
@@ -283,7 +304,7 @@ extern "C" size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx)
     if (T <= 0 || K <= 0 || ldx < K) return 0;
     int nb, ntp, S, nk;
     syrk_geometry(T, K, ldx, &nb, &ntp, &S, &nk);
-    return (size_t)S * ntp * TILE_FLOATS * sizeof(float);
+    return (size_t)S * ntp * TILE_FLOATS * sizeof(float) + 256;
 }
 
 static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ldx, void* ws, hipStream_t st,
@@ -305,6 +326,9 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     a.S = S;
     a.nk = nk;
     a.part = (float*)ws;
+    a.sync = (unsigned*)((char*)ws + (size_t)S * ntp * TILE_FLOATS * sizeof(float));
+    if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
+    if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
     static bool attr_set[2] = {false, false};
     if (dt == LLMC_BF16) {
         if (!attr_set[0]) {

@@ -24,6 +24,10 @@ struct SgemmArgs {
     int a_lower;     // op(A)[i][k] == 0 for k > i  -> stop k after the tile's last row
     int b_upper;     // op(B)[k][j] == 0 for k > j  -> stop k after the tile's last column
     int c_upper_only;  // only tiles that intersect j >= i are computed/stored (symmetric update, upper half)
+    // phased accumulation (SG_SUB only): every `phase_len` k (a multiple of 16) the accumulator is subtracted
+    // from the C tile held in registers and reset to +0:  C -= A[:, p] B[p, :] phase by phase, i.e. exactly what
+    // Kd / phase_len separate launches would compute, with one read and one write of C. 0 = single phase.
+    int phase_len;
     // batch: blockIdx.z-th problem at A + z*sA etc.; dims of the LAST problem may be smaller
     int64_t sA, sB, sC;
     int batch;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void store_cmajor(float* lds, const Stage& s, int tid
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool PHASED>
 __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * GK * GLD];  // [buf][A|B][k][row]
     const int z = blockIdx.z;
@@ -114,6 +114,22 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    // phased mode: the C tile lives in registers for the whole K loop
+    f32x16 cv[2][2];
+    const bool phased = PHASED && a.phase_len > 0 && a.epilogue == SG_SUB;
+    if (PHASED && phased) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = j0 + wn * 64 + n * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    cv[m][n][r] = (row < M && col < N) ? C[(int64_t)row * a.ldc + col] : 0.0f;
+                }
+            }
+    }
 
     auto loadA = [&](int k0) {
         // op(A)[i][k]: TA -> stored [Kd x M] k-major ; else stored [M x Kd] row(i)-major
@@ -159,6 +175,17 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m], fb[n], acc[m][n], 0, 0, 0);
             }
+            if (PHASED && phased && ((k0 + GK - kb) % a.phase_len == 0 || !more)) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            cv[m][n][r] = cv[m][n][r] - acc[m][n][r];
+                            acc[m][n][r] = 0.0f;
+                        }
+            }
             if (more) {
                 storeA(cur ^ 1, sa);
                 storeB(cur ^ 1, sb);
@@ -181,7 +208,8 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
                 if (row >= M) continue;
                 float* pc = C + (int64_t)row * a.ldc + col;
                 const float v = acc[m][n][r];
-                if (a.epilogue == SG_SUB) *pc = *pc - v;
+                if (PHASED && phased) *pc = cv[m][n][r];
+                else if (a.epilogue == SG_SUB) *pc = *pc - v;
                 else if (a.epilogue == SG_SET) *pc = v;
                 else *pc = -v;
             }
@@ -194,10 +222,15 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
                      (((uintptr_t)a.B & 15) == 0) && (a.sA % 4 == 0) && (a.sB % 4 == 0),
                  "sgemm: operands must be 16-B aligned with ld % 4 == 0");
     dim3 grid((a.N + GB - 1) / GB, (a.M + GB - 1) / GB, a.batch);
-    if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false>), grid, dim3(256), 0, st, a);
-    else if (!TA && !TB) hipLaunchKernelGGL((k_sgemm<false, false>), grid, dim3(256), 0, st, a);
-    else if (TA && TB) hipLaunchKernelGGL((k_sgemm<true, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_sgemm<false, true>), grid, dim3(256), 0, st, a);
+    if (a.phase_len > 0) {
+        LLMC_REQUIRE(a.phase_len % GK == 0 && a.epilogue == SG_SUB && !a.a_upper, "sgemm: bad phased configuration");
+        if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false, true>), grid, dim3(256), 0, st, a);
+        else if (!TA && !TB) hipLaunchKernelGGL((k_sgemm<false, false, true>), grid, dim3(256), 0, st, a);
+        else { set_last_error_msg("sgemm: phased mode supports op(B) = N only"); return LLMC_ENOTSUP; }
+    } else if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false, false>), grid, dim3(256), 0, st, a);
+    else if (!TA && !TB) hipLaunchKernelGGL((k_sgemm<false, false, false>), grid, dim3(256), 0, st, a);
+    else if (TA && TB) hipLaunchKernelGGL((k_sgemm<true, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_sgemm<false, true, false>), grid, dim3(256), 0, st, a);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }

@@ -1,0 +1,40 @@
+"""Micro-benchmark of the internal fp32-MFMA GEMM (llmc_test_sgemm) on the shapes K3/K4 use."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from llmc_amd import _ffi
+
+
+def run(M, N, Kd, TA, TB, epi, hints=(0, 0, 0, 0), reps=5, tag=''):
+    L = _ffi.lib()
+    A = torch.randn((Kd, M) if TA else (M, Kd), device='cuda')
+    B = torch.randn((N, Kd) if TB else (Kd, N), device='cuda')
+    C = torch.randn(M, N, device='cuda')
+    def go():
+        _ffi.check(L.llmc_test_sgemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
+                                     M, N, Kd, int(TA), int(TB), epi, *hints, _ffi.stream()), 'sgemm')
+    go()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); go(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = sorted(ts)[len(ts) // 2]
+    fl = 2.0 * M * N * Kd * (0.5 if hints[3] else 1.0)
+    print(f'{tag:28s} M={M} N={N} Kd={Kd} TA={int(TA)} TB={int(TB)}: {t*1e6:9.1f} us  {fl/t/1e12:6.1f} TFLOP/s '
+          f'({fl/t/157.3e12*100:.0f}% of fp32 MFMA peak), C traffic {2*4*M*N*(0.5 if hints[3] else 1)/t/1e12:.2f} TB/s', flush=True)
+
+
+if __name__ == '__main__':
+    run(4096, 4096, 4096, False, False, 1, tag='square NN')
+    run(4096, 4096, 4096, True, False, 1, tag='square TN')
+    run(28672, 3968, 128, False, False, 0, tag='K4 trailing gate|up blk0')
+    run(4096, 14208, 128, False, False, 0, tag='K4 trailing down blk0')
+    run(6144, 2048, 128, False, False, 0, tag='K4 trailing qkv mid')
+    run(14208, 14208, 128, True, False, 0, (0, 0, 0, 1), tag='chol trailing K=14336 blk0')
+    run(128, 14208, 128, True, False, 1, (0, 1, 0, 0), tag='chol panel K=14336 blk0')
+    run(8192, 6144, 8192, False, False, 1, (1, 0, 0, 0), tag='trtri top X=A^-1 C')
