@@ -60,44 +60,60 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 }
 
 // wave-level: factor the 32x32 block at S (upper Cholesky, in place, strict lower zeroed) and write its
-// inverse to V. Lane j (and its twin j+32) owns column j.
-__device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* __restrict__ V, int lane,
-                                                 int kglobal, int* __restrict__ info) {
+// inverse to V. Lane j (and its twin j+32) owns column j in registers.
+// The serial recurrence pivot -> sqrt -> row scale -> next pivot is kept short: row i updates row i+1 EAGERLY
+// with one v_readlane multiplier, while its update of the rows below is applied one step LATER from a copy of the
+// row published in LDS (broadcast reads), off the critical path (look-ahead of depth one inside the wave).
+__device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* __restrict__ V,
+                                                 float* __restrict__ rowbuf, int lane, int kglobal,
+                                                 int* __restrict__ info) {
 #pragma clang fp contract(fast)
     const int j = lane & 31;
     float a[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) a[i] = S[i * PLD + j];
     bool bad = false;
+    float uprev = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
+        if (i >= 1) {   // lazy part of row i-1's update: rows i+1.. (row i received it eagerly)
+            const float* rb = rowbuf + ((i - 1) & 1) * 32;
+#pragma unroll
+            for (int k = i + 1; k < 32; ++k) a[k] -= rb[k] * uprev;
+        }
         const float d = rdlane(a[i], i);
         if (!(d > 0.0f)) bad = true;
-        const float r = sqrtf(d);
-        const float ui = (j > i) ? a[i] / r : (j == i ? r : 0.0f);
+        const float rinv = 1.0f / sqrtf(d);
+        const float ui = (j > i) ? a[i] * rinv : (j == i ? d * rinv : 0.0f);
         a[i] = ui;
-#pragma unroll
-        for (int k = i + 1; k < 32; ++k) {
-            const float t = rdlane(ui, k);
-            a[k] -= t * ui;
+        if (lane < 32) rowbuf[(i & 1) * 32 + j] = ui;   // publish row i of U for the lazy update of step i+1
+        if (i + 1 < 32) {                               // eager: row i+1
+            const float t = rdlane(ui, i + 1);
+            a[i + 1] -= t * ui;
         }
+        uprev = ui;
     }
     if (bad && lane == 0) atomicCAS(info, 0, kglobal + 1);
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) S[i * PLD + j] = a[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // V = U^-1: lane j owns column j; row i of U is read from S as broadcasts; two partial sums per dot product
     float v[32];
 #pragma unroll
     for (int i = 31; i >= 0; --i) {
-        float acc = 0.0f;
+        float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-        for (int k = i + 1; k < 32; ++k) acc += rdlane(a[i], k) * v[k];
-        const float dii = rdlane(a[i], i);
-        v[i] = ((j == i ? 1.0f : 0.0f) - acc) / dii;
+        for (int k = i + 1; k < 32; ++k) {
+            if (k & 1) acc1 += S[i * PLD + k] * v[k];
+            else acc0 += S[i * PLD + k] * v[k];
+        }
+        v[i] = ((j == i ? 1.0f : 0.0f) - (acc0 + acc1)) / S[i * PLD + i];
     }
     if (lane < 32) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            S[i * PLD + j] = a[i];
-            V[i * PLD + j] = v[i];
-        }
+        for (int i = 0; i < 32; ++i) V[i * PLD + j] = v[i];
     }
 }
 
@@ -135,21 +151,51 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
     extern __shared__ __attribute__((aligned(16))) float plds[];
     float* S = plds;
     float* V = plds + NB * PLD;
+    float* rowbuf = plds + 2 * NB * PLD;   // 64 floats of wave-private scratch for the 32x32 factor
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const pf32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        float v = (i == j) ? 1.0f : 0.0f;
-        if (i < nb && j < nb) v = (j >= i) ? W[(int64_t)(k0 + i) * ld + k0 + j] : 0.0f;
-        S[i * PLD + j] = v;
-        V[i * PLD + j] = 0.0f;
+    // load the block with 16 independent 16-B loads per thread in flight (a scalar loop here serialises 64
+    // dependent global-load latencies and was most of this kernel's time)
+    {
+        float4 ld4[16];
+        const bool full = nb == NB && (ld % 4 == 0) && (k0 % 4 == 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e4 = tid + 256 * q;            // float4 index: row = e4 >> 5, col4 = e4 & 31
+            const int i = e4 >> 5, j = (e4 & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (full) {
+                v = *reinterpret_cast<const float4*>(W + (int64_t)(k0 + i) * ld + k0 + j);
+            } else if (i < nb) {
+                const float* p = W + (int64_t)(k0 + i) * ld + k0 + j;
+                if (j < nb) v.x = p[0];
+                if (j + 1 < nb) v.y = p[1];
+                if (j + 2 < nb) v.z = p[2];
+                if (j + 3 < nb) v.w = p[3];
+            }
+            ld4[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e4 = tid + 256 * q;
+            const int i = e4 >> 5, j = (e4 & 31) * 4;
+            float vv[4] = {ld4[q].x, ld4[q].y, ld4[q].z, ld4[q].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int jj = j + t;
+                float x = (i == jj) ? 1.0f : 0.0f;                 // identity padding
+                if (i < nb && jj < nb) x = (jj >= i) ? vv[t] : 0.0f;
+                S[i * PLD + jj] = x;
+                V[i * PLD + jj] = 0.0f;
+            }
+        }
     }
     __syncthreads();
     // ---- blocked upper Cholesky over 4 block rows
     for (int kb = 0; kb < 4; ++kb) {
-        if (wv == 0) wave_potrf32_inv(PBLK(S, kb, kb), PBLK(V, kb, kb), lane, k0 + kb * 32, info);
+        if (wv == 0) wave_potrf32_inv(PBLK(S, kb, kb), PBLK(V, kb, kb), rowbuf, lane, k0 + kb * 32, info);
         __syncthreads();
         {   // panel: S(kb, jb) = V_kk^T * S(kb, jb)
             const int jb = kb + 1 + wv;
@@ -344,7 +390,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     static bool potrf_attr = false;
     if (!potrf_attr) {
         LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_potrf_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * NB * PLD * (int)sizeof(float)));
+                                           (2 * NB * PLD + 64) * (int)sizeof(float)));
         potrf_attr = true;
     }
 
@@ -365,7 +411,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
             const int b = c0 / NB;
             const int nb = K - c0 < NB ? K - c0 : NB;
             float* Vb = Vbuf + (size_t)b * NB * NB;
-            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 2 * NB * PLD * sizeof(float), st, Wk, (int64_t)K, c0,
+            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (2 * NB * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
                                nb, Vb, info_dev);
             LLMC_LAUNCH_CHECK();
             const int nrem = K - c0 - nb;

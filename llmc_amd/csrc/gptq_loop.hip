@@ -110,12 +110,14 @@ __device__ __forceinline__ void gptq_steps16(float (&w)[8], const float (&w0)[8]
 #undef LLMC_STEP
 }
 
-__global__ __launch_bounds__(256) void k_gptq_block(GptqBlockArgs a) {
+static constexpr int GBT = 512;  // threads per workgroup: 8 waves x 4 rows
+
+__global__ __launch_bounds__(GBT) void k_gptq_block(GptqBlockArgs a) {
     // Us[i][p*8 + e] = U[i1+i][i1 + p + 16e] for p+16e > i, else 0 ; dg[i] = U[i1+i][i1+i]
     __shared__ __attribute__((aligned(16))) float Us[BS * BS];
     __shared__ float dg[BS];
     const int tid = threadIdx.x;
-    for (int e = tid; e < BS * BS; e += 256) {
+    for (int e = tid; e < BS * BS; e += GBT) {
         const int i = e >> 7, c = e & 127;  // c = column inside the block
         float v = 0.0f;
         if (i < a.count && c < a.count) {
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_gptq_block(GptqBlockArgs a) {
 
     const int lane = tid & 63;
     const int p = lane & 15;
-    const int64_t row = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 4 + (lane >> 4);
+    const int64_t row = ((int64_t)blockIdx.x * (GBT / 64) + (tid >> 6)) * 4 + (lane >> 4);
     const bool active = row < a.R;
     const int64_t rr = active ? row : a.R - 1;
 
@@ -237,8 +239,8 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
             a.scales = scales; a.zeros = zeros; a.col_group = per_channel ? nullptr : col_group;
             a.R = R; a.K = (int)K; a.i1 = (int)i1; a.count = count; a.ng = ng; a.gsz = static_mode ? BS : gsz;
             a.static_mode = static_mode; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
-            const int grid = (int)ceil_div64(R, 16);
-            hipLaunchKernelGGL(k_gptq_block, dim3(grid), dim3(256), 0, st, a);
+            const int grid = (int)ceil_div64(R, GBT / 16);
+            hipLaunchKernelGGL(k_gptq_block, dim3(grid), dim3(GBT), 0, st, a);
             LLMC_LAUNCH_CHECK();
             const int64_t i2 = i1 + count;
             if (i2 < gend) {   // near columns of the group
