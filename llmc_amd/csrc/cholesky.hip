@@ -9,8 +9,10 @@
 // are fp32-MFMA GEMMs); V = U'^-1 by recursive doubling over the already inverted diagonal blocks
 // ([[A,C],[0,B]]^-1 = [[A^-1, -A^-1 C B^-1],[0, B^-1]]); U = antitranspose(V).  2K^3/3 flops instead of
 // the reference's 4K^3/3.
+#include <stdlib.h>
 #include "common.h"
 #include "sgemm.h"
+#include "side_stream.h"
 
 namespace llmc {
 
@@ -404,6 +406,8 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     // beyond it receive ONE symmetric update with Kd = 512 per outer block, which is where the flops are and
     // runs the fp32-MFMA GEMM at its long-K efficiency instead of its short-K one (tools/bench_sgemm.py).
     const int NBO = 4 * NB;
+    SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
+    bool pending_side = false;
     for (int k0 = 0; k0 < K; k0 += NBO) {
         const int nbo = K - k0 < NBO ? K - k0 : NBO;
         const int oend = k0 + nbo;
@@ -438,16 +442,46 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         }
         const int nfar = K - oend;
         if (nfar > 0) {
-            // far trailing update: T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo)
+            // far trailing update T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo), in two parts: the rows
+            // of the NEXT outer block on the main stream (its factor steps need them), the rows below on the side
+            // stream, overlapped with the next outer block's latency-bound diagonal / panel kernels.
             float* P = Wk + (size_t)k0 * K + oend;
+            const int m1 = nfar < NBO ? nfar : NBO;
+            if (side && pending_side) {          // rows oend.. were last written by the previous side update
+                int rc = join_from_side(side, st);
+                if (rc) return rc;
+                pending_side = false;
+            }
             SgemmArgs u{};
             u.A = P; u.lda = K; u.B = P; u.ldb = K;
             u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
-            u.M = u.M_last = nfar; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
+            u.M = u.M_last = m1; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
             u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
             int rc = sgemm_launch(u, true, false, st);
             if (rc) return rc;
+            const int m2 = nfar - m1;
+            if (m2 > 0) {
+                SgemmArgs v{};
+                v.A = P + m1; v.lda = K; v.B = P + m1; v.ldb = K;
+                v.C = Wk + (size_t)(oend + m1) * K + oend + m1; v.ldc = K;
+                v.M = v.M_last = m2; v.N = v.N_last = m2; v.Kd = v.Kd_last = nbo;
+                v.epilogue = SG_SUB; v.c_upper_only = 1; v.batch = 1;
+                if (side) {
+                    rc = fork_to_side(side, st);   // P is final on main at this point
+                    if (rc) return rc;
+                    rc = sgemm_launch(v, true, false, side->side);
+                    if (rc) return rc;
+                    pending_side = true;
+                } else {
+                    rc = sgemm_launch(v, true, false, st);
+                    if (rc) return rc;
+                }
+            }
         }
+    }
+    if (side && pending_side) {
+        int rc = join_from_side(side, st);
+        if (rc) return rc;
     }
     (void)nblk;
     // ---- V = U'^-1: inverted diagonal blocks, then doubling levels

@@ -11,9 +11,11 @@
 // lane's registers end up holding exactly `tmp` (the weight of each column at the time it was visited).
 // Trailing update W[:, i2:] -= Err1 @ U[i1:i2, i2:] runs on the fp32 MFMA pipe (sgemm.hip) with the
 // k-ordered fma chain that reproduces the reference's CPU sgemm bit for bit.
+#include <stdlib.h>
 #include "common.h"
 #include "quant_math.h"
 #include "sgemm.h"
+#include "side_stream.h"
 
 namespace llmc {
 
@@ -199,7 +201,7 @@ static constexpr int GRP = 4;  // 128-column blocks per outer group (far updates
 
 extern "C" size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K) {
     if (R <= 0 || K <= 0) return 0;
-    return (size_t)R * BS * GRP * sizeof(float);
+    return 2 * (size_t)R * BS * GRP * sizeof(float);   // double-buffered err columns (look-ahead)
 }
 
 extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
@@ -223,14 +225,20 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
         LLMC_REQUIRE(col_group != nullptr, "gptq_quantize: col_group required with static groups");
     }
     hipStream_t st = (hipStream_t)stream;
-    float* Err = (float*)ws;   // [R, GRP*128]: the err columns of the current outer group
     const int ELD = BS * GRP;
+    float* ErrBuf[2] = {(float*)ws, (float*)ws + (size_t)R * ELD};   // [R, GRP*128] x 2: err columns of a group
+    SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
+    bool pending_side = false;
     // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as
     // "W -= chain over the block's 128 k" (gptq.py:244). Columns inside the current outer group get them right
     // after each block (the next block needs them); columns beyond the group get the group's GRP updates in one
     // phased GEMM that keeps the C tile in registers — same arithmetic, one pass over the far columns per group.
-    for (int64_t g0 = 0; g0 < K; g0 += (int64_t)BS * GRP) {
+    // The far update is split: the next group's columns on the main stream, everything beyond on a side stream,
+    // overlapped with the next group's latency-bound in-block kernels (the order per element is unchanged).
+    int gidx = 0;
+    for (int64_t g0 = 0; g0 < K; g0 += (int64_t)BS * GRP, ++gidx) {
         const int64_t gend = g0 + (int64_t)BS * GRP < K ? g0 + (int64_t)BS * GRP : K;
+        float* Err = ErrBuf[gidx & 1];
         for (int64_t i1 = g0; i1 < gend; i1 += BS) {
             const int count = (int)(K - i1 < BS ? K - i1 : BS);
             GptqBlockArgs a;
@@ -255,15 +263,41 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
             }
         }
         if (gend < K) {        // far columns: GRP phases of 128
+            const int64_t gend2 = gend + (int64_t)BS * GRP < K ? gend + (int64_t)BS * GRP : K;
+            if (side && pending_side) {   // columns gend.. were last written by the previous group's side update,
+                int rc = join_from_side(side, st);   // which also still reads the other err buffer
+                if (rc) return rc;
+                pending_side = false;
+            }
             SgemmArgs g{};
             g.A = Err; g.lda = ELD;
             g.B = Hinv + g0 * K + gend; g.ldb = K;
             g.C = W + gend; g.ldc = K;
-            g.M = g.M_last = (int)R; g.N = g.N_last = (int)(K - gend); g.Kd = g.Kd_last = (int)(gend - g0);
+            g.M = g.M_last = (int)R; g.N = g.N_last = (int)(gend2 - gend); g.Kd = g.Kd_last = (int)(gend - g0);
             g.epilogue = SG_SUB; g.batch = 1; g.phase_len = BS;
             int rc = sgemm_launch(g, false, false, st);
             if (rc) return rc;
+            if (gend2 < K) {
+                SgemmArgs h = g;
+                h.B = Hinv + g0 * K + gend2;
+                h.C = W + gend2;
+                h.N = h.N_last = (int)(K - gend2);
+                if (side) {
+                    rc = fork_to_side(side, st);   // this group's err columns are complete on main
+                    if (rc) return rc;
+                    rc = sgemm_launch(h, false, false, side->side);
+                    if (rc) return rc;
+                    pending_side = true;
+                } else {
+                    rc = sgemm_launch(h, false, false, st);
+                    if (rc) return rc;
+                }
+            }
         }
+    }
+    if (side && pending_side) {
+        int rc = join_from_side(side, st);
+        if (rc) return rc;
     }
     return LLMC_OK;
 }
