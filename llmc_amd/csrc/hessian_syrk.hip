@@ -222,6 +222,188 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk(SyrkArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// k_syrk2 — same tiling and data path as k_syrk, deeper pipeline:
+//   * LDS ring of 4 stages of 32 tokens (A 16 KiB + B 16 KiB each); up to 3 stages of LDS-DMA in flight, waited
+//     with a COUNTED vmcnt (never 0 in the steady state);
+//   * fragments are double-buffered in registers at 16-token granularity and the barrier that publishes the next
+//     stage sits BETWEEN the two MFMA bursts of a stage, so the first fragments of the next stage are fetched
+//     under the second burst: the matrix pipe no longer drains at every K-step boundary
+//     (k_syrk: barrier -> 8 DMA issues -> first ds_reads -> MFMA, ~25-30 % of the step with the pipe idle).
+// Steady state of stage s (slot s & 3), F0 = fragments of tokens 0..15 of the stage, F1 = tokens 16..31:
+//     read F1(s) | MFMA F0 | wait DMA(s+1) landed, lgkmcnt(0), s_barrier | issue DMA(s+4) into slot s |
+//     read F0(s+1) | MFMA F1
+// After the barrier of stage s every wave has completed its reads of stage s (F0 before the previous barrier, F1
+// waited by lgkmcnt(0)), so slot s is free for stage s+4.
+// -----------------------------------------------------------------------------------------------------
+static constexpr int ST_TOK = 32;
+static constexpr int ST_PANEL = ST_TOK * TM * 2;     // 16 KiB
+static constexpr int ST_BYTES = 2 * ST_PANEL;        // 32 KiB
+static constexpr int ST_RING = 4;
+static constexpr int SYRK2_LDS = ST_RING * ST_BYTES; // 128 KiB
+
+template <int N> __device__ __forceinline__ void dma_wait_upto() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one unit (tile x token chunk) of k_syrk2; DIAG: the tile is on the diagonal (one panel, 2 DMA pieces per stage)
+template <int DT, bool DIAG>
+__device__ __forceinline__ void syrk2_unit(f32x16 (&acc)[4][2], LDS_AS char* lds, uint32_t lds_base, i32x4 rsrc,
+                                           uint32_t vA, uint32_t vB, uint32_t slab, int64_t row_bytes, int nst,
+                                           int wv, const int (&offA)[4], const int (&offB)[2]) {
+    constexpr int PER = DIAG ? 2 : 4;   // DMA instructions per stage per wave
+    auto stage = [&](int st) {
+        const uint32_t koff = (uint32_t)((int64_t)st * ST_TOK * row_bytes);
+        const uint32_t dst = lds_base + (st & (ST_RING - 1)) * ST_BYTES + wv * 1024;
+        dma16(rsrc, vA + koff, dst);
+        dma16(rsrc, vA + koff + slab, dst + 8192);
+        if (!DIAG) {
+            dma16(rsrc, vB + koff, dst + ST_PANEL);
+            dma16(rsrc, vB + koff + slab, dst + ST_PANEL + 8192);
+        }
+    };
+    s16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    auto read_frags = [&](int st, int kk, s16x8 (&fa)[4], s16x8 (&fb)[2]) {
+        LDS_AS char* pa = lds + (st & (ST_RING - 1)) * ST_BYTES;
+        LDS_AS char* pb = DIAG ? pa : pa + ST_PANEL;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = tr_frag(pa + offA[m], kk * 16 * TM * 2);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fb[n] = tr_frag(pb + offB[n], kk * 16 * TM * 2);
+    };
+    auto mma = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[2]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = Mfma<DT>::run(fa[m], fb[n], acc[m][n]);
+    };
+    if (nst <= 0) return;
+    // prologue: fill the ring, publish stage 0, fetch its first fragments
+    const int npre = nst < ST_RING ? nst : ST_RING;
+    for (int st = 0; st < npre; ++st) stage(st);
+    if (npre == ST_RING) dma_wait_upto<3 * PER>(); else dma_wait_upto<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, fa0, fb0);
+    // vmcnt counts this wave's DMA instructions in issue order. When stage st+1 is published, the stages issued
+    // after it are st+2 and st+3 (steady state): wait until at most 2*PER instructions remain. The last three
+    // stages drain with vmcnt(0).
+    for (int st = 0; st < nst; ++st) {
+        read_frags(st, 1, fa1, fb1);
+        mma(fa0, fb0);
+        if (st + 3 < nst) dma_wait_upto<2 * PER>(); else dma_wait_upto<0>();
+        lds_wait_all();
+        __builtin_amdgcn_s_barrier();
+        if (st + ST_RING < nst) stage(st + ST_RING);
+        if (st + 1 < nst) read_frags(st + 1, 0, fa0, fb0);
+        mma(fa1, fb1);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(SYRK_THREADS) void k_syrk2(SyrkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+
+    // DMA: instruction q (0,1) of wave wv fills KiB-block (q*8 + wv) of a 16-KiB panel = token rows 2*blk, 2*blk+1
+    const int lr = lane >> 5;
+    const int c16 = lane & 31;
+    const int row_lo = 2 * wv + lr;
+    const int u_log = (c16 >> 2) ^ (row_lo & 3);
+    const int ch_off = (u_log * 4 + (c16 & 3)) * 8;
+    const int64_t row_bytes = a.ldx * 2;
+
+    const int p = lane & 15;
+    const int trow = 8 * (lane >> 5) + (p >> 2);
+    const int sub = 32 * ((lane >> 4) & 1) + 8 * (p & 3);
+    int offA[4], offB[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) offA[m] = trow * (TM * 2) + (((4 * wm + m) ^ (p >> 2)) << 6) + sub;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) offB[n] = trow * (TM * 2) + (((2 * wn + n) ^ (p >> 2)) << 6) + sub;
+
+    const int G = gridDim.x;
+    const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int nunits = a.S * a.ntiles_p;
+    const int nrounds = (nunits + G - 1) / G;
+    const int nst_total = (int)((a.T + ST_TOK - 1) / ST_TOK);
+
+    for (int round = 0; round < nrounds; ++round) {
+        if (a.sync && round > 0) {
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = (unsigned)round * (unsigned)G;
+                int spins = 0;
+                while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                }
+            }
+            __syncthreads();
+        }
+        const int u = lw + round * G;
+        if (u >= nunits) continue;
+        const int s = u / a.ntiles_p;
+        const int ti = u - s * a.ntiles_p;
+        const TileIdx t = decode_tile(ti, a.nb);
+        if (!t.valid) continue;
+        // chunk boundaries in 64-token K-steps (same split as k_syrk: ws layout and fixup are shared)
+        const int ks0 = (int)(((int64_t)s * a.nk) / a.S);
+        const int ks1 = (int)(((int64_t)(s + 1) * a.nk) / a.S);
+        const int st0 = 2 * ks0;
+        int st1 = 2 * ks1;
+        if (st1 > nst_total) st1 = nst_total;
+        const int nst = st1 - st0;
+
+        const char* base = a.X + (int64_t)st0 * ST_TOK * row_bytes;
+        int64_t rem_bytes = (a.T - (int64_t)st0 * ST_TOK) * row_bytes;
+        const uint32_t nrec = rem_bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)rem_bytes;
+        i32x4 rsrc;
+        rsrc[0] = (int)(uint32_t)(uintptr_t)base;
+        rsrc[1] = (int)((uint32_t)((uintptr_t)base >> 32) & 0xffffu);
+        rsrc[2] = (int)nrec;
+        rsrc[3] = 0x00020000;
+        const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
+        const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
+        const uint32_t slab = (uint32_t)(16 * row_bytes);
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        if (t.bi == t.bj)
+            syrk2_unit<DT, true>(acc, lds, lds_base, rsrc, vA, vB, slab, row_bytes, nst, wv, offA, offB);
+        else
+            syrk2_unit<DT, false>(acc, lds, lds_base, rsrc, vA, vB, slab, row_bytes, nst, wv, offA, offB);
+        dma_wait_all();
+        __syncthreads();
+
+        float* slot = a.part + (int64_t)u * TILE_FLOATS;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2],
+                               acc[m][n][4 * q + 3]};
+                    int idx = ((((wv * 4 + m) * 2 + n) * 4 + q) * 64 + lane);
+                    *reinterpret_cast<f32x4*>(slot + (int64_t)idx * 4) = v;
+                }
+    }
+}
+
 // Sum the S partials of each tile (chunk order), H <- alpha*H + beta*sum, mirror to the upper triangle.
 // One thread per float4 of the fragment-order tile: idx -> (wv,m,n,q,lane) -> rows i0..i0+3, column j.
 __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ part, float* __restrict__ H,
@@ -330,20 +512,29 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
     if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
     static bool attr_set[2] = {false, false};
+    // k_syrk2 (deeper LDS-DMA ring) measures within 2 % of k_syrk on MI355X (both ~60 % MFMA-busy, clock-limited
+    // on random data: profiles/r01_syrk_variants.txt); k_syrk stays the default, LLMC_SYRK_V2=1 selects the ring.
+    const bool use_v2 = getenv("LLMC_SYRK_V2") != nullptr;
     if (dt == LLMC_BF16) {
         if (!attr_set[0]) {
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk2<LLMC_BF16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK2_LDS));
             LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
             attr_set[0] = true;
         }
-        hipLaunchKernelGGL((k_syrk<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        if (use_v2) hipLaunchKernelGGL((k_syrk2<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK2_LDS, st, a);
+        else hipLaunchKernelGGL((k_syrk<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
     } else {
         if (!attr_set[1]) {
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk2<LLMC_F16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK2_LDS));
             LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
             attr_set[1] = true;
         }
-        hipLaunchKernelGGL((k_syrk<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        if (use_v2) hipLaunchKernelGGL((k_syrk2<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK2_LDS, st, a);
+        else hipLaunchKernelGGL((k_syrk<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
     }
     LLMC_LAUNCH_CHECK();
     *nb_o = nb;

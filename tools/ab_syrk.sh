@@ -1,9 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ab
-for i in 1 2; do
-  echo "sync:"; python tools/bench_syrk.py 262144x4096 65536x14336 2>&1 | grep "T="
-  echo "nosync:"; LLMC_SYRK_NOSYNC=1 python tools/bench_syrk.py 262144x4096 65536x14336 2>&1 | grep "T="
+for f in zeros ones randn; do
+  echo "fill=$f v2:"; FILL=$f python tools/bench_syrk.py 262144x4096 2>&1 | grep "T="
+  echo "fill=$f v1:"; FILL=$f LLMC_SYRK_V1=1 python tools/bench_syrk.py 262144x4096 2>&1 | grep "T="
 done
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/ab/sync -o p -- python tools/bench_syrk.py 262144x4096 > /dev/null 2>&1
-python tools/pmc_summary.py gpurun_out/ab/sync "k_syrk<"

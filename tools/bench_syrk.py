@@ -12,7 +12,13 @@ from llmc_amd.compression.quantization.hessian import HessianAccumulator
 
 def run(T, K, dt=torch.bfloat16, reps=5):
     g = torch.Generator(device='cuda').manual_seed(1)
-    x = torch.randn(T, K, generator=g, device='cuda', dtype=torch.float32).to(dt)
+    fill = os.environ.get('FILL', 'randn')
+    if fill == 'zeros':
+        x = torch.zeros(T, K, device='cuda', dtype=dt)
+    elif fill == 'ones':
+        x = torch.ones(T, K, device='cuda', dtype=dt)
+    else:
+        x = torch.randn(T, K, generator=g, device='cuda', dtype=torch.float32).to(dt)
     acc = HessianAccumulator(K, 'cuda')
     acc.add(x.unsqueeze(0))
     torch.cuda.synchronize()
