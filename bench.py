@@ -218,6 +218,18 @@ def main():
     n_launch = len(timing)
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    # HBM-side bytes of the dominant kernel come from PMC passes that cannot run inside the timed process
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_bench.sh); the committed summary is reported with its source.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if args.model == 'llama3-8b' and args.n_seq == 128 and args.seq_len == 2048 and args.calib_bs == 128 \
+            and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))['k_syrk']
+            traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json (' + tj['note'] + ')'
+        except Exception:
+            traffic = None
+
     if rank == 0:
         total_layers = n_layers_block * args.steps * world
         out = {
@@ -234,7 +246,7 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                'frac': achieved * 1e12 / PEAK_MFMA_16BIT, 'traffic': None,
+                'frac': achieved * 1e12 / PEAK_MFMA_16BIT, 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel': 'k_syrk (llmc_hessian_accum_partials)', 'launches': n_launch,
                 'algorithmic_flops_per_launch': fl / max(1, n_launch),
                 'avg_launch_ms': ms / max(1, n_launch),
