@@ -43,7 +43,10 @@ _orig_to = torch.Tensor.to
 def _to(self, *a, **k):
     if str(k.get('device', '')).startswith('cuda'):
         k['device'] = 'cpu'
-    a = tuple('cpu' if (isinstance(x, str) and x.startswith('cuda')) else x for x in a)
+    a = tuple('cpu' if ((isinstance(x, str) and x.startswith('cuda')) or
+                        (isinstance(x, torch.device) and x.type == 'cuda')) else x for x in a)
+    if isinstance(k.get('device'), torch.device) and k['device'].type == 'cuda':
+        k['device'] = 'cpu'
     return _orig_to(self, *a, **k)
 
 
@@ -463,8 +466,68 @@ def suite_fp8():
     save('fp8', **out)
 
 
+def suite_e2e():
+    """The reference's OWN algorithm classes (RTN / GPTQ / Awq, constructed and driven exactly as llmc/__main__.py
+    does: ctor -> run_block_loop() -> deploy()) on the toy model adapter of tests/toy_model.py, on CPU.
+    tests/test_e2e_gpu.py runs llmc_amd's classes on the same adapter / config / seeds and compares."""
+    import copy
+    import torch.distributed as dist
+    from easydict import EasyDict
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from toy_model import ToyModel, calib_input
+    from llmc.compression.quantization import GPTQ, RTN, Awq
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29593', rank=0, world_size=1)
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()      # GPU semantics of .cpu(): a copy (see suite_awq)
+    out = {}
+
+    def linears(model):
+        return {f'{i}.{n}': m for i, b in enumerate(model.get_blocks()) for n, m in b.named_modules()
+                if hasattr(m, 'weight') and m.weight is not None and m.weight.dim() == 2}
+
+    config = EasyDict(calib={'seq_len': 64}, model={'type': 'Toy'}, eval={})
+    # RTN W4 sym g128 -> fake quant
+    def ToyModel_():
+        return ToyModel(hidden=128, inner=256, seed=3)
+    model = ToyModel_()
+    qc = EasyDict(weight={'bit': 4, 'symmetric': True, 'granularity': 'per_group', 'group_size': 128}, modality='language')
+    algo = RTN(model, qc, calib_input(model), None, config)
+    algo.run_block_loop()
+    algo.deploy('fake_quant')
+    for n, m in linears(model).items():
+        out['rtn/' + n] = f32(m.weight.data)
+    # GPTQ, two configurations
+    for tag, sym, static in (('gptq_dyn', False, False), ('gptq_static', True, True)):
+        model = ToyModel_()
+        qc = EasyDict(weight={'bit': 4, 'symmetric': sym, 'granularity': 'per_group', 'group_size': 128},
+                      special={'actorder': True, 'static_groups': static, 'percdamp': 0.01, 'blocksize': 128,
+                               'true_sequential': True}, quant_out=True, modality='language')
+        algo = GPTQ(model, qc, calib_input(model), None, config)
+        algo.dev = torch.device('cpu')          # the CI rewrite's `self.dev = 'cpu'` (ci_check/change_files.py)
+        algo.run_block_loop()
+        for n, m in linears(model).items():
+            out[f'{tag}/w/{n}'] = f32(m.weight.data)
+            out[f'{tag}/scales/{n}'] = f32(m.buf_scales).reshape(-1)
+        algo.deploy('fake_quant')
+        out[f'{tag}/fake/0.down_proj'] = f32(model.get_blocks()[0].down_proj.weight.data)
+    # Awq: trans v2 + clip v1, one calibration batch
+    model = ToyModel_()
+    inp = calib_input(model)
+    inp1 = {'data': [torch.cat(inp['data'], dim=0)], 'kwargs': [{}]}
+    qc = EasyDict(weight={'bit': 4, 'symmetric': True, 'granularity': 'per_group', 'group_size': 128},
+                  special={'trans': True, 'trans_version': 'v2', 'weight_clip': True, 'clip_sym': True}, modality='language')
+    algo = Awq(model, qc, inp1, None, config)
+    algo.run_block_loop()
+    for i, b in enumerate(model.get_blocks()):
+        out[f'awq/ln/{i}'] = f32(b.ln.weight.data)
+    for n, m in linears(model).items():
+        out['awq/w/' + n] = f32(m.weight.data)
+    save('e2e', **out)
+
+
 SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8}
+          'fp8': suite_fp8, 'e2e': suite_e2e}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

@@ -117,3 +117,77 @@ def test_awq_trans_and_clip_run_and_preserve_function():
     assert s.min() > 0 and s.max() / s.min() > 1.5                            # a non-trivial scale was applied
     algo.deploy('fake_quant')
     assert type(model.get_blocks()[0].gate_proj).__name__ == 'EffcientFakeQuantLinear'
+
+
+# ---- the same adapter / config / seeds through the REFERENCE's own classes on CPU: tests/golden/e2e.npz ----------
+def _linears(model):
+    return {f'{i}.{n}': m for i, b in enumerate(model.get_blocks()) for n, m in b.named_modules()
+            if getattr(m, 'weight', None) is not None and torch.is_tensor(m.weight) and m.weight.dim() == 2}
+
+
+def _toy():
+    from toy_model import ToyModel, calib_input
+    model = ToyModel(hidden=128, inner=256, seed=3)
+    return model, calib_input(model), Cfg(calib=Cfg(seq_len=64), model=Cfg(type='Toy'))
+
+
+def test_rtn_matches_reference_classes_bit_exact():
+    import llmc_amd.compression.quantization as Q
+    from conftest import load_golden
+    g = load_golden('e2e')
+    model, inp, config = _toy()
+    qc = Cfg(weight=Cfg(bit=4, symmetric=True, granularity='per_group', group_size=128))
+    algo = Q.RTN(model, qc, inp, None, config)
+    algo.run_block_loop()
+    algo.deploy('fake_quant')
+    for n, m in _linears(model).items():
+        np.testing.assert_array_equal(m.weight.data.float().cpu().numpy(), g['rtn/' + n], err_msg=n)
+
+
+@pytest.mark.parametrize('tag,sym,static', [('gptq_dyn', False, False), ('gptq_static', True, True)])
+def test_gptq_matches_reference_classes(tag, sym, static):
+    """Same block loop (true_sequential + quant_out re-forwards included) as the reference's GPTQ class. The
+    factorisation order differs (fp32), GPTQ's error feedback amplifies last-bit differences, and later subsets /
+    blocks see inputs produced by earlier quantised layers, so agreement is statistical and degrades with depth."""
+    import llmc_amd.compression.quantization as Q
+    from conftest import load_golden
+    g = load_golden('e2e')
+    model, inp, config = _toy()
+    qc = Cfg(weight=Cfg(bit=4, symmetric=sym, granularity='per_group', group_size=128),
+             special=Cfg(actorder=True, static_groups=static, percdamp=0.01, blocksize=128, true_sequential=True),
+             quant_out=True)
+    algo = Q.GPTQ(model, qc, inp, None, config)
+    algo.run_block_loop()
+    for n, m in _linears(model).items():
+        got, ref = m.weight.data.float().cpu().numpy(), g[f'{tag}/w/{n}']
+        scale = np.abs(ref).max()
+        close = np.mean(np.abs(got - ref) < 2e-2 * scale)
+        first = n.startswith('0.gate') or n.startswith('0.up')
+        assert close > (0.97 if first else 0.80), (n, close)
+        s_got, s_ref = m.buf_scales.float().cpu().numpy().reshape(-1), g[f'{tag}/scales/{n}']
+        assert s_got.shape == s_ref.shape
+        assert np.mean(np.abs(s_got - s_ref) <= 2e-2 * np.abs(s_ref)) > (0.97 if first else 0.80), n
+    algo.deploy('fake_quant')
+    fq = model.get_blocks()[0].down_proj.weight.data.float().cpu().numpy()
+    ref = g[f'{tag}/fake/0.down_proj']
+    assert fq.shape == ref.shape and np.mean(np.abs(fq - ref) < 0.15 * np.abs(ref).max()) > 0.8
+
+
+def test_awq_matches_reference_classes():
+    import llmc_amd.compression.quantization as Q
+    from conftest import load_golden
+    g = load_golden('e2e')
+    model, inp, config = _toy()
+    inp1 = {'data': [torch.cat(inp['data'], dim=0)], 'kwargs': [{}]}
+    qc = Cfg(weight=Cfg(bit=4, symmetric=True, granularity='per_group', group_size=128),
+             special=Cfg(trans=True, trans_version='v2', weight_clip=True, clip_sym=True))
+    algo = Q.Awq(model, qc, inp1, None, config)
+    algo.run_block_loop()
+    # block 0: same calibration input as the reference -> same grid point, scales within a few ulp (bf16)
+    ln_got = model.get_blocks()[0].ln.weight.data.float().cpu().numpy()
+    ln_ref = g['awq/ln/0']
+    assert np.mean(np.abs(ln_got - ln_ref) <= 2.0 ** -6 * np.abs(ln_ref)) > 0.98
+    for n in ('0.gate_proj', '0.up_proj'):
+        got = _linears(model)[n].weight.data.float().cpu().numpy()
+        ref = g['awq/w/' + n]
+        assert np.mean(np.abs(got - ref) <= 2.0 ** -5 * np.abs(ref).max()) > 0.97, n
