@@ -41,12 +41,61 @@ __device__ __forceinline__ float e4m3fn_to_f32(uint8_t v) {
 // scales' dtype sdt: ATen promotes the 0-dim per-tensor absmax (dt) / 0-dim fp32 qmax to fp32, but keeps dt for
 // the per-channel [R,1] absmax.
 template <typename T>
+__device__ __forceinline__ void fp8_one(float w, float s, int tdt, int fake, int DT, T* of, uint8_t* ob) {
+    const float t = rnd(rnd(w / s, tdt) + 0.0f, tdt);          // tensor / scales + zeros
+    const uint8_t q = f32_to_e4m3fn(t);
+    if (fake) *of = from_f32<T>(e4m3fn_to_f32(q) * s);          // fp32 product, one rounding to dt
+    else *ob = q;
+}
+
+template <typename T>
 __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const T* __restrict__ amax, int sdt,
                                                  void* __restrict__ scales, int static_scales, int64_t G, int64_t g,
                                                  int fake, void* __restrict__ out) {
     constexpr int DT = dt_of<T>::value;
-    const int64_t total = G * g;
+    constexpr int V = 16 / sizeof(T);
     const int pdt = promote(DT, sdt);
+    const int tdt = (G == 1) ? DT : pdt;   // a 0-dim fp32 scale does not promote the [R,K] tensor, a [R,1] one does
+    const bool vec = (g % V == 0) && (((uintptr_t)W & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int64_t total = G * g;
+    if (vec) {
+        const int64_t nv = total / V;
+        for (int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * FB) {
+            const int64_t e0 = i * V;
+            const int64_t row = e0 / g;
+            float s;
+            if (static_scales) {
+                s = load_as_f32(scales, row, sdt);
+            } else {
+                s = rnd(to_f32<T>(amax[row]) / 448.0f, sdt);
+                if (e0 == row * g) store_from_f32(scales, row, sdt, s);
+            }
+            if (s == 0.0f) s = 1.0f;                              // scales[scales == 0] = 1 (quant.py:1062)
+            uint4 raw = *reinterpret_cast<const uint4*>(W + e0);
+            T wv[V];
+            __builtin_memcpy(wv, &raw, 16);
+            T of[V];
+            uint8_t ob[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) fp8_one<T>(to_f32<T>(wv[k]), s, tdt, fake, DT, &of[k], &ob[k]);
+            if (fake) {
+                uint4 o;
+                __builtin_memcpy(&o, of, 16);
+                *reinterpret_cast<uint4*>((T*)out + e0) = o;
+            } else {
+                if constexpr (V == 8) {
+                    uint2 o;
+                    __builtin_memcpy(&o, ob, 8);
+                    *reinterpret_cast<uint2*>((uint8_t*)out + e0) = o;
+                } else {
+                    uint32_t o;
+                    __builtin_memcpy(&o, ob, 4);
+                    *reinterpret_cast<uint32_t*>((uint8_t*)out + e0) = o;
+                }
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x; i < total; i += (int64_t)gridDim.x * FB) {
         const int64_t row = i / g;
         float s;
@@ -56,17 +105,11 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
             s = rnd(to_f32<T>(amax[row]) / 448.0f, sdt);
             if (i == row * g) store_from_f32(scales, row, sdt, s);
         }
-        if (s == 0.0f) s = 1.0f;                                  // scales[scales == 0] = 1 (quant.py:1062)
-        // tensor / scales + zeros: a 0-dim fp32 scale does not promote the [R,K] tensor, a [R,1] one of dtype sdt does
-        const int tdt = (G == 1) ? DT : pdt;
-        const float t = rnd(rnd(to_f32<T>(W[i]) / s, tdt) + 0.0f, tdt);
-        const uint8_t q = f32_to_e4m3fn(t);
-        if (fake) {
-            // dequant keeps q in fp32 ((q - 0) * s promotes to fp32), then .to(org dtype)  (quant.py:1071-1080)
-            ((T*)out)[i] = from_f32<T>(e4m3fn_to_f32(q) * s);   // fp32 product, one rounding to dt
-        } else {
-            ((uint8_t*)out)[i] = q;
-        }
+        if (s == 0.0f) s = 1.0f;
+        T of;
+        uint8_t ob;
+        fp8_one<T>(to_f32<T>(W[i]), s, tdt, fake, DT, &of, &ob);
+        if (fake) ((T*)out)[i] = of; else ((uint8_t*)out)[i] = ob;
     }
 }
 
@@ -142,15 +185,15 @@ extern "C" int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int f
     hipStream_t st = (hipStream_t)stream;
     switch (dt) {
         case LLMC_F16:
-            hipLaunchKernelGGL((k_fp8_cast<f16_t>), dim3(grid_fb(G * g)), dim3(FB), 0, st, (const f16_t*)W,
+            hipLaunchKernelGGL((k_fp8_cast<f16_t>), dim3(grid_fb(G * g / 8 + 1)), dim3(FB), 0, st, (const f16_t*)W,
                                (const f16_t*)amax, sdt, scales, static_scales, G, g, fake, out);
             break;
         case LLMC_BF16:
-            hipLaunchKernelGGL((k_fp8_cast<bf16_t>), dim3(grid_fb(G * g)), dim3(FB), 0, st, (const bf16_t*)W,
+            hipLaunchKernelGGL((k_fp8_cast<bf16_t>), dim3(grid_fb(G * g / 8 + 1)), dim3(FB), 0, st, (const bf16_t*)W,
                                (const bf16_t*)amax, sdt, scales, static_scales, G, g, fake, out);
             break;
         default:
-            hipLaunchKernelGGL((k_fp8_cast<float>), dim3(grid_fb(G * g)), dim3(FB), 0, st, (const float*)W,
+            hipLaunchKernelGGL((k_fp8_cast<float>), dim3(grid_fb(G * g / 4 + 1)), dim3(FB), 0, st, (const float*)W,
                                (const float*)amax, sdt, scales, static_scales, G, g, fake, out);
     }
     LLMC_LAUNCH_CHECK();

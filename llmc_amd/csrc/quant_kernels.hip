@@ -140,16 +140,26 @@ __global__ void k_minmax_final(const float2* __restrict__ part, int64_t G, int64
                                int round_zp, float qmin, float qmax, T* __restrict__ scales,
                                T* __restrict__ zeros) {
     constexpr int DT = dt_of<T>::value;
+    __shared__ float smn[16], smx[16];
     int64_t row = blockIdx.x;
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t c = threadIdx.x; c < nch; c += 64) {
+    for (int64_t c = threadIdx.x; c < nch; c += 1024) {
         float2 p = part[row * nch + c];
         mn = fminf(mn, p.x);
         mx = fmaxf(mx, p.y);
     }
     mn = wave_min(mn, 64);
     mx = wave_max(mx, 64);
+    if ((threadIdx.x & 63) == 0) {
+        smn[threadIdx.x >> 6] = mn;
+        smx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) {
+            mn = fminf(mn, smn[i]);
+            mx = fmaxf(mx, smx[i]);
+        }
         QParams q = qparams_from_minmax(mn, mx, DT, sym, round_zp, qmin, qmax);
         scales[row] = from_f32<T>(q.s);
         if (zeros) zeros[row] = from_f32<T>(q.z);
@@ -246,6 +256,102 @@ __global__ __launch_bounds__(kBlock) void k_quant_dynamic(const T* __restrict__ 
     }
 }
 
+// ---- fast path for short rows (per_group: g == LPR * VEC exactly, one 16-B vector per lane per row):
+// UNR independent row-sets per wave iteration keep 4 loads per lane in flight (the generic loop has one and
+// measured 2.2-2.9 TB/s; HBM latency x bandwidth needs ~12 KB in flight per SIMD).
+static constexpr int UNR = 4;
+template <typename T, int VEC, int KIND, bool SCALE>
+__global__ __launch_bounds__(kBlock) void k_quant_dynamic_small(const T* __restrict__ W, const T* __restrict__ cs,
+                                                                int64_t G, int g, int gpr, int lpr, int sym,
+                                                                int round_zp, float qmin, float qmax,
+                                                                void* __restrict__ out, T* __restrict__ scales,
+                                                                T* __restrict__ zeros) {
+    constexpr int DT = dt_of<T>::value;
+    const int lane = threadIdx.x & 63;
+    const int rpw = 64 / lpr;
+    const int sub = lane / lpr, sl = lane % lpr;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r0 = wave * rpw * UNR; r0 < G; r0 += nwaves * rpw * UNR) {
+        RowVec<T, VEC> v[UNR];
+        bool valid[UNR];
+        int64_t rows[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t row = r0 + u * rpw + sub;
+            valid[u] = row < G;
+            rows[u] = valid[u] ? row : G - 1;
+            v[u] = load_vec<T, VEC>(W + rows[u] * g + sl * VEC);
+        }
+        if (SCALE) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                RowVec<T, VEC> sv = load_vec<T, VEC>(cs + (rows[u] % gpr) * g + sl * VEC);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    v[u].v[i] = from_f32<T>(rndc<DT>(to_f32<T>(v[u].v[i]) * to_f32<T>(sv.v[i])));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float f = to_f32<T>(v[u].v[i]);
+                mn = fminf(mn, f);
+                mx = fmaxf(mx, f);
+            }
+            mn = wave_min(mn, lpr);
+            mx = wave_max(mx, lpr);
+            const QParams q = qparams_from_minmax(mn, mx, DT, sym, round_zp, qmin, qmax);
+            if (valid[u] && sl == 0) {
+                if (scales) scales[rows[u]] = from_f32<T>(q.s);
+                if (zeros) zeros[rows[u]] = from_f32<T>(q.z);
+            }
+            if (!valid[u] || out == nullptr) continue;
+            if constexpr (KIND == LLMC_OUT_FAKE) {
+                RowVec<T, VEC> o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float qq = quant_code(to_f32<T>(v[u].v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                    o.v[k] = from_f32<T>(dequant_code(qq, q.s, q.z, DT));
+                }
+                store_vec<T, VEC>((T*)out + rows[u] * g + sl * VEC, o);
+            } else {
+                using C = typename code_t<KIND>::type;
+                RowVec<C, VEC> o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    o.v[k] = (C)quant_code(to_f32<T>(v[u].v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                C* op = (C*)out + rows[u] * g + sl * VEC;
+                if constexpr (sizeof(C) * VEC == 32) {
+                    uint4 lo, hi;
+                    __builtin_memcpy(&lo, &o.v[0], 16);
+                    __builtin_memcpy(&hi, &o.v[VEC / 2], 16);
+                    reinterpret_cast<uint4*>(op)[0] = lo;
+                    reinterpret_cast<uint4*>(op)[1] = hi;
+                } else if constexpr (sizeof(C) * VEC == 16) {
+                    uint4 lo;
+                    __builtin_memcpy(&lo, &o.v[0], 16);
+                    reinterpret_cast<uint4*>(op)[0] = lo;
+                } else if constexpr (sizeof(C) * VEC == 8) {
+                    uint2 lo;
+                    __builtin_memcpy(&lo, &o.v[0], 8);
+                    reinterpret_cast<uint2*>(op)[0] = lo;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) op[k] = o.v[k];
+                }
+            }
+        }
+    }
+}
+
+static inline bool small_ok(int64_t g, int vec) {
+    int64_t lpr = g / vec;
+    return g % vec == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+}
+
 // K7: LSB-first packing. One thread per output word; 32/bits consecutive codes -> one int32.
 template <typename C, bool VECOK>
 __global__ __launch_bounds__(kBlock) void k_pack_lsb(const C* __restrict__ codes, int64_t R, int64_t K,
@@ -321,12 +427,21 @@ static int minmax_qparams_t(const void* W, int64_t G, int64_t g, int sym, int ro
             hipLaunchKernelGGL((k_minmax_partial<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, G, g,
                                nch, (float2*)ws);
         LLMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_minmax_final<T>), dim3((unsigned)G), dim3(64), 0, st, (const float2*)ws, G, nch,
+        hipLaunchKernelGGL((k_minmax_final<T>), dim3((unsigned)G), dim3(1024), 0, st, (const float2*)ws, G, nch,
                            sym, round_zp, qmin, qmax, (T*)scales, (T*)zeros);
         LLMC_LAUNCH_CHECK();
         return LLMC_OK;
     }
     LLMC_REQUIRE(g < (1ll << 31), "minmax_qparams: row too long");
+    if (vec_ok && small_ok(g, V16)) {
+        int lpr = (int)(g / V16);
+        int grid = grid_for(ceil_div64(G, (64 / lpr) * UNR), kBlock / 64);
+        hipLaunchKernelGGL((k_quant_dynamic_small<T, V16, LLMC_OUT_FAKE, false>), dim3(grid), dim3(kBlock), 0, st,
+                           (const T*)W, (const T*)nullptr, G, (int)g, 1, lpr, sym, round_zp, qmin, qmax, (void*)nullptr,
+                           (T*)scales, (T*)zeros);
+        LLMC_LAUNCH_CHECK();
+        return LLMC_OK;
+    }
     if (vec_ok) {
         int lpr = choose_lpr(g, V16);
         int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
@@ -416,6 +531,14 @@ static int quant_dynamic_tk(const void* W, int64_t G, int64_t g, int sym, int ro
     bool vec_ok = (g % V16 == 0) && (((uintptr_t)W & 15) == 0) &&
                   (KIND != LLMC_OUT_FAKE || ((uintptr_t)out & 15) == 0);
     LLMC_REQUIRE(g < (1ll << 31), "quant_dynamic: row too long");
+    if (vec_ok && small_ok(g, V16) && (((uintptr_t)out & 15) == 0)) {
+        int lpr = (int)(g / V16);
+        int grid = grid_for(ceil_div64(G, (64 / lpr) * UNR), kBlock / 64);
+        hipLaunchKernelGGL((k_quant_dynamic_small<T, V16, KIND, false>), dim3(grid), dim3(kBlock), 0, st, (const T*)W,
+                           (const T*)nullptr, G, (int)g, 1, lpr, sym, round_zp, qmin, qmax, out, (T*)scales, (T*)zeros);
+        LLMC_LAUNCH_CHECK();
+        return LLMC_OK;
+    }
     if (vec_ok) {
         int lpr = choose_lpr(g, V16);
         int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
@@ -546,7 +669,13 @@ static int scale_fakequant_t(const void* W, const void* s, int64_t R, int64_t K,
     const int gpr = (int)(K / g);
     bool vec_ok = (g % V16 == 0) && (((uintptr_t)W & 15) == 0) && (((uintptr_t)out & 15) == 0) &&
                   (((uintptr_t)s & 15) == 0);
-    if (vec_ok) {
+    if (vec_ok && small_ok(g, V16)) {
+        int lpr = (int)(g / V16);
+        int grid = grid_for(ceil_div64(G, (64 / lpr) * UNR), kBlock / 64);
+        hipLaunchKernelGGL((k_quant_dynamic_small<T, V16, LLMC_OUT_FAKE, true>), dim3(grid), dim3(kBlock), 0, st,
+                           (const T*)W, (const T*)s, G, (int)g, gpr, lpr, sym, 1, qmin, qmax, out, (T*)nullptr,
+                           (T*)nullptr);
+    } else if (vec_ok) {
         int lpr = choose_lpr(g, V16);
         int grid = grid_for(ceil_div64(G, 64 / lpr), kBlock / 64);
         hipLaunchKernelGGL((k_scale_fakequant<T, V16>), dim3(grid), dim3(kBlock), 0, st, (const T*)W, (const T*)s, G,
