@@ -1,37 +1,46 @@
-"""Block loop base with llmc's BlockwiseOpt surface (llmc/compression/blockwise_optimization.py:8-114).
+"""Block-loop base class with the surface of llmc's BlockwiseOpt (llmc/compression/blockwise_optimization.py).
 
-Difference in mechanics: captured Linear inputs stay on the GPU (the reference moves every hooked input to the
-CPU, blockwise_optimization.py:53-61, and back for each use) — 288 GB of HBM hold a block's calibration
-activations many times over."""
+A transformer is compressed one block at a time: `run_block_loop()` visits the blocks in order and hands each
+to `block_opt()`; subclasses capture the inputs of the block's Linear layers through forward hooks
+(`cache_input_hook`) and rewrite the weights. Captured activations stay on the GPU here — 288 GB of HBM hold a
+block's calibration activations many times over — where the reference parks every hooked input on the host and
+brings it back for each use."""
 import os
-from abc import ABCMeta, abstractmethod
+from abc import ABC, abstractmethod
 
 import torch
 
 
-class BlockwiseOpt(metaclass=ABCMeta):
-    def __init__(self, model, compress_config, input, padding_mask, config):
-        self.model = model
-        self.blocks = model.get_blocks()
-        self.quant_config = compress_config
-        self.sparsity_config = compress_config
-        self.input = input
-        self.padding_mask = padding_mask
-        self.data_free = False if self.input else True
-        self.config = config
-        self.block_idx = None
-        self.num_blocks = len(self.blocks)
-        if self.input:
-            for kw in input['kwargs']:
-                kw.pop('use_cache', None)
-                if 'past_key_value' in kw:
-                    kw['past_key_value'] = None
-            self.n_samples = sum(d.shape[0] for d in input['data'])
+def _strip_cache_kwargs(kwargs_list):
+    """the first-block kwargs captured by the model adapter may carry a KV cache; it must not be reused"""
+    for kw in kwargs_list:
+        kw.pop('use_cache', None)
+        if 'past_key_value' in kw:
+            kw['past_key_value'] = None
 
+
+class BlockwiseOpt(ABC):
+    def __init__(self, model, compress_config, input, padding_mask, config):
+        self.model, self.config = model, config
+        self.quant_config = self.sparsity_config = compress_config
+        self.input, self.padding_mask = input, padding_mask
+        self.blocks = model.get_blocks()
+        self.num_blocks = len(self.blocks)
+        self.block_idx = None
+        self.data_free = not self.input
+        if not self.data_free:
+            _strip_cache_kwargs(input['kwargs'])
+            self.n_samples = int(sum(batch.shape[0] for batch in input['data']))
+
+    # ---- driver -----------------------------------------------------------------------------------
     def run_block_loop(self):
-        for i in range(len(self.blocks)):
-            self.block_idx = i
-            self.block_opt(self.blocks[i])
+        for idx, block in enumerate(self.blocks):
+            self.block_idx = idx
+            self.block_opt(block)
+        self._dump_side_products()
+
+    def _dump_side_products(self):
+        """AWQ's searched scales / clip bounds, for llmc's two-stage pipelines (scales.pth, clips.pth)."""
         if getattr(self, 'save_scale', False):
             os.makedirs(self.scale_path, exist_ok=True)
             torch.save(self.act_scales, os.path.join(self.scale_path, 'scales.pth'))
@@ -39,25 +48,24 @@ class BlockwiseOpt(metaclass=ABCMeta):
             os.makedirs(self.clip_path, exist_ok=True)
             torch.save(self.auto_clipper.weight_clips, os.path.join(self.clip_path, 'clips.pth'))
 
+    # ---- hooks --------------------------------------------------------------------------------------
     def cache_input_hook(self, m, x, y, name, feat_dict):
-        inputs = [i.detach() for i in x]
-        if len(inputs) == 1:
-            inp = inputs[0]
-            if inp.dim() == 2:
-                inp = inp.unsqueeze(0)
-            feat_dict[name].append(inp)
-        else:
-            feat_dict[name].append(tuple(inputs))
+        captured = tuple(t.detach() for t in x)
+        if len(captured) != 1:
+            feat_dict[name].append(captured)
+            return
+        (inp,) = captured
+        feat_dict[name].append(inp.unsqueeze(0) if inp.dim() == 2 else inp)
 
     @abstractmethod
     def block_opt(self, block):
-        pass
+        ...
 
     def layer_init(self, layer):
-        pass
+        return None
 
     def subset_init(self, subset):
-        pass
+        return None
 
     def block_init(self, block):
-        pass
+        return None

@@ -1,49 +1,79 @@
-"""Name -> class registries with llmc's decorator protocol (llmc/utils/registry_factory.py:1-49):
-`@ALGO_REGISTRY` registers a class under its __name__, `@ALGO_REGISTRY('key')` under a given key, a second
-registration of the same key raises, lookup is by item access."""
+"""Plug-in registries keyed by name, compatible with how llmc uses its own (llmc/utils/registry_factory.py):
+
+    @ALGO_REGISTRY                 # key = class name
+    class GPTQ(...): ...
+    @ALGO_REGISTRY('alias')        # explicit key
+    class Other(...): ...
+    algo_cls = ALGO_REGISTRY[config.quant.method]
+
+A key can be bound once; values must be callables (classes or factories).
+"""
+from collections.abc import Callable, Iterator
 
 
-class Register(dict):
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self._dict = {}
+class Registry:
+    """Mapping-like container with decorator registration."""
 
-    def _add(self, key, value):
+    __slots__ = ('_entries', 'kind')
+
+    def __init__(self, kind: str = 'entry'):
+        self._entries: dict = {}
+        self.kind = kind
+
+    # -- registration ---------------------------------------------------------------------------------
+    def bind(self, key: str, value: Callable) -> Callable:
         if not callable(value):
             raise Exception(f'Error:{value} must be callable!')
-        if key in self._dict:
+        if key in self._entries:
             raise Exception(f'{key} already exists.')
-        self._dict[key] = value
+        self._entries[key] = value
         return value
 
     def register(self, target):
+        """Decorator: bare (`@REG`, key = __name__) or with an explicit key (`@REG('name')`)."""
         if callable(target):
-            return self._add(target.__name__, target)
-        return lambda x: self._add(target, x)
+            return self.bind(target.__name__, target)
+        key = target
+
+        def with_key(value):
+            return self.bind(key, value)
+        return with_key
 
     __call__ = register
 
-    def __setitem__(self, key, value):
-        self._dict[key] = value
+    # -- lookup -----------------------------------------------------------------------------------------
+    def __getitem__(self, key: str) -> Callable:
+        return self._entries[key]
 
-    def __getitem__(self, key):
-        return self._dict[key]
+    def __setitem__(self, key: str, value: Callable) -> None:
+        self._entries[key] = value
 
-    def __contains__(self, key):
-        return key in self._dict
+    def __contains__(self, key: object) -> bool:
+        return key in self._entries
 
-    def __str__(self):
-        return str(self._dict)
+    def __iter__(self) -> Iterator[str]:
+        return iter(self._entries)
+
+    def __len__(self) -> int:
+        return len(self._entries)
 
     def keys(self):
-        return self._dict.keys()
+        return self._entries.keys()
 
     def values(self):
-        return self._dict.values()
+        return self._entries.values()
 
     def items(self):
-        return self._dict.items()
+        return self._entries.items()
+
+    def get(self, key, default=None):
+        return self._entries.get(key, default)
+
+    def __repr__(self) -> str:
+        return f'Registry({self.kind}: {sorted(self._entries)})'
 
 
-ALGO_REGISTRY = Register()
-MODEL_REGISTRY = Register()
+Register = Registry  # llmc's name for the class
+
+ALGO_REGISTRY = Registry('algorithm')
+MODEL_REGISTRY = Registry('model')
