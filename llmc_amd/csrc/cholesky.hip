@@ -62,8 +62,10 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 }
 
 // wave-level: factor the 32x32 block at S (upper Cholesky, in place, strict lower zeroed) and write its
-// inverse to V. Lane j (and its twin j+32) owns column j in registers.
-// The serial recurrence pivot -> sqrt -> row scale -> next pivot is kept short: row i updates row i+1 EAGERLY
+// inverse to V. Lanes 0..31 own the columns of the block; lanes 32..63 own the columns of an identity that
+// receives the SAME row operations (scale row i by 1/u_ii, subtract u_ik * row i from row k): the operations
+// that turn A into U turn I into U^-T, so the inverse costs no instruction beyond the factorisation's own.
+// The serial recurrence pivot -> rsq -> row scale -> next pivot is kept short: row i updates row i+1 EAGERLY
 // with one v_readlane multiplier, while its update of the rows below is applied one step LATER from a copy of the
 // row published in LDS (broadcast reads), off the critical path (look-ahead of depth one inside the wave).
 __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* __restrict__ V,
@@ -71,9 +73,11 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
                                                  int* __restrict__ info) {
 #pragma clang fp contract(fast)
     const int j = lane & 31;
+    const bool ehalf = lane >= 32;
+    const int jkeep = ehalf ? 32 : j;   // column j of A keeps row i only for j >= i; the identity half keeps all
     float a[32];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) a[i] = S[i * PLD + j];
+    for (int i = 0; i < 32; ++i) a[i] = ehalf ? (i == j ? 1.0f : 0.0f) : S[i * PLD + j];
     bool bad = false;
     float uprev = 0.0f;
 #pragma unroll
@@ -85,10 +89,16 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
         }
         const float d = rdlane(a[i], i);
         if (!(d > 0.0f)) bad = true;
-        const float rinv = 1.0f / sqrtf(d);
-        const float ui = (j > i) ? a[i] * rinv : (j == i ? d * rinv : 0.0f);
+        // 1/sqrt(d): hardware rsq (1 ulp) + one Newton step, instead of the correctly rounded sqrt and divide
+        // (about 30 dependent instructions on the pivot chain); nothing downstream needs those last bits
+        float rinv = __builtin_amdgcn_rsqf(d);
+        rinv = rinv * (1.5f - 0.5f * d * rinv * rinv);
+        const float ui = jkeep >= i ? a[i] * rinv : 0.0f;
         a[i] = ui;
         if (lane < 32) rowbuf[(i & 1) * 32 + j] = ui;   // publish row i of U for the lazy update of step i+1
+        // compiler-only ordering point: without it hipcc moves the broadcast reads of the double-buffered row
+        // across these writes (observed: wrong inverse), although the wave's LDS accesses execute in order
+        asm volatile("" ::: "memory");
         if (i + 1 < 32) {                               // eager: row i+1
             const float t = rdlane(ui, i + 1);
             a[i + 1] -= t * ui;
@@ -96,26 +106,13 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
         uprev = ui;
     }
     if (bad && lane == 0) atomicCAS(info, 0, kglobal + 1);
-    if (lane < 32) {
+    if (!ehalf) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) S[i * PLD + j] = a[i];
-    }
-    __builtin_amdgcn_wave_barrier();
-    // V = U^-1: lane j owns column j; row i of U is read from S as broadcasts; two partial sums per dot product
-    float v[32];
+    } else {   // a[i] = (U^-T)[i][j] = V[j][i]: this lane holds row j of V
 #pragma unroll
-    for (int i = 31; i >= 0; --i) {
-        float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-        for (int k = i + 1; k < 32; ++k) {
-            if (k & 1) acc1 += S[i * PLD + k] * v[k];
-            else acc0 += S[i * PLD + k] * v[k];
-        }
-        v[i] = ((j == i ? 1.0f : 0.0f) - (acc0 + acc1)) / S[i * PLD + i];
-    }
-    if (lane < 32) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) V[i * PLD + j] = v[i];
+        for (int i = 0; i < 32; i += 4)
+            *reinterpret_cast<float4*>(V + j * PLD + i) = make_float4(a[i], a[i + 1], a[i + 2], a[i + 3]);
     }
 }
 
@@ -148,6 +145,14 @@ __device__ __forceinline__ void blk_sub(float* __restrict__ C, const pf32x16& ac
 }
 #define PBLK(M, bi, bj) ((M) + (bi) * 32 * PLD + (bj) * 32)
 
+// phase stamps for tools/probes/probe_potrf.hip (compiled out of the product build)
+#ifdef LLMC_PROBE_STAMPS
+__device__ long long g_potrf_stamps[32];
+#define LLMC_STAMP(i) do { if (threadIdx.x == 0) g_potrf_stamps[i] = clock64(); } while (0)
+#else
+#define LLMC_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_t ld, int k0, int nb,
                                                    float* __restrict__ Vout, int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) float plds[];
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const pf32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    LLMC_STAMP(0);
     // load the block with 16 independent 16-B loads per thread in flight (a scalar loop here serialises 64
     // dependent global-load latencies and was most of this kernel's time)
     {
@@ -189,16 +195,19 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
                 const int jj = j + t;
                 float x = (i == jj) ? 1.0f : 0.0f;                 // identity padding
                 if (i < nb && jj < nb) x = (jj >= i) ? vv[t] : 0.0f;
-                S[i * PLD + jj] = x;
-                V[i * PLD + jj] = 0.0f;
+                vv[t] = x;
             }
+            *reinterpret_cast<float4*>(S + i * PLD + j) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         }
+        // V needs no initialisation: every block of its upper part is written before it is read
     }
     __syncthreads();
+    LLMC_STAMP(1);
     // ---- blocked upper Cholesky over 4 block rows
     for (int kb = 0; kb < 4; ++kb) {
         if (wv == 0) wave_potrf32_inv(PBLK(S, kb, kb), PBLK(V, kb, kb), rowbuf, lane, k0 + kb * 32, info);
         __syncthreads();
+        LLMC_STAMP(2 + 2 * kb);
         {   // panel: S(kb, jb) = V_kk^T * S(kb, jb)
             const int jb = kb + 1 + wv;
             if (jb < 4) {
@@ -217,12 +226,24 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
                     }
         }
         __syncthreads();
+        LLMC_STAMP(3 + 2 * kb);
     }
     // ---- U back to the work matrix (S becomes scratch afterwards)
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        if (i < nb && j < nb) W[(int64_t)(k0 + i) * ld + k0 + j] = (j >= i) ? S[i * PLD + j] : 0.0f;
+    if (nb == NB && (ld % 4 == 0) && (k0 % 4 == 0)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e4 = tid + 256 * q;
+            const int i = e4 >> 5, j = (e4 & 31) * 4;
+            const float4 s4 = *reinterpret_cast<const float4*>(S + i * PLD + j);   // strict lower is zero in S
+            *reinterpret_cast<float4*>(W + (int64_t)(k0 + i) * ld + k0 + j) = s4;
+        }
+    } else {
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e >> 7, j = e & 127;
+            if (i < nb && j < nb) W[(int64_t)(k0 + i) * ld + k0 + j] = (j >= i) ? S[i * PLD + j] : 0.0f;
+        }
     }
+    LLMC_STAMP(10);
     // ---- V = U^-1 by doubling. Level 32 -> 64: pairs (0,1) and (2,3)
     if (wv < 2) {
         const int a = 2 * wv, b = a + 1;
@@ -248,11 +269,22 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
         blk_store(PBLK(S, r, c), y, lane, -1.0f);
     }
     __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e >> 7, j = e & 127;
+    LLMC_STAMP(11);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e4 = tid + 256 * q;
+        const int i = e4 >> 5, j = (e4 & 31) * 4;
         const float* src = (i < 64 && j >= 64) ? S : V;
-        Vout[e] = (j >= i) ? src[i * PLD + j] : 0.0f;
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j + 3 >= i) {   // the 4-column group touches the upper part (blocks below the diagonal hold no data)
+            v4 = *reinterpret_cast<const float4*>(src + i * PLD + j);
+            if (j < i) v4.x = 0.0f;
+            if (j + 1 < i) v4.y = 0.0f;
+            if (j + 2 < i) v4.z = 0.0f;
+        }
+        *reinterpret_cast<float4*>(Vout + i * NB + j) = v4;
     }
+    LLMC_STAMP(12);
 }
 #undef PBLK
 

@@ -112,30 +112,265 @@ __device__ __forceinline__ void gptq_steps16(float (&w)[8], const float (&w0)[8]
 #undef LLMC_STEP
 }
 
-static constexpr int GBT = 512;  // threads per workgroup: 8 waves x 4 rows
 
-__global__ __launch_bounds__(GBT) void k_gptq_block(GptqBlockArgs a) {
+// ---------------------------------------------------------------------------------------------------------
+// Fast in-block path (count == 128). The serial chain of a column step is what bounds this kernel (one wave
+// per SIMD at R = 4096), so the chain is cut to ~22 dependent VALU ops:
+//   * the two IEEE divisions (w / scale and diff / d) divide by values that are fixed for many steps, so
+//     the reciprocal refinement  y = rcp(d) * (2 - d * rcp(d))  is hoisted (per column for d, per group for
+//     the scale) and each quotient is the remaining 5 ops of the very sequence hipcc emits for `n / d`
+//     (mul, fma, fma, fma, div_fmas == fma).  That sequence first passes n and d through v_div_scale_f32,
+//     which is the identity when both are "plain" (2^-40 <= |x| < 2^40, see the ISA's scaling rules), and
+//     ends in v_div_fixup_f32, which only acts on zero / inf / nan / denormal operands.  Every step checks
+//     its operands are plain (or n == 0, whose quotient is n); a wave that ever sees anything else discards
+//     its work and redoes the block with the generic path below, so results are bit-identical by
+//     construction, not by argument.
+//   * the broadcast of the current column is a DPP row_newbcast (VALU latency) instead of an LDS swizzle;
+//   * the U row, d and 1/d of a step do not depend on the chain and are read from LDS ahead of it; there is
+//     no control flow inside the 128 steps, the losses are evaluated after the loop.
+template <int PO> __device__ __forceinline__ float row_bcast(float v) {
+    // row_newbcast:PO (gfx90a+): every lane of a 16-lane row reads lane PO of its row
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + PO, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = fmaf(-d, y0, 1.0f);
+    return fmaf(e0, y0, y0);
+}
+// 2^-40 <= x < 2^40 and x > 0
+__device__ __forceinline__ bool plain_pos(float x) { return (__float_as_uint(x) - 0x2B800000u) < 0x28000000u; }
+// Range tracker for the numerators: lo/hi = min/max over the |n| bit patterns seen (zeros count as plain).
+struct PlainRange {
+    uint32_t lo, hi;
+    __device__ __forceinline__ void init() { lo = 0x2B800000u; hi = 0x2B800000u; }
+    __device__ __forceinline__ void see(float n) {
+        const uint32_t b = __float_as_uint(n) & 0x7fffffffu;
+        const uint32_t c = n == 0.0f ? 0x2B800000u : b;
+        lo = lo < c ? lo : c;
+        hi = hi > c ? hi : c;
+    }
+    __device__ __forceinline__ bool ok() const { return lo >= 0x2B800000u && hi < 0x53800000u; }
+};
+// n / d for plain d > 0 with y = rcp_refined(d) and n plain or zero
+__device__ __forceinline__ float div_plain(float n, float d, float y) {
+    const float q0 = n * y;
+    const float e1 = fmaf(-d, q0, n);
+    const float q1 = fmaf(e1, y, q0);
+    const float e2 = fmaf(-d, q1, n);
+    const float q = fmaf(e2, y, q1);
+    return n == 0.0f ? n : q;
+}
+
+// One step. (u, dd) were loaded during the previous step; this step loads (un, ddn) for the next one first.
+template <int I, bool STATIC>
+__device__ __forceinline__ void fast_step(float (&w)[8], float (&er)[8], float (&df)[8], const float (&sc)[8],
+                                          const float (&zr)[8], const float (&ys)[8],
+                                          const float* __restrict__ us, const float2* __restrict__ dtab, int p,
+                                          float s_cur, float z_cur, float y_cur, float qmin, float qmax,
+                                          PlainRange& pr, const float (&u)[8], const float2& dd, float (&un)[8],
+                                          float2& ddn) {
+    constexpr int PO = StepIdx<I>::PO, EO = StepIdx<I>::EO;
+    if (I + 1 < BS) {
+        constexpr int EN = StepIdx<I + 1>::EO;
+#pragma unroll
+        for (int e = EN; e < 8; ++e) un[e] = us[(I + 1) * BS + e];
+        ddn = dtab[I + 1];
+    }
+    float s = s_cur, z = z_cur, y = y_cur;
+    if (STATIC) {
+        s = row_bcast<PO>(sc[EO]);
+        z = row_bcast<PO>(zr[EO]);
+        y = row_bcast<PO>(ys[EO]);
+    }
+    const float wi = row_bcast<PO>(w[EO]);
+    pr.see(wi);
+    float t = div_plain(wi, s, y);                  // quant_code(): x / s
+    t = rintf(t);
+    t = t + z;
+    const float qc = fminf(fmaxf(t, qmin), qmax);
+    const float q = (qc - z) * s;                   // dequant_code()
+    const float diff = wi - q;
+    pr.see(diff);
+    const float err = div_plain(diff, dd.x, dd.y);
+    const bool own = p == PO;
+    er[EO] = own ? err : er[EO];
+    df[EO] = own ? diff : df[EO];
+    // pin the two selects here: left alone, the optimiser turns the 16-deep select chains into a private array
+    // indexed by p after the loop, which keeps all 256 err / diff values alive (spills)
+    asm volatile("" : "+v"(er[EO]), "+v"(df[EO]), "+v"(pr.lo), "+v"(pr.hi));
+#pragma unroll
+    for (int e = EO; e < 8; ++e) {
+        const float tt = err * u[e];
+        w[e] = w[e] - tt;
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting later steps' loads (register blow-up)
+}
+
+template <int I0, bool STATIC>
+__device__ __forceinline__ void fast_steps16(float (&w)[8], float (&er)[8], float (&df)[8], const float (&sc)[8],
+                                             const float (&zr)[8], const float (&ys)[8],
+                                             const float* __restrict__ us, const float2* __restrict__ dtab,
+                                             int p, float s_cur, float z_cur, float y_cur, float qmin,
+                                             float qmax, PlainRange& pr, float (&ua)[8], float2& da, float (&ub)[8],
+                                             float2& db) {
+#define LLMC_FSTEP2(J)                                                                                        \
+    fast_step<I0 + J, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, qmin, qmax, pr, ua, da,  \
+                              ub, db);                                                                        \
+    fast_step<I0 + J + 1, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, qmin, qmax, pr, ub,  \
+                                  db, ua, da);
+    LLMC_FSTEP2(0) LLMC_FSTEP2(2) LLMC_FSTEP2(4) LLMC_FSTEP2(6) LLMC_FSTEP2(8) LLMC_FSTEP2(10) LLMC_FSTEP2(12)
+    LLMC_FSTEP2(14)
+#undef LLMC_FSTEP2
+}
+
+// Whole block for one wave (4 rows); returns false (and stores nothing) if any lane met a non-plain operand.
+template <bool STATIC, int GSZ>
+__device__ __forceinline__ bool block_fast(const GptqBlockArgs& a, const float* __restrict__ Us,
+                                           const float2* __restrict__ dtab, int p, int64_t row, bool active) {
+    const int64_t rr = active ? row : a.R - 1;
+    float w[8], w0[8], er[8], df[8], sc[8], zr[8], ys[8];
+    bool bad = false;
+    PlainRange pr;
+    pr.init();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = p + 16 * e;
+        w[e] = a.W[rr * a.K + a.i1 + c];
+        w0[e] = w[e];
+        er[e] = 0.0f;
+        df[e] = 0.0f;
+        sc[e] = 1.0f;
+        zr[e] = 0.0f;
+        ys[e] = 1.0f;
+        if (STATIC) {
+            const int g = a.col_group ? a.col_group[a.i1 + c] : 0;
+            sc[e] = a.scales[rr * a.ng + g];
+            zr[e] = a.zeros ? a.zeros[rr * a.ng + g] : 0.0f;
+            ys[e] = rcp_refined(sc[e]);
+            bad |= !plain_pos(sc[e]);
+        }
+    }
+    float s_cur = 1.0f, z_cur = 0.0f, y_cur = 1.0f;
+    float s_grp[8], z_grp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s_grp[e] = 0.0f;
+        z_grp[e] = 0.0f;
+    }
+    const float* us = Us + p * 8;
+    float ua[8], ub[8];
+    float2 da = dtab[0], db = da;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ua[e] = us[e];
+        ub[e] = 0.0f;
+    }
+#define LLMC_FCHUNK(E)                                                                                 \
+    if (!STATIC && ((16 * E) % GSZ) == 0) {                                                            \
+        float mn = INFINITY, mx = -INFINITY;                                                           \
+        constexpr int e1 = (16 * E + GSZ) >> 4;                                                        \
+        _Pragma("unroll") for (int e = E; e < 8; ++e) if (e < e1) {                                    \
+            mn = fminf(mn, w0[e]);                                                                     \
+            mx = fmaxf(mx, w0[e]);                                                                     \
+        }                                                                                              \
+        mn = wave_min(mn, 16);                                                                         \
+        mx = wave_max(mx, 16);                                                                         \
+        const QParams qp = qparams_from_minmax(mn, mx, LLMC_F32, a.sym, 1, a.qmin, a.qmax);            \
+        s_cur = qp.s;                                                                                  \
+        z_cur = qp.z;                                                                                  \
+        y_cur = rcp_refined(s_cur);                                                                    \
+        bad |= !plain_pos(s_cur);                                                                      \
+    }                                                                                                  \
+    fast_steps16<16 * E, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, a.qmin, a.qmax, pr,  \
+                                 ua, da, ub, db);                                                      \
+    s_grp[E] = s_cur;                                                                                  \
+    z_grp[E] = z_cur;
+    LLMC_FCHUNK(0) LLMC_FCHUNK(1) LLMC_FCHUNK(2) LLMC_FCHUNK(3) LLMC_FCHUNK(4) LLMC_FCHUNK(5) LLMC_FCHUNK(6)
+    LLMC_FCHUNK(7)
+#undef LLMC_FCHUNK
+    if (__any(bad || !pr.ok())) return false;
+    if (!active) return true;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = p + 16 * e;
+        a.Wout[row * a.K + a.i1 + c] = w[e];
+        if (a.losses) {
+            const float d = dtab[c].x;
+            a.losses[row * a.K + a.i1 + c] = (df[e] * df[e]) / (2.0f * (d * d));
+        }
+        a.Err[row * a.err_ld + c] = er[e];
+    }
+    if (!STATIC && p == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = 16 * e;
+            if ((i % GSZ) == 0) {
+                const int g = (a.i1 + i) / GSZ;
+                a.scales[row * a.ng + g] = s_grp[e];
+                if (a.zeros) a.zeros[row * a.ng + g] = z_grp[e];
+            }
+        }
+    }
+    return true;
+}
+
+static constexpr int GBT = 512;  // threads per workgroup: 8 waves x 4 rows (1024 for tall weights, see launch)
+
+// VARIANT: 0 generic path only; 1 fast path for given qparams (static groups / per-channel); 16/32/64/128 fast
+// path for qparams taken at group starts with that group size. The fast variants fall back to the generic code
+// per wave.
+template <int VARIANT, int NT>
+__global__ __launch_bounds__(NT) void k_gptq_block(GptqBlockArgs a) {
     // Us[i][p*8 + e] = U[i1+i][i1 + p + 16e] for p+16e > i, else 0 ; dg[i] = U[i1+i][i1+i]
     __shared__ __attribute__((aligned(16))) float Us[BS * BS];
     __shared__ float dg[BS];
+    __shared__ float2 dtab[BS];   // fast path: {d, refined 1/d}
+    __shared__ int d_not_plain;   // some d of the block is outside the plain range: generic path for everyone
+    if (threadIdx.x == 0) d_not_plain = 0;
+    __syncthreads();
     const int tid = threadIdx.x;
-    for (int e = tid; e < BS * BS; e += GBT) {
-        const int i = e >> 7, c = e & 127;  // c = column inside the block
-        float v = 0.0f;
-        if (i < a.count && c < a.count) {
-            const float u = a.U[(int64_t)(a.i1 + i) * a.K + a.i1 + c];
-            if (c > i) v = u;
-            if (c == i) dg[i] = u;
+    {
+        // all 8 float4 loads of a thread are issued before the first use (a per-element loop serialises 32
+        // L2 round trips, which used to be most of this kernel's time)
+        constexpr int NV = BS * BS / 4 / NT;
+        float4 v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = tid + NT * j;
+            const int i = idx >> 5, c4 = (idx & 31) * 4;   // count and i1 are multiples of 4
+            v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i < a.count && c4 < a.count)
+                v[j] = *reinterpret_cast<const float4*>(a.U + (int64_t)(a.i1 + i) * a.K + a.i1 + c4);
         }
-        Us[i * BS + (c & 15) * 8 + (c >> 4)] = v;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = tid + NT * j;
+            const int i = idx >> 5, c4 = (idx & 31) * 4;
+            const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = c4 + t;   // column inside the block
+                if (c == i && i < a.count) {
+                    dg[i] = vv[t];
+                    dtab[i] = make_float2(vv[t], rcp_refined(vv[t]));
+                    if (!plain_pos(vv[t])) d_not_plain = 1;
+                }
+                Us[i * BS + (c & 15) * 8 + (c >> 4)] = c > i ? vv[t] : 0.0f;
+            }
+        }
     }
     __syncthreads();
 
     const int lane = tid & 63;
     const int p = lane & 15;
-    const int64_t row = ((int64_t)blockIdx.x * (GBT / 64) + (tid >> 6)) * 4 + (lane >> 4);
+    const int64_t row = ((int64_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 4 + (lane >> 4);
     const bool active = row < a.R;
     const int64_t rr = active ? row : a.R - 1;
+
+    if (VARIANT != 0 && !d_not_plain) {
+        const bool done = block_fast<VARIANT == 1, VARIANT == 1 ? BS : VARIANT>(a, Us, dtab, p, row, active);
+        if (done) return;
+    }
 
     float w[8], w0[8], er[8], ls[8], sc[8], zr[8];
 #pragma unroll
@@ -229,6 +464,7 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
     float* ErrBuf[2] = {(float*)ws, (float*)ws + (size_t)R * ELD};   // [R, GRP*128] x 2: err columns of a group
     SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
     bool pending_side = false;
+    const int force_generic = getenv("LLMC_GPTQ_GENERIC") ? 1 : 0;
     // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as
     // "W -= chain over the block's 128 k" (gptq.py:244). Columns inside the current outer group get them right
     // after each block (the next block needs them); columns beyond the group get the group's GRP updates in one
@@ -247,8 +483,22 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
             a.scales = scales; a.zeros = zeros; a.col_group = per_channel ? nullptr : col_group;
             a.R = R; a.K = (int)K; a.i1 = (int)i1; a.count = count; a.ng = ng; a.gsz = static_mode ? BS : gsz;
             a.static_mode = static_mode; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
-            const int grid = (int)ceil_div64(R, GBT / 16);
-            hipLaunchKernelGGL(k_gptq_block, dim3(grid), dim3(GBT), 0, st, a);
+            // 64 KB of LDS per workgroup = 2 workgroups per CU: tall weights use 1024-thread workgroups so that the
+            // whole grid is resident at once (R = 28672: 448 workgroups on 512 slots instead of 896)
+            const int nt = R >= 16384 ? 1024 : GBT;
+            const int grid = (int)ceil_div64(R, nt / 16);
+            // group sizes 16/32/64 with qparams taken mid-block stay on the generic path (their fast variants
+            // spill: the qparams change inside the unrolled loop)
+            const int variant = (count != BS || force_generic) ? 0 : static_mode ? 1 : gsz == BS ? BS : 0;
+            switch (variant) {
+#define LLMC_GB(V)                                                                                   \
+    case V:                                                                                          \
+        if (nt == 1024) hipLaunchKernelGGL((k_gptq_block<V, 1024>), dim3(grid), dim3(1024), 0, st, a); \
+        else hipLaunchKernelGGL((k_gptq_block<V, GBT>), dim3(grid), dim3(GBT), 0, st, a);             \
+        break;
+                LLMC_GB(0) LLMC_GB(1) LLMC_GB(128)
+#undef LLMC_GB
+            }
             LLMC_LAUNCH_CHECK();
             const int64_t i2 = i1 + count;
             if (i2 < gend) {   // near columns of the group

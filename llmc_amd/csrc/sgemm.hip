@@ -196,20 +196,30 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
     }
 
     // epilogue: acc[m][n][r] -> row i0 + wm*64 + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), col j0 + wn*64 + n*32 + (lane&31)
+    // SG_SUB without the phased path: all C loads of a 32x32 block are issued before its first store (a fused
+    // load-subtract-store loop is ordered load, store, load, ... by possible aliasing: 64 serial round trips).
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int col = j0 + wn * 64 + n * 32 + (lane & 31);
-            if (col >= N) continue;
+            const bool colok = col < N;
+            float old[16];
+            if (!(PHASED && phased) && a.epilogue == SG_SUB) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    old[r] = (colok && row < M) ? C[(int64_t)row * a.ldc + col] : 0.0f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= M) continue;
+                if (!colok || row >= M) continue;
                 float* pc = C + (int64_t)row * a.ldc + col;
                 const float v = acc[m][n][r];
                 if (PHASED && phased) *pc = cv[m][n][r];
-                else if (a.epilogue == SG_SUB) *pc = *pc - v;
+                else if (a.epilogue == SG_SUB) *pc = old[r] - v;
                 else if (a.epilogue == SG_SET) *pc = v;
                 else *pc = -v;
             }
@@ -222,6 +232,13 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
                      (((uintptr_t)a.B & 15) == 0) && (a.sA % 4 == 0) && (a.sB % 4 == 0),
                  "sgemm: operands must be 16-B aligned with ld % 4 == 0");
     dim3 grid((a.N + GB - 1) / GB, (a.M + GB - 1) / GB, a.batch);
+    if (a.phase_len == 0 && a.epilogue == SG_SUB && !a.a_upper && !TB) {
+        // plain C -= AB: one phase covering the whole K loop, i.e. the C tile is fetched while the first operand
+        // tiles are, and the epilogue is stores only (same single rounding C - acc)
+        SgemmArgs b = a;
+        b.phase_len = 1 << 30;
+        return sgemm_launch(b, TA, TB, st);
+    }
     if (a.phase_len > 0) {
         LLMC_REQUIRE(a.phase_len % GK == 0 && a.epilogue == SG_SUB && !a.a_upper, "sgemm: bad phased configuration");
         if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false, true>), grid, dim3(256), 0, st, a);
