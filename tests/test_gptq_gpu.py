@@ -28,7 +28,9 @@ def sgemm(A, B, C, M, N, Kd, TA, TB, epi, hints=(0, 0, 0, 0)):
     return C
 
 
-@pytest.mark.parametrize('shape', [(96, 200, 128), (300, 260, 128), (128, 128, 16), (257, 513, 72), (1024, 3968, 128)])
+# Kd <= 128 runs the short-K kernel, larger Kd the 128x128-tile kernel
+@pytest.mark.parametrize('shape', [(96, 200, 128), (300, 260, 128), (128, 128, 16), (257, 513, 72), (1024, 3968, 128),
+                                   (200, 300, 512), (257, 129, 200), (64, 64, 2), (130, 70, 127)])
 def test_sgemm_bitwise_chain(shape):
     M, N, Kd = shape
     gen = torch.Generator().manual_seed(M + N)
@@ -76,6 +78,27 @@ def test_sgemm_triangular_hints_do_not_change_bits():
     full = sgemm(Ad, Xd, torch.zeros(n, n).cuda(), n, n, n, True, False, 1)
     hint = sgemm(Ad, Xd, torch.zeros(n, n).cuda(), n, n, n, True, False, 1, (0, 1, 0, 0))
     assert torch.equal(full, hint)
+
+
+def test_sgemm_shortk_hints_do_not_change_bits():
+    n = 128
+    gen = torch.Generator().manual_seed(2)
+    V = torch.triu(torch.randn(n, n, generator=gen))
+    X = torch.randn(n, 520, generator=gen)
+    Vd, Xd = V.cuda(), X.cuda()
+    # panel solve shape: op(A) = V^T (lower), Kd = 128
+    full = sgemm(Vd, Xd, torch.zeros(n, 520).cuda(), n, 520, n, True, False, 1)
+    hint = sgemm(Vd, Xd, torch.zeros(n, 520).cuda(), n, 520, n, True, False, 1, (0, 1, 0, 0))
+    assert torch.equal(full, hint)
+    # symmetric update, upper tiles only: tiles that touch j >= i equal the full result, the others are untouched
+    P = torch.randn(n, 384, generator=gen).cuda()
+    C0 = torch.randn(384, 384, generator=gen).cuda()
+    full = sgemm(P, P, C0.clone(), 384, 384, n, True, False, 0)
+    up = sgemm(P, P, C0.clone(), 384, 384, n, True, False, 0, (0, 0, 0, 1))
+    iu = torch.triu(torch.ones(384, 384, dtype=torch.bool)).cuda()
+    assert torch.equal(full[iu], up[iu])
+    tile_lower = (torch.arange(384)[None, :] // 64 * 64 + 64 <= torch.arange(384)[:, None] // 64 * 64).cuda()
+    assert torch.equal(up[tile_lower], C0[tile_lower])
 
 
 def test_column_loop_bit_exact_vs_reference_golden():
