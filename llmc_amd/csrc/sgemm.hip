@@ -18,7 +18,9 @@ struct Stage {
     float4 v[2];
 };
 
-// memory is k-major: src[k*ld + c]; tile rows k0..k0+15, cols c0..c0+127
+// memory is k-major: src[k*ld + c]; tile rows k0..k0+15, cols c0..c0+127. EDGE = false: the tile is known to be
+// fully inside the operand (no bounds checks, no control flow around the loads).
+template <bool EDGE>
 __device__ __forceinline__ Stage load_kmajor(const float* src, int64_t ld, int k0, int c0, int kmax, int cmax,
                                              int tid) {
     Stage s;
@@ -28,7 +30,9 @@ __device__ __forceinline__ Stage load_kmajor(const float* src, int64_t ld, int k
         int k = k0 + (idx >> 5);
         int c = c0 + 4 * (idx & 31);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kmax) {
+        if (!EDGE) {
+            v = *reinterpret_cast<const float4*>(src + (int64_t)k * ld + c);
+        } else if (k < kmax) {
             const float* p = src + (int64_t)k * ld + c;
             if (c + 3 < cmax) {
                 v = *reinterpret_cast<const float4*>(p);
@@ -50,6 +54,7 @@ __device__ __forceinline__ void store_kmajor(float* lds, const Stage& s, int tid
     }
 }
 // memory is c-major: src[c*ld + k]; transposed by the LDS writes
+template <bool EDGE>
 __device__ __forceinline__ Stage load_cmajor(const float* src, int64_t ld, int k0, int c0, int kmax, int cmax,
                                              int tid) {
     Stage s;
@@ -59,7 +64,9 @@ __device__ __forceinline__ Stage load_cmajor(const float* src, int64_t ld, int k
         int c = c0 + (idx >> 2);
         int k = k0 + 4 * (idx & 3);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < cmax) {
+        if (!EDGE) {
+            v = *reinterpret_cast<const float4*>(src + (int64_t)c * ld + k);
+        } else if (c < cmax) {
             const float* p = src + (int64_t)c * ld + k;
             if (k + 3 < kmax) {
                 v = *reinterpret_cast<const float4*>(p);
@@ -85,8 +92,8 @@ __device__ __forceinline__ void store_cmajor(float* lds, const Stage& s, int tid
     }
 }
 
-template <bool TA, bool TB, bool PHASED>
-__global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
+template <bool TA, bool TB, bool PHASED, bool EDGE>
+__global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * GK * GLD];  // [buf][A|B][k][row]
     const int z = blockIdx.z;
     const float* A = a.A + (int64_t)z * a.sA;
@@ -134,11 +141,11 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
 
     auto loadA = [&](int k0) {
         // op(A)[i][k]: TA -> stored [Kd x M] k-major ; else stored [M x Kd] row(i)-major
-        return TA ? load_kmajor(A, a.lda, k0, i0, ke, M, tid) : load_cmajor(A, a.lda, k0, i0, ke, M, tid);
+        return TA ? load_kmajor<EDGE>(A, a.lda, k0, i0, ke, M, tid) : load_cmajor<EDGE>(A, a.lda, k0, i0, ke, M, tid);
     };
     auto loadB = [&](int k0) {
         // op(B)[k][j]: !TB -> stored [Kd x N] k-major ; TB -> stored [N x Kd]
-        return TB ? load_cmajor(B, a.ldb, k0, j0, ke, N, tid) : load_kmajor(B, a.ldb, k0, j0, ke, N, tid);
+        return TB ? load_cmajor<EDGE>(B, a.ldb, k0, j0, ke, N, tid) : load_kmajor<EDGE>(B, a.ldb, k0, j0, ke, N, tid);
     };
     auto storeA = [&](int buf, const Stage& s) {
         float* p = lds + buf * (2 * GK * GLD);
@@ -150,31 +157,56 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
     };
 
     if (kb < ke) {
-        Stage sa = loadA(kb), sb = loadB(kb);
-        storeA(0, sa);
-        storeB(0, sb);
+        // register prefetch of depth two: the loads of K-step n+2 are issued before the MFMAs of step n, so a load
+        // has two MFMA phases (~1.7 us) to land before it is written to LDS (one phase is less than the HBM latency
+        // under load and stalled every step)
+        Stage ra[2], rb[2];
+        ra[0] = loadA(kb);
+        rb[0] = loadB(kb);
+        storeA(0, ra[0]);
+        storeB(0, rb[0]);
+        if (kb + GK < ke) {
+            ra[1] = loadA(kb + GK);
+            rb[1] = loadB(kb + GK);
+        }
         __syncthreads();
-        int cur = 0;
-        for (int k0 = kb; k0 < ke; k0 += GK) {
+        auto step = [&](int k0, int cur, Stage& fa_next2, Stage& fb_next2, const Stage& fa_next, const Stage& fb_next) {
             const bool more = k0 + GK < ke;
-            if (more) {
-                sa = loadA(k0 + GK);
-                sb = loadB(k0 + GK);
+            if (k0 + 2 * GK < ke) {
+                fa_next2 = loadA(k0 + 2 * GK);
+                fb_next2 = loadB(k0 + 2 * GK);
             }
             const float* pa = lds + cur * (2 * GK * GLD) + (lane >> 5) * GLD + wm * 64 + (lane & 31);
             const float* pb = lds + cur * (2 * GK * GLD) + GK * GLD + (lane >> 5) * GLD + wn * 64 + (lane & 31);
+            // operand fragments double-buffered in registers: the LDS reads of pair kk+1 are in flight while the four
+            // MFMAs of pair kk run (reusing one register set exposes the LDS latency before every group of MFMAs)
+            float fa[2][2], fb[2][2];
+            fa[0][0] = pa[0];
+            fa[0][1] = pa[32];
+            fb[0][0] = pb[0];
+            fb[0][1] = pb[32];
 #pragma unroll
             for (int kk = 0; kk < GK / 2; ++kk) {
-                float fa[2], fb[2];
-                fa[0] = pa[2 * kk * GLD];
-                fa[1] = pa[2 * kk * GLD + 32];
-                fb[0] = pb[2 * kk * GLD];
-                fb[1] = pb[2 * kk * GLD + 32];
+                const int c = kk & 1;
+                if (kk + 1 < GK / 2) {
+                    fa[c ^ 1][0] = pa[2 * (kk + 1) * GLD];
+                    fa[c ^ 1][1] = pa[2 * (kk + 1) * GLD + 32];
+                    fb[c ^ 1][0] = pb[2 * (kk + 1) * GLD];
+                    fb[c ^ 1][1] = pb[2 * (kk + 1) * GLD + 32];
+                }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][m], fb[c][n], acc[m][n], 0, 0, 0);
+            }
+            // machine schedule: reads of pairs 0 and 1, then [4 MFMAs of pair kk, reads of pair kk+2] ... (left alone the
+            // scheduler sinks every read to just before its MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int kk = 0; kk < GK / 2; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (kk + 2 < GK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
             if (PHASED && phased && ((k0 + GK - kb) % a.phase_len == 0 || !more)) {
 #pragma unroll
@@ -188,11 +220,14 @@ __global__ __launch_bounds__(256) void k_sgemm(SgemmArgs a) {
                         }
             }
             if (more) {
-                storeA(cur ^ 1, sa);
-                storeB(cur ^ 1, sb);
+                storeA(cur ^ 1, fa_next);
+                storeB(cur ^ 1, fb_next);
             }
             __syncthreads();
-            cur ^= 1;
+        };
+        for (int k0 = kb; k0 < ke; k0 += 2 * GK) {
+            step(k0, 0, ra[0], rb[0], ra[1], rb[1]);                       // stage in buffer 0; next stage sits in r[1]
+            if (k0 + GK < ke) step(k0 + GK, 1, ra[1], rb[1], ra[0], rb[0]);
         }
     }
 
@@ -368,15 +403,24 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
         b.phase_len = 1 << 30;
         return sgemm_launch(b, TA, TB, st);
     }
+    // interior-only instantiation when every tile and K range is whole (the shapes of the 128-aligned layers)
+    auto whole = [&](int M, int N, int Kd) { return M % GB == 0 && N % GB == 0 && Kd % GK == 0; };
+    const bool edge = !(whole(a.M, a.N, a.Kd) && whole(a.M_last, a.N_last, a.Kd_last));
+#define LLMC_SG(TA_, TB_, PH_)                                                                        \
+    do {                                                                                              \
+        if (edge) hipLaunchKernelGGL((k_sgemm<TA_, TB_, PH_, true>), grid, dim3(256), 0, st, a);      \
+        else hipLaunchKernelGGL((k_sgemm<TA_, TB_, PH_, false>), grid, dim3(256), 0, st, a);          \
+    } while (0)
     if (a.phase_len > 0) {
         LLMC_REQUIRE(a.phase_len % GK == 0 && a.epilogue == SG_SUB && !a.a_upper, "sgemm: bad phased configuration");
-        if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false, true>), grid, dim3(256), 0, st, a);
-        else if (!TA && !TB) hipLaunchKernelGGL((k_sgemm<false, false, true>), grid, dim3(256), 0, st, a);
+        if (TA && !TB) LLMC_SG(true, false, true);
+        else if (!TA && !TB) LLMC_SG(false, false, true);
         else { set_last_error_msg("sgemm: phased mode supports op(B) = N only"); return LLMC_ENOTSUP; }
-    } else if (TA && !TB) hipLaunchKernelGGL((k_sgemm<true, false, false>), grid, dim3(256), 0, st, a);
-    else if (!TA && !TB) hipLaunchKernelGGL((k_sgemm<false, false, false>), grid, dim3(256), 0, st, a);
-    else if (TA && TB) hipLaunchKernelGGL((k_sgemm<true, true, false>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_sgemm<false, true, false>), grid, dim3(256), 0, st, a);
+    } else if (TA && !TB) LLMC_SG(true, false, false);
+    else if (!TA && !TB) LLMC_SG(false, false, false);
+    else if (TA && TB) LLMC_SG(true, true, false);
+    else LLMC_SG(false, true, false);
+#undef LLMC_SG
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }

@@ -10,8 +10,10 @@ from llmc_amd import _ffi
 
 def run(M, N, Kd, TA, TB, epi, hints=(0, 0, 0, 0), reps=5, tag=''):
     L = _ffi.lib()
-    A = torch.randn((Kd, M) if TA else (M, Kd), device='cuda')
-    B = torch.randn((N, Kd) if TB else (Kd, N), device='cuda')
+    fill = os.environ.get('FILL', 'randn')   # zeros: how much of the gap to peak is power (DVFS), not the kernel
+    mk = torch.zeros if fill == 'zeros' else torch.randn
+    A = mk((Kd, M) if TA else (M, Kd), device='cuda')
+    B = mk((N, Kd) if TB else (Kd, N), device='cuda')
     C = torch.randn(M, N, device='cuda')
     def go():
         _ffi.check(L.llmc_test_sgemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
@@ -38,3 +40,8 @@ if __name__ == '__main__':
     run(14208, 14208, 128, True, False, 0, (0, 0, 0, 1), tag='chol trailing K=14336 blk0')
     run(128, 14208, 128, True, False, 1, (0, 1, 0, 0), tag='chol panel K=14336 blk0')
     run(8192, 6144, 8192, False, False, 1, (1, 0, 0, 0), tag='trtri top X=A^-1 C')
+    run(2048, 2048, 2048, False, False, 1, (1, 0, 0, 0), tag='trtri K=4096 top X=A^-1 C')
+    run(4096, 9216, 512, False, False, 0, tag='K4 far down grp')
+    run(28672, 3072, 512, False, False, 0, tag='K4 far gate|up grp')
+    run(13312, 13312, 512, True, False, 0, (0, 0, 0, 1), tag='chol far K=14336 grp')
+    run(3072, 3072, 512, True, False, 0, (0, 0, 0, 1), tag='chol far K=4096 grp')
