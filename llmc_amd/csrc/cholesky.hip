@@ -79,6 +79,7 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
 #pragma unroll
     for (int i = 0; i < 32; ++i) a[i] = ehalf ? (i == j ? 1.0f : 0.0f) : S[i * PLD + j];
     bool bad = false;
+#ifdef LLMC_POTRF_LDS_BCAST
     float uprev = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -89,8 +90,6 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
         }
         const float d = rdlane(a[i], i);
         if (!(d > 0.0f)) bad = true;
-        // 1/sqrt(d): hardware rsq (1 ulp) + one Newton step, instead of the correctly rounded sqrt and divide
-        // (about 30 dependent instructions on the pivot chain); nothing downstream needs those last bits
         float rinv = __builtin_amdgcn_rsqf(d);
         rinv = rinv * (1.5f - 0.5f * d * rinv * rinv);
         const float ui = jkeep >= i ? a[i] * rinv : 0.0f;
@@ -105,6 +104,24 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
         }
         uprev = ui;
     }
+#else
+    // multipliers u_ik come from v_readlane (SGPR operands of the fma): no LDS round trip anywhere in the
+    // factorisation. 1/sqrt(d): hardware rsq (1 ulp) + one Newton step instead of the correctly rounded sqrt and
+    // divide (about 30 dependent instructions on the pivot chain); nothing downstream needs those last bits.
+    (void)rowbuf;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float d = rdlane(a[i], i);
+        if (!(d > 0.0f)) bad = true;
+        float rinv = __builtin_amdgcn_rsqf(d);
+        rinv = rinv * (1.5f - 0.5f * d * rinv * rinv);
+        const float ui = jkeep >= i ? a[i] * rinv : 0.0f;
+        a[i] = ui;
+#pragma unroll
+        for (int k = i + 1; k < 32; ++k) a[k] -= rdlane(ui, k) * ui;
+        __builtin_amdgcn_sched_barrier(0);   // keep the readlanes of later pivots from being hoisted (SGPR blow-up)
+    }
+#endif
     if (bad && lane == 0) atomicCAS(info, 0, kglobal + 1);
     if (!ehalf) {
 #pragma unroll

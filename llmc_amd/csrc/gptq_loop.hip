@@ -121,10 +121,12 @@ __device__ __forceinline__ void gptq_steps16(float (&w)[8], const float (&w0)[8]
 //     the scale) and each quotient is the remaining 5 ops of the very sequence hipcc emits for `n / d`
 //     (mul, fma, fma, fma, div_fmas == fma).  That sequence first passes n and d through v_div_scale_f32,
 //     which is the identity when both are "plain" (2^-40 <= |x| < 2^40, see the ISA's scaling rules), and
-//     ends in v_div_fixup_f32, which only acts on zero / inf / nan / denormal operands.  Every step checks
-//     its operands are plain (or n == 0, whose quotient is n); a wave that ever sees anything else discards
-//     its work and redoes the block with the generic path below, so results are bit-identical by
-//     construction, not by argument.
+//     ends in v_div_fixup_f32, which only acts on zero / inf / nan / denormal operands.  Every numerator
+//     of the block is still in registers after the loop (w[] holds each column's value at the time it was
+//     visited, df[] each diff), so ONE check after the 128 steps proves all operands were plain (+0 counts:
+//     the 5-op chain returns +0 for it, like the division); a wave that saw anything else (-0, tiny, huge,
+//     inf, nan) discards its work and redoes the block with the generic path below, so results are
+//     bit-identical by construction, not by argument.
 //   * the broadcast of the current column is a DPP row_newbcast (VALU latency) instead of an LDS swizzle;
 //   * the U row, d and 1/d of a step do not depend on the chain and are read from LDS ahead of it; there is
 //     no control flow inside the 128 steps, the losses are evaluated after the loop.
@@ -139,26 +141,18 @@ __device__ __forceinline__ float rcp_refined(float d) {
 }
 // 2^-40 <= x < 2^40 and x > 0
 __device__ __forceinline__ bool plain_pos(float x) { return (__float_as_uint(x) - 0x2B800000u) < 0x28000000u; }
-// Range tracker for the numerators: lo/hi = min/max over the |n| bit patterns seen (zeros count as plain).
-struct PlainRange {
-    uint32_t lo, hi;
-    __device__ __forceinline__ void init() { lo = 0x2B800000u; hi = 0x2B800000u; }
-    __device__ __forceinline__ void see(float n) {
-        const uint32_t b = __float_as_uint(n) & 0x7fffffffu;
-        const uint32_t c = n == 0.0f ? 0x2B800000u : b;
-        lo = lo < c ? lo : c;
-        hi = hi > c ? hi : c;
-    }
-    __device__ __forceinline__ bool ok() const { return lo >= 0x2B800000u && hi < 0x53800000u; }
-};
-// n / d for plain d > 0 with y = rcp_refined(d) and n plain or zero
+// plain numerator: 2^-40 <= |x| < 2^40, or +0
+__device__ __forceinline__ bool plain_num(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return ((b & 0x7fffffffu) - 0x2B800000u) < 0x28000000u || b == 0u;
+}
+// n / d for plain d > 0 with y = rcp_refined(d) and n a plain numerator: the tail of hipcc's division sequence
 __device__ __forceinline__ float div_plain(float n, float d, float y) {
     const float q0 = n * y;
     const float e1 = fmaf(-d, q0, n);
     const float q1 = fmaf(e1, y, q0);
     const float e2 = fmaf(-d, q1, n);
-    const float q = fmaf(e2, y, q1);
-    return n == 0.0f ? n : q;
+    return fmaf(e2, y, q1);
 }
 
 // One step. (u, dd) were loaded during the previous step; this step loads (un, ddn) for the next one first.
@@ -167,7 +161,7 @@ __device__ __forceinline__ void fast_step(float (&w)[8], float (&er)[8], float (
                                           const float (&zr)[8], const float (&ys)[8],
                                           const float* __restrict__ us, const float2* __restrict__ dtab, int p,
                                           float s_cur, float z_cur, float y_cur, float qmin, float qmax,
-                                          PlainRange& pr, const float (&u)[8], const float2& dd, float (&un)[8],
+                                          const float (&u)[8], const float2& dd, float (&un)[8],
                                           float2& ddn) {
     constexpr int PO = StepIdx<I>::PO, EO = StepIdx<I>::EO;
     if (I + 1 < BS) {
@@ -183,25 +177,33 @@ __device__ __forceinline__ void fast_step(float (&w)[8], float (&er)[8], float (
         y = row_bcast<PO>(ys[EO]);
     }
     const float wi = row_bcast<PO>(w[EO]);
-    pr.see(wi);
     float t = div_plain(wi, s, y);                  // quant_code(): x / s
     t = rintf(t);
     t = t + z;
     const float qc = fminf(fmaxf(t, qmin), qmax);
     const float q = (qc - z) * s;                   // dequant_code()
     const float diff = wi - q;
-    pr.see(diff);
     const float err = div_plain(diff, dd.x, dd.y);
     const bool own = p == PO;
     er[EO] = own ? err : er[EO];
     df[EO] = own ? diff : df[EO];
     // pin the two selects here: left alone, the optimiser turns the 16-deep select chains into a private array
     // indexed by p after the loop, which keeps all 256 err / diff values alive (spills)
-    asm volatile("" : "+v"(er[EO]), "+v"(df[EO]), "+v"(pr.lo), "+v"(pr.hi));
+    asm volatile("" : "+v"(er[EO]), "+v"(df[EO]));
+    // w[e] -= fl(err * u[e]) for e >= EO, two columns per packed instruction where a pair is whole
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    if (EO & 1) {
+        const float tt = err * u[EO];
+        w[EO] = w[EO] - tt;
+    }
 #pragma unroll
-    for (int e = EO; e < 8; ++e) {
-        const float tt = err * u[e];
-        w[e] = w[e] - tt;
+    for (int e = (EO + 1) & ~1; e < 8; e += 2) {
+        const v2f uu = {u[e], u[e + 1]};
+        v2f ww = {w[e], w[e + 1]};
+        const v2f tt = uu * err;
+        ww = ww - tt;
+        w[e] = ww.x;
+        w[e + 1] = ww.y;
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting later steps' loads (register blow-up)
 }
@@ -211,12 +213,12 @@ __device__ __forceinline__ void fast_steps16(float (&w)[8], float (&er)[8], floa
                                              const float (&zr)[8], const float (&ys)[8],
                                              const float* __restrict__ us, const float2* __restrict__ dtab,
                                              int p, float s_cur, float z_cur, float y_cur, float qmin,
-                                             float qmax, PlainRange& pr, float (&ua)[8], float2& da, float (&ub)[8],
+                                             float qmax, float (&ua)[8], float2& da, float (&ub)[8],
                                              float2& db) {
 #define LLMC_FSTEP2(J)                                                                                        \
-    fast_step<I0 + J, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, qmin, qmax, pr, ua, da,  \
+    fast_step<I0 + J, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, qmin, qmax, ua, da, \
                               ub, db);                                                                        \
-    fast_step<I0 + J + 1, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, qmin, qmax, pr, ub,  \
+    fast_step<I0 + J + 1, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, qmin, qmax, ub, \
                                   db, ua, da);
     LLMC_FSTEP2(0) LLMC_FSTEP2(2) LLMC_FSTEP2(4) LLMC_FSTEP2(6) LLMC_FSTEP2(8) LLMC_FSTEP2(10) LLMC_FSTEP2(12)
     LLMC_FSTEP2(14)
@@ -230,8 +232,6 @@ __device__ __forceinline__ bool block_fast(const GptqBlockArgs& a, const float* 
     const int64_t rr = active ? row : a.R - 1;
     float w[8], w0[8], er[8], df[8], sc[8], zr[8], ys[8];
     bool bad = false;
-    PlainRange pr;
-    pr.init();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = p + 16 * e;
@@ -281,14 +281,16 @@ __device__ __forceinline__ bool block_fast(const GptqBlockArgs& a, const float* 
         y_cur = rcp_refined(s_cur);                                                                    \
         bad |= !plain_pos(s_cur);                                                                      \
     }                                                                                                  \
-    fast_steps16<16 * E, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, a.qmin, a.qmax, pr,  \
+    fast_steps16<16 * E, STATIC>(w, er, df, sc, zr, ys, us, dtab, p, s_cur, z_cur, y_cur, a.qmin, a.qmax, \
                                  ua, da, ub, db);                                                      \
     s_grp[E] = s_cur;                                                                                  \
     z_grp[E] = z_cur;
     LLMC_FCHUNK(0) LLMC_FCHUNK(1) LLMC_FCHUNK(2) LLMC_FCHUNK(3) LLMC_FCHUNK(4) LLMC_FCHUNK(5) LLMC_FCHUNK(6)
     LLMC_FCHUNK(7)
 #undef LLMC_FCHUNK
-    if (__any(bad || !pr.ok())) return false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bad |= !plain_num(w[e]) | !plain_num(df[e]);
+    if (__any(bad)) return false;
     if (!active) return true;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

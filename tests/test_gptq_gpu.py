@@ -160,6 +160,41 @@ def test_column_loop_bit_exact_vs_oracle_larger(cfg):
         np.testing.assert_array_equal(z.cpu().numpy(), ref['zeros'])
 
 
+@pytest.mark.parametrize('static_groups', [False, True])
+def test_column_loop_non_plain_operands_fall_back_bit_exact(static_groups):
+    """Operands outside the fast in-block path's "plain" range (-0, denormal, tiny, huge, all-zero rows) make the
+    owning wave redo the block with the generic IEEE-division path: results stay bit-identical to the oracle."""
+    from llmc_amd.compression.quantization.gptq_ops import gptq_quantize
+    R, K, bit, sym, gs = 256, 512, 4, False, 128
+    gen = torch.Generator().manual_seed(77)
+    W = (torch.randn(R, K, generator=gen) * 0.02).numpy()
+    W[0, 5] = -0.0
+    W[1, 130:140] = -0.0
+    W[8, 7] = 1e-42          # denormal
+    W[9, 300] = 1e-30        # below 2^-40
+    W[16, 64] = 1e13         # above 2^40
+    W[24, :] = 0.0           # scale clamps to 1e-5, every diff is +0
+    W[32, 128:256] = 0.0
+    W[40, 200] = np.float32(0.02) * 0 - 0.0
+    X = torch.randn(2 * K, K, generator=gen).double()
+    H = (X.T @ X / K + 0.01 * torch.eye(K, dtype=torch.float64)).numpy()
+    U = np.linalg.cholesky(np.linalg.inv(H)).T.astype(np.float32).copy()
+    qmin, qmax = Q.int_range(bit, sym)
+    scales = zeros = col_group = None
+    ng = K // gs
+    if static_groups:
+        s, z = Q.minmax_qparams(W.reshape(-1, gs), 'f32', sym, qmin, qmax)
+        scales, zeros = s.reshape(R, ng), z.reshape(R, ng)
+        col_group = (np.arange(K) // gs).astype(np.int32)
+    ref = G.weight_transform(W, U, sym, qmin, qmax, gs, static_groups, col_group, scales, zeros)
+    tmp, losses, s, z = gptq_quantize(
+        cu(W), cu(U), sym, qmin, qmax, gs, static_groups,
+        None if col_group is None else torch.from_numpy(col_group).cuda(),
+        None if scales is None else cu(scales), None if zeros is None else cu(zeros))
+    np.testing.assert_array_equal(bits(tmp.cpu().numpy()), bits(ref['tmp']))
+    np.testing.assert_array_equal(bits(losses.cpu().numpy()), bits(ref['losses']))
+
+
 @pytest.mark.parametrize('K', [128, 384, 1000, 4096])
 def test_chol_inv_upper_vs_fp64(K):
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
