@@ -161,6 +161,11 @@ __device__ __forceinline__ void blk_sub(float* __restrict__ C, const pf32x16& ac
     }
 }
 #define PBLK(M, bi, bj) ((M) + (bi) * 32 * PLD + (bj) * 32)
+// Blocks of the inverse V live in the part of S the factor does not use: V(a,b), a < b, in S's block (b,a) below the
+// diagonal; the four diagonal blocks V(a,a) side by side in a 32-row strip Vd. That keeps the kernel at 85 KB of
+// LDS (S 66 KB + strip 16.5 KB) instead of 2 x 66 KB, so it can be co-resident with workgroups of the far-update
+// GEMM running on the helper stream instead of waiting for a CU to drain.
+#define VBLK(a, b) ((a) == (b) ? (Vd + (a) * 32) : PBLK(S, b, a))
 
 // phase stamps for tools/probes/probe_potrf.hip (compiled out of the product build)
 #ifdef LLMC_PROBE_STAMPS
@@ -170,12 +175,12 @@ __device__ long long g_potrf_stamps[32];
 #define LLMC_STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_t ld, int k0, int nb,
+__global__ __launch_bounds__(256, 2) void k_potrf_inv(float* __restrict__ W, int64_t ld, int k0, int nb,
                                                    float* __restrict__ Vout, int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) float plds[];
     float* S = plds;
-    float* V = plds + NB * PLD;
-    float* rowbuf = plds + 2 * NB * PLD;   // 64 floats of wave-private scratch for the 32x32 factor
+    float* Vd = plds + NB * PLD;
+    float* rowbuf = plds + NB * PLD + 32 * PLD;   // 64 floats of wave-private scratch for the 32x32 factor
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,13 +227,13 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
     LLMC_STAMP(1);
     // ---- blocked upper Cholesky over 4 block rows
     for (int kb = 0; kb < 4; ++kb) {
-        if (wv == 0) wave_potrf32_inv(PBLK(S, kb, kb), PBLK(V, kb, kb), rowbuf, lane, k0 + kb * 32, info);
+        if (wv == 0) wave_potrf32_inv(PBLK(S, kb, kb), VBLK(kb, kb), rowbuf, lane, k0 + kb * 32, info);
         __syncthreads();
         LLMC_STAMP(2 + 2 * kb);
         {   // panel: S(kb, jb) = V_kk^T * S(kb, jb)
             const int jb = kb + 1 + wv;
             if (jb < 4) {
-                pf32x16 acc = blk_mm<true>(PBLK(V, kb, kb), PBLK(S, kb, jb), zero, lane);
+                pf32x16 acc = blk_mm<true>(VBLK(kb, kb), PBLK(S, kb, jb), zero, lane);
                 blk_store(PBLK(S, kb, jb), acc, lane, 1.0f);
             }
         }
@@ -251,7 +256,9 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
         for (int q = 0; q < 16; ++q) {
             const int e4 = tid + 256 * q;
             const int i = e4 >> 5, j = (e4 & 31) * 4;
-            const float4 s4 = *reinterpret_cast<const float4*>(S + i * PLD + j);   // strict lower is zero in S
+            // diagonal blocks hold zeros below the diagonal; blocks below it are about to receive parts of V
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((j >> 5) >= (i >> 5)) s4 = *reinterpret_cast<const float4*>(S + i * PLD + j);
             *reinterpret_cast<float4*>(W + (int64_t)(k0 + i) * ld + k0 + j) = s4;
         }
     } else {
@@ -264,25 +271,25 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
     // ---- V = U^-1 by doubling. Level 32 -> 64: pairs (0,1) and (2,3)
     if (wv < 2) {
         const int a = 2 * wv, b = a + 1;
-        pf32x16 x = blk_mm<false>(PBLK(V, a, a), PBLK(S, a, b), zero, lane);   // X = V_aa * U_ab
-        blk_store(PBLK(V, a, b), x, lane, 1.0f);
-        pf32x16 y = blk_mm<false>(PBLK(V, a, b), PBLK(V, b, b), zero, lane);   // Y = X * V_bb
-        blk_store(PBLK(V, a, b), y, lane, -1.0f);
+        pf32x16 x = blk_mm<false>(VBLK(a, a), PBLK(S, a, b), zero, lane);   // X = V_aa * U_ab
+        blk_store(VBLK(a, b), x, lane, 1.0f);
+        pf32x16 y = blk_mm<false>(VBLK(a, b), VBLK(b, b), zero, lane);   // Y = X * V_bb
+        blk_store(VBLK(a, b), y, lane, -1.0f);
     }
     __syncthreads();
     // Level 64 -> 128: X = V[0:64,0:64] * U[0:64,64:128] (into V scratch), then -X * V[64:,64:] (into S scratch)
     {
         const int r = wv >> 1, c = 2 + (wv & 1);
-        pf32x16 x = blk_mm<false>(PBLK(V, r, r), PBLK(S, r, c), zero, lane);
-        if (r == 0) x = blk_mm<false>(PBLK(V, 0, 1), PBLK(S, 1, c), x, lane);
+        pf32x16 x = blk_mm<false>(VBLK(r, r), PBLK(S, r, c), zero, lane);
+        if (r == 0) x = blk_mm<false>(VBLK(0, 1), PBLK(S, 1, c), x, lane);
         __syncthreads();  // everyone has read U[0:64,64:128] from S and the level-1 V blocks
-        blk_store(PBLK(V, r, c), x, lane, 1.0f);
+        blk_store(VBLK(r, c), x, lane, 1.0f);
     }
     __syncthreads();
     {
         const int r = wv >> 1, c = 2 + (wv & 1);
-        pf32x16 y = blk_mm<false>(PBLK(V, r, 2), PBLK(V, 2, c), zero, lane);
-        if (c == 3) y = blk_mm<false>(PBLK(V, r, 3), PBLK(V, 3, 3), y, lane);
+        pf32x16 y = blk_mm<false>(VBLK(r, 2), VBLK(2, c), zero, lane);
+        if (c == 3) y = blk_mm<false>(VBLK(r, 3), VBLK(3, 3), y, lane);
         blk_store(PBLK(S, r, c), y, lane, -1.0f);
     }
     __syncthreads();
@@ -291,14 +298,11 @@ __global__ __launch_bounds__(256) void k_potrf_inv(float* __restrict__ W, int64_
     for (int q = 0; q < 16; ++q) {
         const int e4 = tid + 256 * q;
         const int i = e4 >> 5, j = (e4 & 31) * 4;
-        const float* src = (i < 64 && j >= 64) ? S : V;
+        const int bi = i >> 5, bj = j >> 5;
         float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j + 3 >= i) {   // the 4-column group touches the upper part (blocks below the diagonal hold no data)
-            v4 = *reinterpret_cast<const float4*>(src + i * PLD + j);
-            if (j < i) v4.x = 0.0f;
-            if (j + 1 < i) v4.y = 0.0f;
-            if (j + 2 < i) v4.z = 0.0f;
-        }
+        if (bi == bj) v4 = *reinterpret_cast<const float4*>(Vd + (i & 31) * PLD + j);             // zeros below diag
+        else if (bi < 2 && bj >= 2) v4 = *reinterpret_cast<const float4*>(S + i * PLD + j);       // level-2 result
+        else if (bi < bj) v4 = *reinterpret_cast<const float4*>(S + (bj * 32 + (i & 31)) * PLD + bi * 32 + (j & 31));
         *reinterpret_cast<float4*>(Vout + i * NB + j) = v4;
     }
     LLMC_STAMP(12);
@@ -441,7 +445,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     static bool potrf_attr = false;
     if (!potrf_attr) {
         LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_potrf_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (2 * NB * PLD + 64) * (int)sizeof(float)));
+                                           (NB * PLD + 32 * PLD + 64) * (int)sizeof(float)));
         potrf_attr = true;
     }
 
@@ -464,7 +468,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
             const int b = c0 / NB;
             const int nb = K - c0 < NB ? K - c0 : NB;
             float* Vb = Vbuf + (size_t)b * NB * NB;
-            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (2 * NB * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
+            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (NB * PLD + 32 * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
                                nb, Vb, info_dev);
             LLMC_LAUNCH_CHECK();
             const int nrem = K - c0 - nb;

@@ -24,7 +24,7 @@ int main() {
     float *W, *V; int* info;
     hipMalloc(&W, h.size() * 4); hipMalloc(&V, n * n * 4); hipMalloc(&info, 4);
     hipMemset(info, 0, 4);
-    const size_t lds = (2 * llmc::NB * llmc::PLD + 64) * sizeof(float);
+    const size_t lds = (llmc::NB * llmc::PLD + 32 * llmc::PLD + 64) * sizeof(float);
     hipFuncSetAttribute((const void*)llmc::k_potrf_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     long long st[32];
     for (int it = 0; it < 3; ++it) {
