@@ -134,6 +134,10 @@ size_t llmc_hessian_prep_ws_bytes(int64_t K);
 int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
                       float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream);
 
+/* `W = tmp[:, invperm]` after the column loop (gptq.py:186-188) and any other fp32 column gather:
+ * out[r][j] = in[r][idx[j]], in/out [R, K] fp32 contiguous, K % 4 == 0, K <= 16384, out must not alias in. */
+int llmc_gather_cols(const float* in, int64_t R, int64_t K, const int64_t* idx, float* out, llmc_stream_t stream);
+
 /* gptq.py:172-174: cholesky -> cholesky_inverse -> cholesky(upper). Computes the same upper factor U
  * (H^-1 = U^T U) by one reverse Cholesky H = R R^T (R upper) and one triangular inverse U = R^-1, in
  * fp32. A [K, K] is overwritten by U (strict lower triangle zeroed). info_dev: int32, 0 on success,

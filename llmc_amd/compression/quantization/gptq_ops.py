@@ -28,6 +28,20 @@ def hessian_prep(H, W, perm, percdamp, want_h=True, h_out=None):
     return Hout, Wout
 
 
+def gather_cols(src, idx):
+    """out[:, j] = src[:, idx[j]] for fp32 [R, K] on the GPU (the reference's `tmp[:, invperm]`, gptq.py:186-188)."""
+    _ffi.require_gpu(src, idx)
+    L = _ffi.lib()
+    if src.dtype != torch.float32 or src.dim() != 2:
+        raise ValueError('gather_cols: src must be fp32 [R, K]')
+    src = src.contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty_like(src)
+    _ffi.check(L.llmc_gather_cols(_ffi.ptr(src), src.shape[0], src.shape[1], _ffi.ptr(idx), _ffi.ptr(out),
+                                  _ffi.stream()), 'llmc_gather_cols')
+    return out
+
+
 _chol_ws = {}
 
 

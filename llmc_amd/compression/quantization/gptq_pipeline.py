@@ -81,7 +81,9 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
                                                want_losses=want_losses, blocksize=cfg.blocksize)
     if perm is not None:
         invperm = torch.argsort(perm)
-        tmp = tmp.index_select(1, invperm)                          # gptq.py:188
+        K4 = tmp.shape[1]
+        # gptq.py:188. LDS-staged gather where the shape allows it (K % 4 == 0, K <= 16384)
+        tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= 16384) else tmp.index_select(1, invperm)
     out = []
     r0 = 0
     for r in rows:

@@ -377,9 +377,81 @@ __global__ __launch_bounds__(256) void k_gather_w(const T* __restrict__ W, int64
     }
 }
 
+
+// LDS-staged gathers (K % 4 == 0, K*4 <= 64 KB): a workgroup reads ONE source row contiguously (16-B loads), keeps it
+// in LDS as fp32, and writes the permuted row contiguously (16-B stores) — both HBM streams coalesced; the random
+// access happens in LDS. The element-wise kernels above remain for other shapes.
+template <typename T> __device__ __forceinline__ float4 load4_f32(const T* p);
+template <> __device__ __forceinline__ float4 load4_f32<float>(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+}
+template <> __device__ __forceinline__ float4 load4_f32<f16_t>(const f16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    f16_t h[4];
+    __builtin_memcpy(h, &u, 8);
+    return make_float4(to_f32<f16_t>(h[0]), to_f32<f16_t>(h[1]), to_f32<f16_t>(h[2]), to_f32<f16_t>(h[3]));
+}
+template <> __device__ __forceinline__ float4 load4_f32<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    bf16_t h[4];
+    __builtin_memcpy(h, &u, 8);
+    return make_float4(to_f32<bf16_t>(h[0]), to_f32<bf16_t>(h[1]), to_f32<bf16_t>(h[2]), to_f32<bf16_t>(h[3]));
+}
+
+// MODE 0: out[r][j] = in[r][idx[j]]                                   (column gather)
+// MODE 1: out[r][j] = dead[idx[j]] ? 0 : in[r][idx[j]]                (k_gather_w)
+// MODE 2: out[r][j] = in[idx[r]][idx[j]] + (r == j) * damp            (k_gather_h)
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void k_gather_lds(const T* __restrict__ in, int K, const int64_t* __restrict__ idx,
+                                                   const uint8_t* __restrict__ dead, float percdamp,
+                                                   const float* __restrict__ diag_mean, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float grow[];
+    const int64_t r = blockIdx.x;
+    const int64_t sr = (MODE == 2 && idx) ? idx[r] : r;
+    const T* src = in + sr * K;
+    for (int c = 4 * threadIdx.x; c < K; c += 4 * 512) *reinterpret_cast<float4*>(grow + c) = load4_f32<T>(src + c);
+    __syncthreads();
+    const float damp = MODE == 2 ? percdamp * (*diag_mean) : 0.0f;
+    for (int c = 4 * threadIdx.x; c < K; c += 4 * 512) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t pj = idx ? idx[c + t] : c + t;
+            float x = grow[pj];
+            if (MODE == 1 && dead[pj]) x = 0.0f;
+            if (MODE == 2 && r == c + t) x += damp;
+            v[t] = x;
+        }
+        *reinterpret_cast<float4*>(out + r * K + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <typename T, int MODE>
+static int gather_lds_launch(const T* in, int64_t R, int64_t K, const int64_t* idx, const uint8_t* dead,
+                             float percdamp, const float* diag_mean, float* out, hipStream_t st) {
+    hipLaunchKernelGGL((k_gather_lds<T, MODE>), dim3((unsigned)R), dim3(512), (size_t)K * 4, st, in, (int)K, idx, dead,
+                       percdamp, diag_mean, out);
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+static inline bool gather_lds_ok(int64_t K, const void* in, const void* out, int esz) {
+    return K % 4 == 0 && K * 4 <= 65536 && ((uintptr_t)in % (4 * esz)) == 0 && ((uintptr_t)out & 15) == 0;
+}
+
 }  // namespace llmc
 
 using namespace llmc;
+
+extern "C" int llmc_gather_cols(const float* in, int64_t R, int64_t K, const int64_t* idx, float* out,
+                                llmc_stream_t stream) {
+    LLMC_REQUIRE(in && idx && out && R > 0 && K > 0, "gather_cols: null/empty argument");
+    LLMC_REQUIRE(in != out, "gather_cols: out must not alias in");
+    hipStream_t st = (hipStream_t)stream;
+    if (gather_lds_ok(K, in, out, 4))
+        return gather_lds_launch<float, 0>(in, R, K, idx, nullptr, 0.0f, nullptr, out, st);
+    set_last_error_msg("gather_cols: K must be a multiple of 4 with K <= 16384 and 16-byte aligned rows");
+    return LLMC_ENOTSUP;
+}
 
 extern "C" size_t llmc_hessian_prep_ws_bytes(int64_t K) {
     if (K <= 0) return 0;
@@ -400,9 +472,22 @@ extern "C" int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, in
     LLMC_LAUNCH_CHECK();
     int gx = (int)ceil_div64(K, 256 * 4);
     if (Hout) {
-        hipLaunchKernelGGL(k_gather_h, dim3(gx, (unsigned)K), dim3(256), 0, st, (const float*)H, (int)K, perm,
-                           percdamp, (const float*)diag_mean, Hout);
-        LLMC_LAUNCH_CHECK();
+        if (gather_lds_ok(K, H, Hout, 4)) {
+            int rc = gather_lds_launch<float, 2>(H, K, K, perm, nullptr, percdamp, diag_mean, Hout, st);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_gather_h, dim3(gx, (unsigned)K), dim3(256), 0, st, (const float*)H, (int)K, perm,
+                               percdamp, (const float*)diag_mean, Hout);
+            LLMC_LAUNCH_CHECK();
+        }
+    }
+    if (W && gather_lds_ok(K, W, Wout, wdt == LLMC_F32 ? 4 : 2)) {
+        int rc;
+        if (wdt == LLMC_F16) rc = gather_lds_launch<f16_t, 1>((const f16_t*)W, R, K, perm, dead, 0.0f, nullptr, Wout, st);
+        else if (wdt == LLMC_BF16)
+            rc = gather_lds_launch<bf16_t, 1>((const bf16_t*)W, R, K, perm, dead, 0.0f, nullptr, Wout, st);
+        else rc = gather_lds_launch<float, 1>((const float*)W, R, K, perm, dead, 0.0f, nullptr, Wout, st);
+        return rc;
     }
     // grid.y is limited to 65535: loop over row slabs
     for (int64_t r0 = 0; W && r0 < R; r0 += 32768) {

@@ -195,6 +195,45 @@ def test_column_loop_non_plain_operands_fall_back_bit_exact(static_groups):
     np.testing.assert_array_equal(bits(losses.cpu().numpy()), bits(ref['losses']))
 
 
+@pytest.mark.parametrize('shape', [(37, 128), (300, 4096), (16, 14336)])
+def test_gather_cols_matches_index_select(shape):
+    from llmc_amd.compression.quantization.gptq_ops import gather_cols
+    R, K = shape
+    gen = torch.Generator().manual_seed(K)
+    src = torch.randn(R, K, generator=gen).cuda()
+    idx = torch.randperm(K, generator=gen).cuda()
+    assert torch.equal(gather_cols(src, idx), src.index_select(1, idx))
+
+
+@pytest.mark.parametrize('wdtype', [torch.float16, torch.bfloat16, torch.float32])
+def test_hessian_prep_lds_gather_matches_definition(wdtype):
+    from llmc_amd.compression.quantization.gptq_ops import hessian_prep
+    K, R = 1024, 77
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(2 * K, K, generator=gen)
+    H = (X.T @ X / K).cuda()
+    H[:, 17] = 0
+    H[17, :] = 0
+    H[:, 900] = 0
+    H[900, :] = 0
+    W = torch.randn(R, K, generator=gen).to(wdtype).cuda()
+    perm = torch.randperm(K, generator=gen).cuda()
+    Hd = H.clone()
+    Hp, Wp = hessian_prep(Hd, W, perm, 0.01)
+    Href = H.clone()
+    dead = torch.diagonal(Href) == 0
+    Href[dead, dead] = 1
+    damp = (0.01 * torch.diagonal(Href).double().mean()).float()
+    Wref = W.float().clone()
+    Wref[:, dead] = 0
+    Href = Href[perm][:, perm] + torch.eye(K, device='cuda') * damp
+    assert torch.equal(Wp, Wref[:, perm])
+    assert torch.equal(torch.diagonal(Hd), torch.diagonal(torch.where(torch.eye(K, device='cuda', dtype=torch.bool), torch.where(H == 0, torch.ones_like(H), H), H)))
+    off = ~torch.eye(K, dtype=torch.bool, device='cuda')
+    assert torch.equal(Hp[off], Href[off])
+    assert torch.allclose(torch.diagonal(Hp), torch.diagonal(Href), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize('K', [128, 384, 1000, 4096])
 def test_chol_inv_upper_vs_fp64(K):
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
