@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(SgemmArgs a) {
     float* C = a.C + (int64_t)z * a.sC;
     const bool last = z == a.batch - 1;
     const int M = last ? a.M_last : a.M, N = last ? a.N_last : a.N, Kd = last ? a.Kd_last : a.Kd;
-    const int i0 = blockIdx.y * GB, j0 = blockIdx.x * GB;
+    // b_upper: a tile's K range grows with its column, so columns are dealt heaviest first (shorter tail)
+    const int bx = a.b_upper ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int i0 = blockIdx.y * GB, j0 = bx * GB;
     if (i0 >= M || j0 >= N) return;
     if (a.c_upper_only && j0 + GB <= i0) return;  // tile strictly below the diagonal
 

@@ -26,7 +26,7 @@ def run(M, N, Kd, TA, TB, epi, hints=(0, 0, 0, 0), reps=5, tag=''):
         e0.record(); go(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e-3)
     t = sorted(ts)[len(ts) // 2]
-    fl = 2.0 * M * N * Kd * (0.5 if hints[3] else 1.0)
+    fl = 2.0 * M * N * Kd * (0.5 if (hints[3] or hints[0] or hints[2]) else 1.0)
     print(f'{tag:28s} M={M} N={N} Kd={Kd} TA={int(TA)} TB={int(TB)}: {t*1e6:9.1f} us  {fl/t/1e12:6.1f} TFLOP/s '
           f'({fl/t/157.3e12*100:.0f}% of fp32 MFMA peak), C traffic {2*4*M*N*(0.5 if hints[3] else 1)/t/1e12:.2f} TB/s', flush=True)
 
@@ -40,6 +40,7 @@ if __name__ == '__main__':
     run(14208, 14208, 128, True, False, 0, (0, 0, 0, 1), tag='chol trailing K=14336 blk0')
     run(128, 14208, 128, True, False, 1, (0, 1, 0, 0), tag='chol panel K=14336 blk0')
     run(8192, 6144, 8192, False, False, 1, (1, 0, 0, 0), tag='trtri top X=A^-1 C')
+    run(8192, 6144, 6144, False, False, 2, (0, 0, 1, 0), tag='trtri top Y=-X B^-1')
     run(2048, 2048, 2048, False, False, 1, (1, 0, 0, 0), tag='trtri K=4096 top X=A^-1 C')
     run(4096, 9216, 512, False, False, 0, tag='K4 far down grp')
     run(28672, 3072, 512, False, False, 0, tag='K4 far gate|up grp')
