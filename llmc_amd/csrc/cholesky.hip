@@ -546,6 +546,8 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     const int NBO = 4 * NB;
     SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
     bool pending_side = false;
+    const int x3mode = getenv("LLMC_K3_X3") ? atoi(getenv("LLMC_K3_X3")) : 0;   // experimental (gemm3.hip)
+    const bool use_x3u = x3mode == 1 || x3mode == 2, use_x3 = x3mode == 1 || x3mode == 3;
     for (int k0 = 0; k0 < K; k0 += NBO) {
         const int nbo = K - k0 < NBO ? K - k0 : NBO;
         const int oend = k0 + nbo;
@@ -574,7 +576,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
                 u.C = Wk + (size_t)(c0 + nb) * K + c0 + nb; u.ldc = K;
                 u.M = u.M_last = mrows; u.N = u.N_last = nrem; u.Kd = u.Kd_last = nb;
                 u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
-                rc = sgemm_launch(u, true, false, st);
+                    rc = sgemm_launch(u, true, false, st);
                 if (rc) return rc;
             }
         }
@@ -595,7 +597,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
             u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
             u.M = u.M_last = m1; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
             u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
-            int rc = sgemm_launch(u, true, false, st);
+            int rc = use_x3u ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
             if (rc) return rc;
             const int m2 = nfar - m1;
             if (m2 > 0) {
@@ -607,11 +609,11 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
                 if (side) {
                     rc = fork_to_side(side, st);   // P is final on main at this point
                     if (rc) return rc;
-                    rc = sgemm_launch(v, true, false, side->side);
+                    rc = use_x3 ? gemm3_tn_launch(v, side->side) : sgemm_launch(v, true, false, side->side);
                     if (rc) return rc;
                     pending_side = true;
                 } else {
-                    rc = sgemm_launch(v, true, false, st);
+                    rc = use_x3 ? gemm3_tn_launch(v, st) : sgemm_launch(v, true, false, st);
                     if (rc) return rc;
                 }
             }

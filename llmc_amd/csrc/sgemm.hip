@@ -281,61 +281,20 @@ __global__ __launch_bounds__(256) void k_sgemm_shortk(SgemmArgs a) {
     __shared__ __attribute__((aligned(16))) float As[SKD * SLB];
     __shared__ __attribute__((aligned(16))) float Bs[SKD * SLB];
     const int M = a.M, N = a.N, Kd = a.Kd;
-    const int i0 = blockIdx.y * SB, j0 = blockIdx.x * SB;
-    if (a.c_upper_only && j0 + SB <= i0) return;   // tile strictly below the diagonal
-    int ke = Kd;
-    if (a.a_lower) ke = min(ke, i0 + SB);
+    const int j0 = blockIdx.x * SB;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     constexpr int LA = TA ? SLB : SLT;
-
-    // ---- C tile first (SG_SUB): its latency overlaps the operand loads
     const int col = j0 + wn * 32 + (lane & 31);
-    float cv[16];
-    if (a.epilogue == SG_SUB) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            cv[r] = (row < M && col < N) ? a.C[(int64_t)row * a.ldc + col] : 0.0f;
-        }
-    }
-    // ---- operand panels: 8 + 8 float4 per thread, all issued before the first LDS write
-    float4 va[8], vb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int idx = tid + 256 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (TA) {   // memory [Kd x M]: k = idx >> 4, 4 consecutive rows i
-            const int k = idx >> 4, i = i0 + 4 * (idx & 15);
-            if (k < ke) {
-                const float* p = a.A + (int64_t)k * a.lda + i;
-                if (i + 3 < M) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (i < M) v.x = p[0];
-                    if (i + 1 < M) v.y = p[1];
-                    if (i + 2 < M) v.z = p[2];
-                }
-            }
-        } else {    // memory [M x Kd]: row i = idx >> 5, 4 consecutive k
-            const int i = i0 + (idx >> 5), k = 4 * (idx & 31);
-            if (i < M) {
-                const float* p = a.A + (int64_t)i * a.lda + k;
-                if (k + 3 < ke) v = *reinterpret_cast<const float4*>(p);
-                else {
-                    if (k < ke) v.x = p[0];
-                    if (k + 1 < ke) v.y = p[1];
-                    if (k + 2 < ke) v.z = p[2];
-                }
-            }
-        }
-        va[q] = v;
-    }
+
+    // ---- B panel once per workgroup: 8 float4 per thread, all issued before the first LDS write
+    float4 vb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int idx = tid + 256 * q;
         const int k = idx >> 4, j = j0 + 4 * (idx & 15);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < ke) {
+        if (k < Kd) {
             const float* p = a.B + (int64_t)k * a.ldb + j;
             if (j + 3 < N) v = *reinterpret_cast<const float4*>(p);
             else {
@@ -346,41 +305,93 @@ __global__ __launch_bounds__(256) void k_sgemm_shortk(SgemmArgs a) {
         }
         vb[q] = v;
     }
+    // ---- row tiles of this column block. gridDim.y covers all of them (one iteration each) except for an in-place
+    // product (C aliases B, the panel solve P = V^T P): there ONE workgroup walks the row tiles, so that every row
+    // of B it needs is in LDS before any row of C is written (separate workgroups would race: the tile of rows
+    // 64..127 reads rows 0..63, which the tile of rows 0..63 overwrites).
+    bool first = true;
+    for (int i0 = blockIdx.y * SB; i0 < M; i0 += gridDim.y * SB) {
+        if (a.c_upper_only && j0 + SB <= i0) continue;   // tile strictly below the diagonal (uniform)
+        int ke = Kd;
+        if (a.a_lower) ke = min(ke, i0 + SB);
+        // C tile first (SG_SUB): its latency overlaps the operand loads
+        float cv[16];
+        if (a.epilogue == SG_SUB) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int idx = tid + 256 * q;
-        if (TA) {
-            *reinterpret_cast<float4*>(As + (idx >> 4) * SLB + 4 * (idx & 15)) = va[q];
-        } else {
-            const int i = idx >> 5, k = 4 * (idx & 31);
-            As[(k + 0) * SLT + i] = va[q].x;
-            As[(k + 1) * SLT + i] = va[q].y;
-            As[(k + 2) * SLT + i] = va[q].z;
-            As[(k + 3) * SLT + i] = va[q].w;
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                cv[r] = (row < M && col < N) ? a.C[(int64_t)row * a.ldc + col] : 0.0f;
+            }
         }
-        *reinterpret_cast<float4*>(Bs + (idx >> 4) * SLB + 4 * (idx & 15)) = vb[q];
-    }
-    __syncthreads();
-
-    f32x16 acc;
+        float4 va[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const float* pa = As + (lane >> 5) * LA + wm * 32 + (lane & 31);
-    const float* pb = Bs + (lane >> 5) * SLB + wn * 32 + (lane & 31);
-    const int npair = (ke + 1) >> 1;   // rows >= ke of both panels are zero-filled
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TA) {   // memory [Kd x M]: k = idx >> 4, 4 consecutive rows i
+                const int k = idx >> 4, i = i0 + 4 * (idx & 15);
+                if (k < ke) {
+                    const float* p = a.A + (int64_t)k * a.lda + i;
+                    if (i + 3 < M) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (i < M) v.x = p[0];
+                        if (i + 1 < M) v.y = p[1];
+                        if (i + 2 < M) v.z = p[2];
+                    }
+                }
+            } else {    // memory [M x Kd]: row i = idx >> 5, 4 consecutive k
+                const int i = i0 + (idx >> 5), k = 4 * (idx & 31);
+                if (i < M) {
+                    const float* p = a.A + (int64_t)i * a.lda + k;
+                    if (k + 3 < ke) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (k < ke) v.x = p[0];
+                        if (k + 1 < ke) v.y = p[1];
+                        if (k + 2 < ke) v.z = p[2];
+                    }
+                }
+            }
+            va[q] = v;
+        }
+        if (!first) __syncthreads();   // the previous row tile's MFMAs have read As
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            if (TA) {
+                *reinterpret_cast<float4*>(As + (idx >> 4) * SLB + 4 * (idx & 15)) = va[q];
+            } else {
+                const int i = idx >> 5, k = 4 * (idx & 31);
+                As[(k + 0) * SLT + i] = va[q].x;
+                As[(k + 1) * SLT + i] = va[q].y;
+                As[(k + 2) * SLT + i] = va[q].z;
+                As[(k + 3) * SLT + i] = va[q].w;
+            }
+            if (first) *reinterpret_cast<float4*>(Bs + (idx >> 4) * SLB + 4 * (idx & 15)) = vb[q];
+        }
+        first = false;
+        __syncthreads();
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float* pa = As + (lane >> 5) * LA + wm * 32 + (lane & 31);
+        const float* pb = Bs + (lane >> 5) * SLB + wn * 32 + (lane & 31);
+        const int npair = (ke + 1) >> 1;   // rows >= ke of the A panel are zero-filled
 #pragma unroll 8
-    for (int kk = 0; kk < npair; ++kk)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk * LA], pb[2 * kk * SLB], acc, 0, 0, 0);
+        for (int kk = 0; kk < npair; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk * LA], pb[2 * kk * SLB], acc, 0, 0, 0);
 
-    if (col >= N) return;
+        if (col < N) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        float* pc = a.C + (int64_t)row * a.ldc + col;
-        if (a.epilogue == SG_SUB) *pc = cv[r] - acc[r];
-        else if (a.epilogue == SG_SET) *pc = acc[r];
-        else *pc = -acc[r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                float* pc = a.C + (int64_t)row * a.ldc + col;
+                if (a.epilogue == SG_SUB) *pc = cv[r] - acc[r];
+                else if (a.epilogue == SG_SET) *pc = acc[r];
+                else *pc = -acc[r];
+            }
+        }
     }
 }
 
@@ -391,12 +402,15 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
                  "sgemm: operands must be 16-B aligned with ld % 4 == 0");
     if (!TB && a.batch == 1 && a.Kd <= SKD && !a.a_upper && !a.b_upper && (a.phase_len == 0 || a.phase_len >= a.Kd) &&
         !getenv("LLMC_NO_SHORTK")) {
-        dim3 sgrid((a.N + SB - 1) / SB, (a.M + SB - 1) / SB, 1);
+        const bool in_place = (const void*)a.C == (const void*)a.B;
+        dim3 sgrid((a.N + SB - 1) / SB, in_place ? 1 : (a.M + SB - 1) / SB, 1);
         if (TA) hipLaunchKernelGGL((k_sgemm_shortk<true>), sgrid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_sgemm_shortk<false>), sgrid, dim3(256), 0, st, a);
         LLMC_LAUNCH_CHECK();
         return LLMC_OK;
     }
+    LLMC_REQUIRE((const void*)a.C != (const void*)a.B || (a.M <= GB && a.batch == 1),
+                 "sgemm: in-place C = op(A) B needs a single row tile (M <= 128)");
     dim3 grid((a.N + GB - 1) / GB, (a.M + GB - 1) / GB, a.batch);
     if (a.phase_len == 0 && a.epilogue == SG_SUB && !a.a_upper && !TB) {
         // plain C -= AB: one phase covering the whole K loop, i.e. the C tile is fetched while the first operand

@@ -61,6 +61,34 @@ def test_sgemm_bitwise_chain(shape):
     np.testing.assert_array_equal(bits(C3.cpu().numpy()[:, :N]), bits(-ref))
 
 
+@pytest.mark.parametrize('shape', [(128, 128, 32), (384, 512, 512), (1000, 776, 200), (2048, 2048, 512)])
+def test_gemm3_split_bf16_matches_fp32_accuracy(shape):
+    """C -= A^T B on the 16-bit pipe with 3-term bf16 operands: error vs fp64 within 2x of the exact fp32 chain's."""
+    from llmc_amd import _ffi
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M + Kd)
+    A = (torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    B = (torch.randn(Kd, N, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    C0 = torch.randn(M, N, generator=gen).cuda()
+    L = _ffi.lib()
+    C3 = C0.clone()
+    _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), C3.data_ptr(), A.stride(0), B.stride(0), C3.stride(0),
+                                 M, N, Kd, 0, _ffi.stream()), 'gemm3')
+    C1 = sgemm(A, B, C0.clone(), M, N, Kd, True, False, 0)
+    ref = C0.double() - A.double().T @ B.double()
+    scale = (A.double().abs().T @ B.double().abs()).max()
+    e3 = ((C3.double() - ref).abs().max() / scale).item()
+    e1 = ((C1.double() - ref).abs().max() / scale).item()
+    assert e3 <= max(2 * e1, 2e-7), (e3, e1)
+    # upper tiles only
+    if M == N:
+        Cu = C0.clone()
+        _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), Cu.data_ptr(), A.stride(0), B.stride(0),
+                                     Cu.stride(0), M, N, Kd, 1, _ffi.stream()), 'gemm3')
+        iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
+        assert torch.equal(Cu[iu], C3[iu])
+
+
 def test_sgemm_triangular_hints_do_not_change_bits():
     n = 384
     gen = torch.Generator().manual_seed(1)
@@ -90,6 +118,14 @@ def test_sgemm_shortk_hints_do_not_change_bits():
     full = sgemm(Vd, Xd, torch.zeros(n, 520).cuda(), n, 520, n, True, False, 1)
     hint = sgemm(Vd, Xd, torch.zeros(n, 520).cuda(), n, 520, n, True, False, 1, (0, 1, 0, 0))
     assert torch.equal(full, hint)
+    # the same product in place (C aliases B), as the factorisation's panel solve runs it: one workgroup per column
+    # block walks the row tiles, so no tile can read rows another one has already overwritten
+    for n_cols in (520, 8192):
+        Xb = torch.randn(n, n_cols, generator=gen).cuda()
+        ref = sgemm(Vd, Xb, torch.zeros(n, n_cols).cuda(), n, n_cols, n, True, False, 1, (0, 1, 0, 0))
+        inp = Xb.clone()
+        sgemm(Vd, inp, inp, n, n_cols, n, True, False, 1, (0, 1, 0, 0))
+        assert torch.equal(inp, ref)
     # symmetric update, upper tiles only: tiles that touch j >= i equal the full result, the others are untouched
     P = torch.randn(n, 384, generator=gen).cuda()
     C0 = torch.randn(384, 384, generator=gen).cuda()
