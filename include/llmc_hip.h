@@ -222,14 +222,14 @@ int llmc_clamp_groups(void* W, int dt, int64_t R, int64_t K, int64_t g, const vo
 
 /* ------------------------------------------------------------------------------------------------
  * Test hooks (tests/test_gptq_gpu.py only): the internal fp32-MFMA GEMM used by K3/K4, and the split-bf16 GEMM
- * (C -= A^T B, A [Kd x M], B [Kd x N] fp32, three bf16 terms per operand, six products) used by K3's far updates.
+ * (C (op) op(A) B, TA / epilogue / hints as in llmc_test_sgemm, three bf16 terms per operand, six products) used by K3.
  * C (op) op(A)[M x Kd] . op(B)[Kd x N]; epilogue 0: C -= AB, 1: C = AB, 2: C = -AB.
  * ---------------------------------------------------------------------------------------------- */
 int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M,
                     int N, int Kd, int TA, int TB, int epilogue, int a_upper, int a_lower, int b_upper,
                     int c_upper_only, llmc_stream_t stream);
 int llmc_test_gemm3(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
-                    int Kd, int c_upper_only, llmc_stream_t stream);
+                    int Kd, int TA, int epilogue, int a_upper, int b_upper, int c_upper_only, llmc_stream_t stream);
 
 #ifdef __cplusplus
 }

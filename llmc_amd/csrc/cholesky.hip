@@ -546,8 +546,11 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     const int NBO = 4 * NB;
     SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
     bool pending_side = false;
-    const int x3mode = getenv("LLMC_K3_X3") ? atoi(getenv("LLMC_K3_X3")) : 0;   // experimental (gemm3.hip)
-    const bool use_x3u = x3mode == 1 || x3mode == 2, use_x3 = x3mode == 1 || x3mode == 3;
+    // The large products of K3 (far updates, triangular-inverse levels >= 512) run as split-bf16 products on the 16-bit
+    // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
+    // the fp32 MFMA path.
+    const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
+    const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
     for (int k0 = 0; k0 < K; k0 += NBO) {
         const int nbo = K - k0 < NBO ? K - k0 : NBO;
         const int oend = k0 + nbo;
@@ -642,7 +645,8 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
         x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2_last; x.Kd = x.Kd_last = (int)h;
         x.epilogue = SG_SET; x.a_upper = 1; x.batch = npairs;
-        int rc = sgemm_launch(x, false, false, st);
+        const bool lvl_x3 = use_x3t && h >= 512;   // small levels are latency-bound: the fp32 kernels stay
+        int rc = lvl_x3 ? gemm3_launch(x, false, st) : sgemm_launch(x, false, false, st);
         if (rc) return rc;
         // C = -X B^-1
         SgemmArgs y{};
@@ -651,7 +655,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         y.C = Wk + h; y.ldc = K; y.sC = stride;
         y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2_last; y.Kd = (int)h; y.Kd_last = n2_last;
         y.epilogue = SG_NEG; y.b_upper = 1; y.batch = npairs;
-        rc = sgemm_launch(y, false, false, st);
+        rc = lvl_x3 ? gemm3_launch(y, false, st) : sgemm_launch(y, false, false, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);

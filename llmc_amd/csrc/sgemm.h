@@ -40,5 +40,7 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st);
 // C -= A^T B (A [Kd x M], B [Kd x N], both k-major) on the 16-bit MFMA pipe with three bf16 terms per fp32 operand
 // (gemm3.hip): fp32-level accuracy, NOT the bitwise fma chain above — K3 only.
 int gemm3_tn_launch(const SgemmArgs& a, hipStream_t st);
+// general form: TA as in sgemm_launch, op(B) = N; hints a_upper / a_lower / b_upper / c_upper_only, all epilogues, batch
+int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st);
 
 }  // namespace llmc

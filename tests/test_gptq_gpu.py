@@ -61,32 +61,57 @@ def test_sgemm_bitwise_chain(shape):
     np.testing.assert_array_equal(bits(C3.cpu().numpy()[:, :N]), bits(-ref))
 
 
-@pytest.mark.parametrize('shape', [(128, 128, 32), (384, 512, 512), (1000, 776, 200), (2048, 2048, 512)])
-def test_gemm3_split_bf16_matches_fp32_accuracy(shape):
-    """C -= A^T B on the 16-bit pipe with 3-term bf16 operands: error vs fp64 within 2x of the exact fp32 chain's."""
+def gemm3(A, B, C, M, N, Kd, TA, epi, hints=(0, 0, 0)):
     from llmc_amd import _ffi
+    L = _ffi.lib()
+    _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
+                                 M, N, Kd, int(TA), epi, *hints, _ffi.stream()), 'gemm3')
+    return C
+
+
+@pytest.mark.parametrize('shape', [(128, 128, 32), (384, 512, 512), (1000, 776, 200), (2048, 2048, 512)])
+@pytest.mark.parametrize('TA', [True, False])
+def test_gemm3_split_bf16_matches_fp32_accuracy(shape, TA):
+    """C (op) op(A) B on the 16-bit pipe with 3-term bf16 operands: error vs fp64 within 2x of the exact fp32 chain's."""
     M, N, Kd = shape
     gen = torch.Generator().manual_seed(M + Kd)
-    A = (torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    At = (torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen)))
     B = (torch.randn(Kd, N, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    Kp = (Kd + 3) // 4 * 4
+    if TA:
+        A = At.cuda()
+    else:
+        A = torch.zeros(M, Kp)
+        A[:, :Kd] = At.T
+        A = A.cuda()
     C0 = torch.randn(M, N, generator=gen).cuda()
-    L = _ffi.lib()
-    C3 = C0.clone()
-    _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), C3.data_ptr(), A.stride(0), B.stride(0), C3.stride(0),
-                                 M, N, Kd, 0, _ffi.stream()), 'gemm3')
-    C1 = sgemm(A, B, C0.clone(), M, N, Kd, True, False, 0)
-    ref = C0.double() - A.double().T @ B.double()
-    scale = (A.double().abs().T @ B.double().abs()).max()
-    e3 = ((C3.double() - ref).abs().max() / scale).item()
-    e1 = ((C1.double() - ref).abs().max() / scale).item()
-    assert e3 <= max(2 * e1, 2e-7), (e3, e1)
-    # upper tiles only
-    if M == N:
-        Cu = C0.clone()
-        _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), Cu.data_ptr(), A.stride(0), B.stride(0),
-                                     Cu.stride(0), M, N, Kd, 1, _ffi.stream()), 'gemm3')
+    ref_prod = At.double().T.cuda() @ B.double()
+    scale = (At.double().abs().T.cuda() @ B.double().abs()).max()
+    for epi, ref in ((0, C0.double() - ref_prod), (1, ref_prod), (2, -ref_prod)):
+        C3 = gemm3(A, B, C0.clone(), M, N, Kd, TA, epi)
+        C1 = sgemm(A, B, C0.clone(), M, N, Kd, TA, False, epi)
+        e3 = ((C3.double() - ref).abs().max() / scale).item()
+        e1 = ((C1.double() - ref).abs().max() / scale).item()
+        assert e3 <= max(2 * e1, 2e-7), (epi, e3, e1)
+    if M == N and TA:   # upper tiles only
+        C3 = gemm3(A, B, C0.clone(), M, N, Kd, TA, 0)
+        Cu = gemm3(A, B, C0.clone(), M, N, Kd, TA, 0, (0, 0, 1))
         iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
         assert torch.equal(Cu[iu], C3[iu])
+
+
+def test_gemm3_triangular_hints_do_not_change_results():
+    n = 384
+    gen = torch.Generator().manual_seed(3)
+    A = torch.triu(torch.randn(n, n, generator=gen)).cuda()
+    B = torch.triu(torch.randn(n, n, generator=gen)).cuda()
+    X = torch.randn(n, n, generator=gen).cuda()
+    full = gemm3(A, X, torch.zeros(n, n).cuda(), n, n, n, False, 1)
+    hint = gemm3(A, X, torch.zeros(n, n).cuda(), n, n, n, False, 1, (1, 0, 0))
+    assert torch.equal(full, hint)
+    full = gemm3(X, B, torch.zeros(n, n).cuda(), n, n, n, False, 2)
+    hint = gemm3(X, B, torch.zeros(n, n).cuda(), n, n, n, False, 2, (0, 1, 0))
+    assert torch.equal(full, hint)
 
 
 def test_sgemm_triangular_hints_do_not_change_bits():
