@@ -295,6 +295,24 @@ def test_hessian_prep_lds_gather_matches_definition(wdtype):
     assert torch.allclose(torch.diagonal(Hp), torch.diagonal(Href), rtol=1e-6, atol=0)
 
 
+def test_factor_and_column_loop_are_run_to_run_deterministic():
+    """Helper-stream overlap must not change a single bit between runs (a race would): 4 runs each of the K = 4096
+    factorisation and of a 2048 x 4096 column loop, which both use the look-ahead stream."""
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper, gptq_quantize
+    K = 4096
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    X = torch.randn(2 * K, K, generator=gen, device='cuda')
+    H = X.T @ X / K
+    H += 0.01 * torch.diagonal(H).mean() * torch.eye(K, device='cuda')
+    Us = [chol_inv_upper(H.clone(), check=False).clone() for _ in range(4)]
+    for u in Us[1:]:
+        assert torch.equal(u, Us[0])
+    W = torch.randn(2048, K, generator=gen, device='cuda') * 0.02
+    outs = [gptq_quantize(W.clone(), Us[0], False, 0.0, 15.0, 128) for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
 @pytest.mark.parametrize('K', [128, 384, 1000, 4096])
 def test_chol_inv_upper_vs_fp64(K):
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
