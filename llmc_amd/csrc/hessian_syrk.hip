@@ -18,6 +18,7 @@
 // unit index is XOR-ed with (token & 3) so the four rows land on four different bank quarters. The
 // swizzle is applied to the DMA's per-lane SOURCE address (LDS image stays lane-linear) and to the read.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "mfma_common.h"
 
@@ -86,7 +87,18 @@ struct SyrkArgs {
     unsigned* sync;    // round barrier counter (zeroed before the launch), or null
 };
 
-template <int DT>
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// PH8 = false: one barrier per K-step, the whole next stage is requested at its start and waited for (vmcnt 0) at
+// its end. PH8 = true: the guide's phase-split schedule (cdna_hip_programming.md, "8-phase template") mapped onto this
+// kernel's 64-token K-step: four phases per K-step, one per 16-token slice,
+//     phase p:  request slice p of the NEXT K-step (2 LDS-DMA pieces) | read the 6 fragments of slice p |
+//               counted vmcnt: retire slice p+1 | s_barrier | lgkmcnt(0) | setprio(1) 8 MFMA setprio(0) | s_barrier
+// and the two wave rows (wm = 0 / 1, one wave of each per SIMD) run offset by one barrier, so that one of them is in
+// its MFMA burst while the other issues its reads and requests: the matrix pipe is fed alternately and never waits
+// for a whole stage. A slice is requested a full K-step before it is read and retired (own vmcnt, then a barrier)
+// one phase before it is read; it overwrites LDS last read a full K-step earlier.
+template <int DT, bool PH8>
 __global__ __launch_bounds__(SYRK_THREADS) void k_syrk(SyrkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LDS_AS char* lds = (LDS_AS char*)smem;
@@ -182,9 +194,60 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk(SyrkArgs a) {
             }
         };
 
+        if constexpr (PH8) {
+            const int nks = ks1 - ks0;
+            if (nks > 0) {
+                stage(0, ks0);
+                dma_wait_all();
+                __builtin_amdgcn_s_barrier();
+                if (wm == 1) __builtin_amdgcn_s_barrier();   // offset the second wave row by one barrier
+                for (int i = 0; i < nks; ++i) {
+                    const bool more = i + 1 < nks;
+                    LDS_AS char* pa = lds + (i & 1) * STAGE_BYTES;
+                    LDS_AS char* pb = diag ? pa : pa + PANEL_BYTES;
+                    const uint32_t koff = (uint32_t)((int64_t)(i + 1) * BK * row_bytes);
+                    const uint32_t dst = lds_base + ((i + 1) & 1) * STAGE_BYTES + wv * 1024;
+                    auto phase = [&](auto phc) {
+                        constexpr int ph = decltype(phc)::value;
+                        if (more) {
+                            dma16(rsrc, vA + koff + ph * slab, dst + ph * 8192);
+                            if (!diag) dma16(rsrc, vB + koff + ph * slab, dst + PANEL_BYTES + ph * 8192);
+                        }
+                        s16x8 fa[4], fb[2];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) fa[m] = tr_frag(pa + offA[m], ph * 16 * TM * 2);
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) fb[n] = tr_frag(pb + offB[n], ph * 16 * TM * 2);
+                        // retire slice ph+1 (of this K-step, or slice 0 of the next one): requests issued after it
+                        // may stay in flight — three phases' worth while requests are being issued, fewer at the end
+                        if (more) {
+                            if (diag) vm_wait<3>(); else vm_wait<6>();
+                        } else if (ph < 3) {
+                            if (diag) vm_wait<2 - ph>(); else vm_wait<2 * (2 - ph)>();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n) acc[m][n] = Mfma<DT>::run(fa[m], fb[n], acc[m][n]);
+                        __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                    };
+                    phase(std::integral_constant<int, 0>{});
+                    phase(std::integral_constant<int, 1>{});
+                    phase(std::integral_constant<int, 2>{});
+                    phase(std::integral_constant<int, 3>{});
+                }
+                if (wm == 0) __builtin_amdgcn_s_barrier();   // the first wave row waits for the second one's last phase
+            }
+        }
         int cur = 0;
-        if (ks0 < ks1) stage(0, ks0);
-        for (int ks = ks0; ks < ks1; ++ks) {
+        if (!PH8 && ks0 < ks1) stage(0, ks0);
+        for (int ks = ks0; !PH8 && ks < ks1; ++ks) {
             dma_wait_all();   // this wave's DMA pieces have landed
             __syncthreads();  // everyone's pieces landed; previous stage fully read
             if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);
@@ -515,26 +578,33 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     // k_syrk2 (deeper LDS-DMA ring) measures within 2 % of k_syrk on MI355X (both ~60 % MFMA-busy, clock-limited
     // on random data: profiles/r01_syrk_variants.txt); k_syrk stays the default, LLMC_SYRK_V2=1 selects the ring.
     const bool use_v2 = getenv("LLMC_SYRK_V2") != nullptr;
+    const bool use_ph8 = getenv("LLMC_SYRK_PH8") != nullptr;
     if (dt == LLMC_BF16) {
         if (!attr_set[0]) {
             LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk2<LLMC_BF16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SYRK2_LDS));
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16>,
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16, false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16, true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
             attr_set[0] = true;
         }
         if (use_v2) hipLaunchKernelGGL((k_syrk2<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK2_LDS, st, a);
-        else hipLaunchKernelGGL((k_syrk<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        else if (use_ph8) hipLaunchKernelGGL((k_syrk<LLMC_BF16, true>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        else hipLaunchKernelGGL((k_syrk<LLMC_BF16, false>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
     } else {
         if (!attr_set[1]) {
             LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk2<LLMC_F16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SYRK2_LDS));
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16>,
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16, false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
+            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16, true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
             attr_set[1] = true;
         }
         if (use_v2) hipLaunchKernelGGL((k_syrk2<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK2_LDS, st, a);
-        else hipLaunchKernelGGL((k_syrk<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        else if (use_ph8) hipLaunchKernelGGL((k_syrk<LLMC_F16, true>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        else hipLaunchKernelGGL((k_syrk<LLMC_F16, false>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
     }
     LLMC_LAUNCH_CHECK();
     *nb_o = nb;
