@@ -61,6 +61,14 @@ int llmc_minmax_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, in
                         float qmin, float qmax, void* scales, void* zeros, void* ws,
                         llmc_stream_t stream);
 
+/* calib_algo 'mse': BaseQuantizer.get_mse_range (quant.py:145-203) followed by get_qparams (:545-559) on a [G, g]
+ * view. The reference casts the tensor to fp32 first, so ranges and qparams are fp32 whatever `dt` is:
+ * scales / zeros / min_out / max_out are fp32 [G] (zeros may be NULL when sym, min_out / max_out may be NULL).
+ * nsteps = int(maxshrink * mse_grid) and grid = mse_grid as Python computes them; norm = 2.4 in the reference. */
+int llmc_mse_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, int round_zp, float qmin, float qmax,
+                     int nsteps, int grid, float norm, float* scales, float* zeros, float* min_out, float* max_out,
+                     llmc_stream_t stream);
+
 /* IntegerQuantizer.quant / quant_dequant with given qparams (quant.py:699-717), i.e. the arithmetic of
  * fake_quant_weight_static (quant.py:785-831) and real_quant_weight_static (quant.py:871-914).
  * W: [G, g] dtype wdt. scales [G] dtype sdt. zeros [G] dtype zdt, or NULL (== 0, the symmetric case).

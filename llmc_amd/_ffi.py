@@ -22,6 +22,7 @@ SIGNATURES = {
     'llmc_hip_last_error': (_i32, [C.c_char_p, _sz]),
     'llmc_minmax_qparams_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_minmax_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    'llmc_mse_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     'llmc_quant_static': (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp, _i32, _f32, _f32, _i32, _vp, _vp]),
     'llmc_quant_dynamic_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_quant_dynamic': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -5,7 +5,8 @@ argument meaning, return shapes/dtypes (BaseQuantizer :46-658, IntegerQuantizer 
 FloatQuantizer :963-1229).  In scope: calib_algo 'minmax' (the algorithm of every GPTQ/AWQ/RTN config
 named in BASELINE.json); granularity per_group / per_channel / per_token / per_tensor / per_head;
 FloatQuantizer e4m3 with the qtorch path pinned to torch.float8_e4m3fn's RNE cast.
-Out of scope (raise NotImplementedError): mse / learnable / hist / hqq range search, W48, per_block.
+Also in scope: calib_algo 'mse' (get_mse_range, quant.py:145-203).
+Out of scope (raise NotImplementedError): learnable / hist / hqq range search, W48, per_block.
 
 Tensors must live on the GPU; there is no CPU fallback (see llmc_amd/_ffi.py).
 """
@@ -28,9 +29,13 @@ class BaseQuantizer(object):
         self.kwargs = kwargs
 
         self.calib_algo = self.kwargs.get('calib_algo', 'minmax')
-        if self.calib_algo not in ('minmax', 'static_minmax'):
+        if self.calib_algo not in ('minmax', 'static_minmax', 'mse'):
             raise NotImplementedError(
-                f'calib_algo={self.calib_algo}: only minmax ranges are on the accelerated path')
+                f'calib_algo={self.calib_algo}: only minmax and mse ranges are on the accelerated path')
+        # mse config (quant.py:78-81)
+        self.mse_b_num = self.kwargs.get('mse_b_num', 1)
+        self.maxshrink = self.kwargs.get('maxshrink', 0.8)
+        self.mse_grid = self.kwargs.get('mse_grid', 100)
 
         if self.granularity == 'per_group':
             self.group_size = self.kwargs['group_size']
@@ -86,8 +91,44 @@ class BaseQuantizer(object):
             return ()
         return (*tensor.shape[:-1], 1)
 
+    def _mse_qparams(self, tensor, want_range=False):
+        """get_mse_range + get_qparams (quant.py:145-203, 545-559): fp32 scales / zeros whatever the tensor dtype
+        (the reference searches on tensor.float()). mse_b_num only batches the reference's memory use."""
+        _ffi.require_gpu(tensor)
+        L = _ffi.lib()
+        tensor = tensor.contiguous()
+        G, g = self._geometry(tensor)
+        if self.mse_b_num < 1 or tensor.shape[0] % self.mse_b_num != 0:
+            raise AssertionError('Batch number must be divisible by tensor.shape[0],')
+        dev = tensor.device
+        scales = torch.empty(G, dtype=torch.float32, device=dev)
+        zeros = None if self.sym else torch.empty(G, dtype=torch.float32, device=dev)
+        mn = torch.empty(G, dtype=torch.float32, device=dev) if want_range else None
+        mx = torch.empty(G, dtype=torch.float32, device=dev) if want_range else None
+        _ffi.check(L.llmc_mse_qparams(
+            _ffi.ptr(tensor), _ffi.dt(tensor), G, g, int(self.sym), int(self.round_zp), float(self.qmin),
+            float(self.qmax), int(self.maxshrink * self.mse_grid), int(self.mse_grid), 2.4, _ffi.ptr(scales),
+            _ffi.ptr(zeros), _ffi.ptr(mn), _ffi.ptr(mx), _ffi.stream()), 'llmc_mse_qparams')
+        shp = self._qparam_shape(tensor)
+        scales = scales.reshape(shp)
+        zeros = torch.tensor(0.0) if self.sym else zeros.reshape(shp)
+        if want_range:
+            return scales, zeros, mn.reshape(shp), mx.reshape(shp)
+        return scales, zeros
+
+    def get_tensor_range(self, tensor, args={}):
+        """quant.py:122-130 for the algorithms on the accelerated path: (min_val, max_val)."""
+        if self.calib_algo == 'mse':
+            _, _, mn, mx = self._mse_qparams(tensor, want_range=True)
+            return mn, mx
+        if self.granularity == 'per_tensor':
+            return torch.min(tensor), torch.max(tensor)
+        return tensor.amin(dim=-1, keepdim=True), tensor.amax(dim=-1, keepdim=True)
+
     def _minmax_qparams(self, tensor):
-        """tensor: reshaped, contiguous, on GPU. Returns (scales, zeros) in tensor dtype."""
+        """tensor: reshaped, contiguous, on GPU. Returns (scales, zeros) in tensor dtype (fp32 for calib_algo mse)."""
+        if self.calib_algo == 'mse':
+            return self._mse_qparams(tensor)
         _ffi.require_gpu(tensor)
         L = _ffi.lib()
         tensor = tensor.contiguous()
@@ -191,6 +232,13 @@ class IntegerQuantizer(BaseQuantizer):
     # ---- dynamic (fused min/max + quant) -----------------------------------------------------------
     def _dynamic(self, tensor, out_kind, want_qparams):
         _ffi.require_gpu(tensor)
+        if self.calib_algo == 'mse':   # searched range first, then the static arithmetic with its fp32 qparams
+            tensor = tensor.contiguous()
+            scales, zeros = self._mse_qparams(tensor)
+            out = self._static(tensor, scales, zeros, self.qmax, self.qmin, out_kind)
+            if not want_qparams:
+                return out, None, None
+            return out, scales.reshape(-1), None if self.sym else zeros.reshape(-1)
         L = _ffi.lib()
         tensor = tensor.contiguous()
         G, g = self._geometry(tensor)

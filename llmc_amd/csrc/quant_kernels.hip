@@ -471,6 +471,84 @@ extern "C" int llmc_minmax_qparams(const void* W, int dt, int64_t G, int64_t g, 
     }
 }
 
+
+// calib_algo = 'mse' (BaseQuantizer.get_mse_range, quant.py:145-203) + get_qparams on the searched range.
+// One wave per row of the [G, g] view. The reference works on tensor.float(): ranges, qparams and the fake-quant are
+// fp32. Its candidate ranges COMPOUND: best_min_val aliases _min_val, so after an improvement at step i the next
+// candidate is p_{i+1} times the already shrunk range (oracle/quant_ref.py:mse_range pins this against the goldens).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mse_qparams(const T* __restrict__ W, int64_t G, int g, int sym,
+                                                        int round_zp, float qmin, float qmax, int nsteps, int grid,
+                                                        float norm, float* __restrict__ scales,
+                                                        float* __restrict__ zeros, float* __restrict__ min_out,
+                                                        float* __restrict__ max_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t row = wave; row < G; row += nwaves) {
+        const T* w = W + row * g;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int c = lane; c < g; c += 64) {
+            const float x = to_f32<T>(w[c]);
+            mn = fminf(mn, x);
+            mx = fmaxf(mx, x);
+        }
+        float cur_min = wave_min(mn, 64), cur_max = wave_max(mx, 64);
+        float best = INFINITY;
+        for (int i = 0; i < nsteps; ++i) {
+            const float p = (float)(1.0 - (double)i / (double)grid);   // python float -> fp32 scalar operand
+            const float xmin = p * cur_min, xmax = p * cur_max;
+            const QParams q = qparams_from_minmax(xmin, xmax, LLMC_F32, sym, round_zp, qmin, qmax);
+            float acc = 0.0f;
+            for (int c = lane; c < g; c += 64) {
+                const float x = to_f32<T>(w[c]);
+                const float code = quant_code(x, q.s, q.z, LLMC_F32, LLMC_F32, qmin, qmax);
+                const float d = fabsf(dequant_code(code, q.s, q.z, LLMC_F32) - x);
+                acc += powf(d, norm);
+            }
+            const float err = wave_sum(acc, 64);
+            if (err < best) {
+                best = err;
+                cur_min = xmin;
+                cur_max = xmax;
+            }
+        }
+        if (lane == 0) {
+            const QParams q = qparams_from_minmax(cur_min, cur_max, LLMC_F32, sym, round_zp, qmin, qmax);
+            scales[row] = q.s;
+            if (zeros) zeros[row] = q.z;
+            if (min_out) min_out[row] = cur_min;
+            if (max_out) max_out[row] = cur_max;
+        }
+    }
+}
+
+extern "C" int llmc_mse_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, int round_zp, float qmin,
+                                float qmax, int nsteps, int grid, float norm, float* scales, float* zeros,
+                                float* min_out, float* max_out, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(dt), "mse_qparams: bad dtype");
+    LLMC_REQUIRE(W && scales && G > 0 && g > 0 && g < (1ll << 31), "mse_qparams: null/empty argument");
+    LLMC_REQUIRE(sym || zeros, "mse_qparams: zeros required for asymmetric");
+    LLMC_REQUIRE(nsteps >= 1 && grid >= 1, "mse_qparams: nsteps and grid must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = grid_for(G, kBlock / 64);
+    switch (dt) {
+        case LLMC_F16:
+            hipLaunchKernelGGL((k_mse_qparams<f16_t>), dim3(nblk), dim3(kBlock), 0, st, (const f16_t*)W, G, (int)g, sym,
+                               round_zp, qmin, qmax, nsteps, grid, norm, scales, zeros, min_out, max_out);
+            break;
+        case LLMC_BF16:
+            hipLaunchKernelGGL((k_mse_qparams<bf16_t>), dim3(nblk), dim3(kBlock), 0, st, (const bf16_t*)W, G, (int)g, sym,
+                               round_zp, qmin, qmax, nsteps, grid, norm, scales, zeros, min_out, max_out);
+            break;
+        default:
+            hipLaunchKernelGGL((k_mse_qparams<float>), dim3(nblk), dim3(kBlock), 0, st, (const float*)W, G, (int)g, sym,
+                               round_zp, qmin, qmax, nsteps, grid, norm, scales, zeros, min_out, max_out);
+    }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
 template <typename T, int KIND>
 static int quant_static_tk(const void* W, int64_t G, int64_t g, const void* scales, int sdt,
                            const void* zeros, int zdt, float qmin, float qmax, void* out, hipStream_t st) {

@@ -526,7 +526,42 @@ def suite_e2e():
     save('e2e', **out)
 
 
-SUITES = {'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+
+def suite_mse():
+    """calib_algo='mse' weight ranges (quant.py:145-203): the searched (min, max) per row/group and the qparams and
+    fake-quantized weights that follow from them."""
+    gen = torch.Generator().manual_seed(4321)
+    out = {}
+    cases = []
+    for dt in ('f16', 'bf16', 'f32'):
+        for (bit, sym, gran, gs) in [(4, False, 'per_group', 128), (4, True, 'per_group', 128),
+                                     (8, True, 'per_channel', None), (3, False, 'per_group', 64)]:
+            cases.append((dt, bit, sym, gran, gs))
+    for ci, (dt, bit, sym, gran, gs) in enumerate(cases):
+        kw = dict(group_size=gs) if gs else {}
+        q = IntegerQuantizer(bit, sym, gran, calib_algo='mse', **kw)
+        w = rand_weight(gen, 24, 512, dt)
+        t = q.reshape_tensor(w)
+        mn0, mx0 = q.get_minmax_range(t.float())
+        mn, mx = q.get_tensor_range(t.clone())
+        _, s, z, qmax, qmin = q.get_tensor_qparams(w)
+        fq = q.fake_quant_weight_dynamic(w)
+        p = f'c{ci}_'
+        out[p + 'w'] = f32(w)
+        out[p + 'min0'] = f32(mn0).reshape(-1)
+        out[p + 'max0'] = f32(mx0).reshape(-1)
+        out[p + 'min'] = f32(mn).reshape(-1)
+        out[p + 'max'] = f32(mx).reshape(-1)
+        out[p + 'scales'] = f32(s).reshape(-1)
+        out[p + 'scales_dtype'] = np.array(str(s.dtype))
+        out[p + 'zeros'] = f32(z).reshape(-1) if z.dim() > 0 else np.zeros(0, np.float32)
+        out[p + 'fake'] = f32(fq)
+        out[p + 'fake_dtype'] = np.array(str(fq.dtype))
+        out[p + 'meta'] = np.array([bit, int(sym), gs or 0, float(qmin), float(qmax)], dtype=np.float64)
+    out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
+    save('mse', **out)
+
+SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e}
 
 if __name__ == '__main__':

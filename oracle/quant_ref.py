@@ -228,3 +228,29 @@ def fp8_fake(w2d, dt):
     """fake_quant_weight_dynamic: (q - 0) * s is an fp32 product, then .to(dt)  (quant.py:1074-1080, 1165-1176)."""
     bits, s, _ = fp8_quant(w2d, dt)
     return rnd(e4m3fn_bits_to_f32(bits) * s, dt)
+
+
+def mse_range(x, sym, qmin, qmax, round_zp=True, maxshrink=0.8, grid=100, norm=2.4):
+    """quant.py:145-203 (get_mse_range) on the fp32 [G, g] view `x` (the reference casts to float first).
+    NOTE the reference's aliasing: `best_min_val` IS `_min_val` (a view of `min_val`), so a row that improves at step i
+    continues the search from its already shrunk range: xmin_i = p_i * current_min, not p_i * original_min.
+    Returns (min_val, max_val) fp32 [G]. |q - x| ** norm and the row sum are fp32 like torch's; their last bits depend on
+    the pow / summation implementation, so the argmin can differ from the reference on near-ties only."""
+    x = np.asarray(x, dtype=np.float32)
+    cur_min = x.min(axis=1).astype(np.float32)
+    cur_max = x.max(axis=1).astype(np.float32)
+    best = np.full(x.shape[0], np.inf, dtype=np.float32)
+    for i in range(int(maxshrink * grid)):
+        p = np.float32(1 - i / grid)           # python float -> fp32 scalar of a fp32 tensor op
+        xmin = (p * cur_min).astype(np.float32)
+        xmax = (p * cur_max).astype(np.float32)
+        s, z = qparams_from_minmax(xmin, xmax, F32, sym, qmin, qmax, round_zp)
+        codes, p2 = quant_codes(x, F32, s[:, None], F32, z[:, None], F32, qmin, qmax)
+        q = dequant(codes, s[:, None], z[:, None], p2)
+        d = np.abs((q - x).astype(np.float32))
+        err = np.power(d, np.float32(norm), dtype=np.float32).sum(axis=1, dtype=np.float32)
+        better = err < best
+        best = np.where(better, err, best)
+        cur_min = np.where(better, xmin, cur_min)
+        cur_max = np.where(better, xmax, cur_max)
+    return cur_min, cur_max

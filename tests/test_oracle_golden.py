@@ -54,6 +54,30 @@ def test_quant_static_mixed_dtypes_bit_exact():
         np.testing.assert_array_equal(codes.reshape(w.shape).astype(np.int32), g[p + 'codes'])
 
 
+def test_mse_range_search_bit_exact():
+    """calib_algo='mse' (quant.py:145-203): the oracle reproduces the reference's searched ranges — including its
+    compounding-shrink aliasing — its fp32 qparams and the fake-quantized weights on every golden row."""
+    g = load_golden('mse')
+    for ci, c in enumerate(g['cases']):
+        dt, bit, sym, gran, gs = str(c).split('|')
+        sym, gs = sym == 'True', (None if gs == 'None' else int(gs))
+        p = f'c{ci}_'
+        _, _, _, qmin, qmax = g[p + 'meta']
+        w = g[p + 'w']
+        x = _rows(w, gran, gs)
+        mn, mx = Q.mse_range(x, sym, qmin, qmax)
+        np.testing.assert_array_equal(mn.view(np.uint32), g[p + 'min'].view(np.uint32), err_msg=str(c))
+        np.testing.assert_array_equal(mx.view(np.uint32), g[p + 'max'].view(np.uint32), err_msg=str(c))
+        assert (g[p + 'min'] != g[p + 'min0']).any()          # the search moved ranges, the fixture is not trivial
+        s, z = Q.qparams_from_minmax(mn, mx, Q.F32, sym, qmin, qmax)
+        assert str(g[p + 'scales_dtype']) == 'torch.float32'
+        np.testing.assert_array_equal(s.view(np.uint32), g[p + 'scales'].view(np.uint32), err_msg=str(c))
+        if not sym:
+            np.testing.assert_array_equal(z, g[p + 'zeros'], err_msg=str(c))
+        fq = Q.fake_quant_static(x, dt, s[:, None], Q.F32, None if sym else z[:, None], None if sym else Q.F32, qmin, qmax)
+        np.testing.assert_array_equal(fq.reshape(w.shape).view(np.uint32), g[p + 'fake'].view(np.uint32), err_msg=str(c))
+
+
 def test_pack_vllm_bit_exact():
     g = load_golden('pack')
     for ci in range(int(g['n_vllm'])):
