@@ -62,8 +62,10 @@ def test_quantizer_ranges_and_views_without_gpu():
     assert q.restore_tensor(q.reshape_tensor(t), t.shape).shape == t.shape
     with pytest.raises(ValueError):
         q.reshape_tensor(torch.zeros(2, 100))
+    qm = Q.IntegerQuantizer(4, True, 'per_group', group_size=64, calib_algo='mse')
+    assert (qm.maxshrink, qm.mse_grid, qm.mse_b_num) == (0.8, 100, 1)
     with pytest.raises(NotImplementedError):
-        Q.IntegerQuantizer(4, True, 'per_group', group_size=64, calib_algo='mse')
+        Q.IntegerQuantizer(4, True, 'per_group', group_size=64, calib_algo='hist')
     f = Q.FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True)
     assert float(f.qmax) == 448.0
 
