@@ -31,6 +31,8 @@ class Awq(BaseBlockwiseQuantization):
         self.save_mem = special.get('save_mem', True)
         if not self.w_only:
             raise NotImplementedError('Awq with activation quantization is outside the hot path')
+        if self.wquantizer.calib_algo != 'minmax':
+            raise NotImplementedError('Awq: the fused scale/clip search kernels take min/max ranges (calib_algo=minmax)')
 
     @torch.no_grad()
     def get_weight_scale(self, layers_dict):

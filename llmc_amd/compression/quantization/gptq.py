@@ -47,6 +47,10 @@ class GPTQ(BaseBlockwiseQuantization):
         if special.get('owq', False):
             raise NotImplementedError('OWQ is outside the hot path')
         self.owq = False
+        if self.wquantizer.calib_algo == 'mse' and not self.static_groups and self.wquantizer.granularity == 'per_group':
+            # the column loop's kernel takes the qparams of a group from min/max of the current weights; searched
+            # ranges inside the loop are not on the accelerated path (static_groups / per-channel use the quantizer)
+            raise NotImplementedError('GPTQ with calib_algo=mse needs static_groups (or per_channel weights)')
         self.need_perm = (self.wquantizer.granularity == 'per_group' and not self.static_groups and self.actorder)
         gs = self.wquantizer.group_size if self.wquantizer.granularity == 'per_group' else 0
         self.gcfg = GptqConfig(bit=self.wquantizer.bit, symmetric=self.wquantizer.sym, group_size=gs,
