@@ -32,6 +32,24 @@ template <int DT> __device__ __forceinline__ float rfast(float v) {
     }
 }
 
+// round four fp32 values to DT and back (bf16: two v_cvt_pk_bf16_f32 + shifts/masks instead of 16 integer ops)
+template <int DT> __device__ __forceinline__ void rfast4(float (&v)[4]) {
+    if constexpr (DT == LLMC_BF16) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 a = {v[0], v[1]}, b = {v[2], v[3]};
+        const uint32_t pa = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2));
+        const uint32_t pb = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf2));
+        v[0] = __uint_as_float(pa << 16);
+        v[1] = __uint_as_float(pa & 0xffff0000u);
+        v[2] = __uint_as_float(pb << 16);
+        v[3] = __uint_as_float(pb & 0xffff0000u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rfast<DT>(v[j]);
+    }
+}
+
 struct ClipArgs {
     const void* W;   // [R, K]
     const void* X;   // [n_tok, K]
@@ -96,11 +114,15 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
                 mytab[(s + 1) * CG + lane + 64] = v1 ? q1 : 0.f;
             }
             // ---- outputs of every candidate for this tile's tokens, 4 tokens per lane, 256 per pass
+            // every loop over candidates is fully unrolled with a uniform guard: indexing acc / esum with a runtime
+            // candidate index put them in scratch memory (5x slower)
             float esum[CMAXS];
+#pragma unroll
             for (int s = 0; s < CMAXS; ++s) esum[s] = 0.f;
             for (int tb = 0; tb < nt; tb += 256) {
                 float acc[CMAXS][4];
-                for (int s = 0; s <= ns; ++s)
+#pragma unroll
+                for (int s = 0; s < CMAXS; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[s][j] = 0.f;
                 const int tl = tb + lane * 4;
@@ -108,26 +130,39 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
                     float xv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[j] = to_f32<T>(xt[k * CTOK + tl + j]);
-                    for (int s = 0; s <= ns; ++s) {
-                        const float wv_ = mytab[s * CG + k];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[s][j] += rfast<DT>(xv[j] * wv_);
+                    for (int s = 0; s < CMAXS; ++s) {
+                        if (s <= ns) {
+                            const float wv_ = mytab[s * CG + k];
+                            float pr[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pr[j] = xv[j] * wv_;
+                            rfast4<DT>(pr);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[s][j] += pr[j];
+                        }
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (tl + j < nt) {
                         const float o0 = rfast<DT>(acc[0][j]);
-                        for (int s = 1; s <= ns; ++s) {
-                            const float d = rfast<DT>(rfast<DT>(acc[s][j]) - o0);
-                            esum[s] += rfast<DT>(d * d);
+#pragma unroll
+                        for (int s = 1; s < CMAXS; ++s) {
+                            if (s <= ns) {
+                                const float d = rfast<DT>(rfast<DT>(acc[s][j]) - o0);
+                                esum[s] += rfast<DT>(d * d);
+                            }
                         }
                     }
                 }
             }
-            for (int s = 1; s <= ns; ++s) {
-                const float tot = wave_sum(esum[s], 64);
-                if (lane == 0) esum_all[rr * CMAXS + s] += tot;
+#pragma unroll
+            for (int s = 1; s < CMAXS; ++s) {
+                if (s <= ns) {
+                    const float tot = wave_sum(esum[s], 64);
+                    if (lane == 0) esum_all[rr * CMAXS + s] += tot;
+                }
             }
         }
     }
