@@ -313,6 +313,30 @@ def test_factor_and_column_loop_are_run_to_run_deterministic():
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
+def test_split_bf16_factor_is_as_accurate_as_fp32_on_outlier_channels(monkeypatch):
+    """K3's large products run as split-bf16 by default; on a Hessian with 100x outlier channels (condition number
+    ~1e6 after damping) its factor must be as close to the fp64 factor as the all-fp32-MFMA path's (LLMC_K3_FP32=1)."""
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
+    K = 2048
+    gen = torch.Generator().manual_seed(5)
+    c = torch.exp(0.5 * torch.randn(K, generator=gen, dtype=torch.float64))
+    c[torch.randperm(K, generator=gen)[:8]] *= 100
+    X = torch.randn(3 * K, K, generator=gen, dtype=torch.float64) * c
+    H = (X.T @ X) * (2.0 / 3)
+    H = H[torch.argsort(torch.diagonal(H), descending=True)][:, torch.argsort(torch.diagonal(H), descending=True)]
+    H += 0.01 * H.diag().mean() * torch.eye(K, dtype=torch.float64)
+    Hd = H.float().cuda()
+    Uref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd.double().cpu())), upper=True)
+    monkeypatch.delenv('LLMC_K3_FP32', raising=False)
+    U3 = chol_inv_upper(Hd.clone()).double().cpu()
+    monkeypatch.setenv('LLMC_K3_FP32', '1')
+    U1 = chol_inv_upper(Hd.clone()).double().cpu()
+    e3 = ((U3 - Uref).abs().max() / Uref.abs().max()).item()
+    e1 = ((U1 - Uref).abs().max() / Uref.abs().max()).item()
+    assert not torch.equal(U3, U1)          # the two paths really are different arithmetic
+    assert e3 <= max(2 * e1, 1e-6), (e3, e1)
+
+
 @pytest.mark.parametrize('K', [128, 384, 1000, 4096])
 def test_chol_inv_upper_vs_fp64(K):
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
