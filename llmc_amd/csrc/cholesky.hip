@@ -61,76 +61,61 @@ __device__ __forceinline__ float rdlane(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// wave-level: factor the 32x32 block at S (upper Cholesky, in place, strict lower zeroed) and write its
-// inverse to V. Lanes 0..31 own the columns of the block; lanes 32..63 own the columns of an identity that
-// receives the SAME row operations (scale row i by 1/u_ii, subtract u_ik * row i from row k): the operations
-// that turn A into U turn I into U^-T, so the inverse costs no instruction beyond the factorisation's own.
-// The serial recurrence pivot -> rsq -> row scale -> next pivot is kept short: row i updates row i+1 EAGERLY
-// with one v_readlane multiplier, while its update of the rows below is applied one step LATER from a copy of the
-// row published in LDS (broadcast reads), off the critical path (look-ahead of depth one inside the wave).
+// wave-level: factor the 32x32 block at S (upper Cholesky, in place, strict lower zeroed) and write its inverse to V.
+// An identity carried next to the block receives the SAME row operations (scale row i by 1/u_ii, subtract u_ik * row i
+// from row k): the operations that turn A into U turn I into U^-T, so the inverse needs no back-substitution pass.
+// 1/sqrt(d) is the hardware rsq (1 ulp) + one Newton step instead of the correctly rounded sqrt and divide (about 30
+// dependent instructions on the pivot chain); nothing downstream needs those last bits. (Earlier variants kept the
+// block in 32 registers per lane with v_readlane / LDS-broadcast multipliers; see the git history.)
+//
+// On the matrix pipe: the 32x32 block and the identity live in two MFMA accumulators
+// (C layout: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31), and the rank-1 update of pivot i,
+// rows k > i of [A | I] -= u_ik * (scaled row i), is ONE v_mfma_f32_32x32x2_f32 per accumulator: the scaled row sits in
+// the 32 lanes of one half-wave, which is exactly where the MFMA takes both its row-indexed multipliers (A operand,
+// masked to rows > i) and its column-indexed row vector (B operand) for k-slot `half`; the other k-slot is fed zeros.
+// No cross-lane traffic besides the pivot's v_readlane; 2 x 64 matrix-pipe cycles per pivot instead of ~2 x 31
+// readlane + fma pairs.
 __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* __restrict__ V,
                                                  float* __restrict__ rowbuf, int lane, int kglobal,
                                                  int* __restrict__ info) {
 #pragma clang fp contract(fast)
-    const int j = lane & 31;
-    const bool ehalf = lane >= 32;
-    const int jkeep = ehalf ? 32 : j;   // column j of A keeps row i only for j >= i; the identity half keeps all
-    float a[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) a[i] = ehalf ? (i == j ? 1.0f : 0.0f) : S[i * PLD + j];
-    bool bad = false;
-#ifdef LLMC_POTRF_LDS_BCAST
-    float uprev = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if (i >= 1) {   // lazy part of row i-1's update: rows i+1.. (row i received it eagerly)
-            const float* rb = rowbuf + ((i - 1) & 1) * 32;
-#pragma unroll
-            for (int k = i + 1; k < 32; ++k) a[k] -= rb[k] * uprev;
-        }
-        const float d = rdlane(a[i], i);
-        if (!(d > 0.0f)) bad = true;
-        float rinv = __builtin_amdgcn_rsqf(d);
-        rinv = rinv * (1.5f - 0.5f * d * rinv * rinv);
-        const float ui = jkeep >= i ? a[i] * rinv : 0.0f;
-        a[i] = ui;
-        if (lane < 32) rowbuf[(i & 1) * 32 + j] = ui;   // publish row i of U for the lazy update of step i+1
-        // compiler-only ordering point: without it hipcc moves the broadcast reads of the double-buffered row
-        // across these writes (observed: wrong inverse), although the wave's LDS accesses execute in order
-        asm volatile("" ::: "memory");
-        if (i + 1 < 32) {                               // eager: row i+1
-            const float t = rdlane(ui, i + 1);
-            a[i + 1] -= t * ui;
-        }
-        uprev = ui;
-    }
-#else
-    // multipliers u_ik come from v_readlane (SGPR operands of the fma): no LDS round trip anywhere in the
-    // factorisation. 1/sqrt(d): hardware rsq (1 ulp) + one Newton step instead of the correctly rounded sqrt and
-    // divide (about 30 dependent instructions on the pivot chain); nothing downstream needs those last bits.
     (void)rowbuf;
+    typedef __attribute__((ext_vector_type(16))) float acc16;
+    const int j = lane & 31, h = lane >> 5;
+    acc16 A, E;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        A[r] = S[row * PLD + j];
+        E[r] = row == j ? 1.0f : 0.0f;
+    }
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-        const float d = rdlane(a[i], i);
+        const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;   // register and half-wave holding row i
+        const float d = rdlane(A[ri], hi * 32 + i);
         if (!(d > 0.0f)) bad = true;
         float rinv = __builtin_amdgcn_rsqf(d);
         rinv = rinv * (1.5f - 0.5f * d * rinv * rinv);
-        const float ui = jkeep >= i ? a[i] * rinv : 0.0f;
-        a[i] = ui;
-#pragma unroll
-        for (int k = i + 1; k < 32; ++k) a[k] -= rdlane(ui, k) * ui;
-        __builtin_amdgcn_sched_barrier(0);   // keep the readlanes of later pivots from being hoisted (SGPR blow-up)
+        const bool mine = h == hi;
+        const float va = (mine && j >= i) ? A[ri] * rinv : 0.0f;   // scaled row i of A (upper part), other half 0
+        const float ve = mine ? E[ri] * rinv : 0.0f;               // scaled row i of the identity half
+        A[ri] = mine ? va : A[ri];
+        E[ri] = mine ? ve : E[ri];
+        const float mult = (mine && j > i) ? -va : 0.0f;           // -u_ik as the multiplier of row k = j, k > i
+        A = __builtin_amdgcn_mfma_f32_32x32x2f32(mult, va, A, 0, 0, 0);
+        E = __builtin_amdgcn_mfma_f32_32x32x2f32(mult, ve, E, 0, 0, 0);
     }
-#endif
     if (bad && lane == 0) atomicCAS(info, 0, kglobal + 1);
-    if (!ehalf) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) S[i * PLD + j] = a[i];
-    } else {   // a[i] = (U^-T)[i][j] = V[j][i]: this lane holds row j of V
-#pragma unroll
-        for (int i = 0; i < 32; i += 4)
-            *reinterpret_cast<float4*>(V + j * PLD + i) = make_float4(a[i], a[i + 1], a[i + 2], a[i + 3]);
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        S[row * PLD + j] = j >= row ? A[r] : 0.0f;
     }
+    // E = U^-T: E[row][j] = V[j][row]; four consecutive rows per register quad -> one 16-B store
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(V + j * PLD + 8 * q + 4 * h) = make_float4(E[4 * q], E[4 * q + 1], E[4 * q + 2], E[4 * q + 3]);
 }
 
 // 32x32x32 block product on the f32 MFMA: acc += op(A) * B, op(A)[i][k] = TA ? A[k][i] : A[i][k]

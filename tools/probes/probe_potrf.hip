@@ -2,7 +2,7 @@
 // Build (from the repo root):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
 //     -DLLMC_PROBE_STAMPS -Iinclude -Illmc_amd/csrc tools/probes/probe_potrf.hip llmc_amd/csrc/sgemm.hip \
-//     llmc_amd/csrc/abi.hip -o tools/probes/probe_potrf
+//     llmc_amd/csrc/abi.hip llmc_amd/csrc/gemm3.hip -o tools/probes/probe_potrf
 #include "../../llmc_amd/csrc/cholesky.hip"
 #include <stdio.h>
 #include <math.h>
