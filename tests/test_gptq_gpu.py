@@ -189,7 +189,8 @@ def test_column_loop_bit_exact_vs_reference_golden():
 
 
 @pytest.mark.parametrize('cfg', [(1024, 1024, 4, False, 128, False), (512, 2048, 4, True, 128, True),
-                                 (333, 640, 4, False, 64, False), (256, 512, 8, True, 0, False)])
+                                 (333, 640, 4, False, 64, False), (256, 512, 8, True, 0, False),
+                                 (200, 1000, 4, True, 0, False), (64, 2304, 4, False, 128, False)])
 def test_column_loop_bit_exact_vs_oracle_larger(cfg):
     from llmc_amd.compression.quantization.gptq_ops import gptq_quantize
     R, K, bit, sym, gs, static_groups = cfg
