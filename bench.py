@@ -233,7 +233,9 @@ def main():
     if rank == 0:
         total_layers = n_layers_block * args.steps * world
         out = {
-            'metric': 'layers/sec (GPTQ W4A16, Llama-3-8B Linear shapes, 128x2048 calib)',
+            'metric': 'layers/sec (GPTQ W4A16, %s Linear shapes, %dx%d calib)' % (
+                {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B'}.get(args.model, args.model), args.n_seq,
+                args.seq_len),
             'value': total_layers / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
