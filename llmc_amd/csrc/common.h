@@ -66,11 +66,12 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t u) {
     return __uint_as_float(((uint32_t)u) << 16);
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float v) {
-    uint32_t x = __float_as_uint(v);
-    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x0040u);  // quiet NaN
-    uint32_t lsb = (x >> 16) & 1u;
-    x += 0x7fffu + lsb;  // RNE
-    return (uint16_t)(x >> 16);
+    // gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN stays a quiet NaN); the integer
+    // emulation this replaces (NaN test, lsb, add, shift) was ~6 VALU ops on every rounding of the ATen-style chains
+    const __bf16 h = (__bf16)v;
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
 }
 
 // round an fp32 value to storage dtype `dt` and come back to fp32 (ATen "opmath" semantics)
