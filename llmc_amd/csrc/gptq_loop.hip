@@ -134,13 +134,6 @@ template <int PO> __device__ __forceinline__ float row_bcast(float v) {
     // row_newbcast:PO (gfx90a+): every lane of a 16-lane row reads lane PO of its row
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + PO, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float rcp_refined(float d) {
-    const float y0 = __builtin_amdgcn_rcpf(d);
-    const float e0 = fmaf(-d, y0, 1.0f);
-    return fmaf(e0, y0, y0);
-}
-// 2^-40 <= x < 2^40 and x > 0
-__device__ __forceinline__ bool plain_pos(float x) { return (__float_as_uint(x) - 0x2B800000u) < 0x28000000u; }
 // plain numerator: 2^-40 <= |x| < 2^40, or +0
 __device__ __forceinline__ bool plain_num(float x) {
     const uint32_t b = __float_as_uint(x);

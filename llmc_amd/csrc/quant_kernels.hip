@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_quant_dynamic(const T* __restrict__ 
             if (zeros) zeros[row] = from_f32<T>(q.z);
         }
         if (!valid) continue;
+        const Divisor dv = make_divisor(q.s, fmaxf(fabsf(mn), fabsf(mx)));
         bool use_first = true;
         for (int c = sl * VEC; c < g; c += lpr * VEC) {
             RowVec<T, VEC> v = use_first ? first : load_vec<T, VEC>(rp + c);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_quant_dynamic(const T* __restrict__ 
                 RowVec<T, VEC> o;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    float qq = quant_code(to_f32<T>(v.v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                    float qq = quant_code(to_f32<T>(v.v[k]), dv, q.z, DT, DT, qmin, qmax);
                     o.v[k] = from_f32<T>(dequant_code(qq, q.s, q.z, DT));
                 }
                 store_vec<T, VEC>((T*)out + rr * g + c, o);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_quant_dynamic(const T* __restrict__ 
                 C* op = (C*)out + rr * g + c;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    op[k] = (C)quant_code(to_f32<T>(v.v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                    op[k] = (C)quant_code(to_f32<T>(v.v[k]), dv, q.z, DT, DT, qmin, qmax);
             }
         }
     }
@@ -309,11 +310,12 @@ __global__ __launch_bounds__(kBlock) void k_quant_dynamic_small(const T* __restr
                 if (zeros) zeros[rows[u]] = from_f32<T>(q.z);
             }
             if (!valid[u] || out == nullptr) continue;
+            const Divisor dv = make_divisor(q.s, fmaxf(fabsf(mn), fabsf(mx)));
             if constexpr (KIND == LLMC_OUT_FAKE) {
                 RowVec<T, VEC> o;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const float qq = quant_code(to_f32<T>(v[u].v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                    const float qq = quant_code(to_f32<T>(v[u].v[k]), dv, q.z, DT, DT, qmin, qmax);
                     o.v[k] = from_f32<T>(dequant_code(qq, q.s, q.z, DT));
                 }
                 store_vec<T, VEC>((T*)out + rows[u] * g + sl * VEC, o);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_quant_dynamic_small(const T* __restr
                 RowVec<C, VEC> o;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    o.v[k] = (C)quant_code(to_f32<T>(v[u].v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                    o.v[k] = (C)quant_code(to_f32<T>(v[u].v[k]), dv, q.z, DT, DT, qmin, qmax);
                 C* op = (C*)out + rows[u] * g + sl * VEC;
                 if constexpr (sizeof(C) * VEC == 32) {
                     uint4 lo, hi;
@@ -494,15 +496,17 @@ __global__ __launch_bounds__(kBlock) void k_mse_qparams(const T* __restrict__ W,
             mx = fmaxf(mx, x);
         }
         float cur_min = wave_min(mn, 64), cur_max = wave_max(mx, 64);
+        const float row_absmax = fmaxf(fabsf(cur_min), fabsf(cur_max));
         float best = INFINITY;
         for (int i = 0; i < nsteps; ++i) {
             const float p = (float)(1.0 - (double)i / (double)grid);   // python float -> fp32 scalar operand
             const float xmin = p * cur_min, xmax = p * cur_max;
             const QParams q = qparams_from_minmax(xmin, xmax, LLMC_F32, sym, round_zp, qmin, qmax);
+            const Divisor dv = make_divisor(q.s, row_absmax);
             float acc = 0.0f;
             for (int c = lane; c < g; c += 64) {
                 const float x = to_f32<T>(w[c]);
-                const float code = quant_code(x, q.s, q.z, LLMC_F32, LLMC_F32, qmin, qmax);
+                const float code = quant_code(x, dv, q.z, LLMC_F32, LLMC_F32, qmin, qmax);
                 const float d = fabsf(dequant_code(code, q.s, q.z, LLMC_F32) - x);
                 acc += powf(d, norm);
             }
@@ -716,6 +720,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_fakequant(const T* __restrict_
         mx = wave_max(mx, lpr);
         QParams q = qparams_from_minmax(mn, mx, DT, sym, 1, qmin, qmax);
         if (!valid) continue;
+        const Divisor dv = make_divisor(q.s, fmaxf(fabsf(mn), fabsf(mx)));
         bool use_first = true;
         for (int c = sl * VEC; c < g; c += lpr * VEC) {
             RowVec<T, VEC> v;
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_fakequant(const T* __restrict_
             RowVec<T, VEC> o;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float qq = quant_code(to_f32<T>(v.v[k]), q.s, q.z, DT, DT, qmin, qmax);
+                float qq = quant_code(to_f32<T>(v.v[k]), dv, q.z, DT, DT, qmin, qmax);
                 o.v[k] = from_f32<T>(dequant_code(qq, q.s, q.z, DT));
             }
             store_vec<T, VEC>(out + rr * g + c, o);

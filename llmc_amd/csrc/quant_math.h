@@ -37,10 +37,52 @@ __device__ __forceinline__ QParams qparams_from_minmax(float mn, float mx, int d
     return q;
 }
 
+
+// ---- division by a value that is fixed for many elements (a group's scale) --------------------------------------
+// `x / s` compiles to hipcc's IEEE sequence: v_div_scale x2, rcp, 2 fma (reciprocal refinement), mul, 3 fma, v_div_fmas,
+// v_div_fixup. v_div_scale is the identity when the operands are "plain" and v_div_fixup only acts on zero / inf /
+// nan / denormal operands, so with the refined reciprocal hoisted the quotient is the 5-op tail below, bit for bit.
+// Plain: divisor in [2^-40, 2^40) and |x| < 2^40. (|x| below 2^-103 is scaled by the full sequence; the tail then
+// differs in the last bits of a quotient below 2^-63, which every caller rounds to an integer: still 0.)
+__device__ __forceinline__ bool plain_pos(float x) { return (__float_as_uint(x) - 0x2B800000u) < 0x28000000u; }
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = fmaf(-d, y0, 1.0f);
+    return fmaf(e0, y0, y0);
+}
+__device__ __forceinline__ float div_tail(float n, float d, float y) {
+    const float q0 = n * y;
+    const float e1 = fmaf(-d, q0, n);
+    const float q1 = fmaf(e1, y, q0);
+    const float e2 = fmaf(-d, q1, n);
+    return fmaf(e2, y, q1);
+}
+struct Divisor {
+    float s, y;
+    bool fast;
+};
+// absmax: an upper bound of |x| over the elements that will be divided (the group's max(|min|, |max|))
+__device__ __forceinline__ Divisor make_divisor(float s, float absmax) {
+    Divisor d;
+    d.s = s;
+    d.y = rcp_refined(s);
+    d.fast = plain_pos(s) && absmax < 1.099511627776e12f;   // 2^40; false for inf / nan bounds
+    return d;
+}
+__device__ __forceinline__ float div_by(float x, const Divisor& d) { return d.fast ? div_tail(x, d.s, d.y) : x / d.s; }
+
 // quant (quant.py:699-707, round_zp=True branch). p1 = promote(wdt, sdt); p2 = promote(p1, zdt).
 __device__ __forceinline__ float quant_code(float x, float s, float z, int p1, int p2, float qmin,
                                             float qmax) {
     float t = rnd(x / s, p1);
+    t = rintf(t);
+    t = rnd(t + z, p2);
+    return fminf(fmaxf(t, qmin), qmax);
+}
+// same with the group's hoisted divisor
+__device__ __forceinline__ float quant_code(float x, const Divisor& d, float z, int p1, int p2, float qmin,
+                                            float qmax) {
+    float t = rnd(div_by(x, d), p1);
     t = rintf(t);
     t = rnd(t + z, p2);
     return fminf(fmaxf(t, qmin), qmax);
