@@ -134,6 +134,35 @@ def test_llama_shape_vs_oracle(dt, cfg):
     np.testing.assert_array_equal(bits(host(rs).reshape(-1)), bits(s_ref.reshape(-1)))
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f32'])
+@pytest.mark.parametrize('sym', [False, True])
+def test_groups_outside_the_plain_range_take_the_ieee_division(dt, sym):
+    """The dynamic quantizer kernels divide by a hoisted reciprocal only when a group is "plain" (scale in
+    [2^-40, 2^40), |w| < 2^40); groups that are not (huge, tiny-scaled, denormal, inf-free extremes) must match the
+    oracle bit for bit through the IEEE-division fallback, and plain groups next to them must be unaffected."""
+    R, K, gs = 8, 512, 128
+    gen = torch.Generator().manual_seed(9)
+    w = (torch.randn(R, K, generator=gen) * 0.02)
+    w[0, :128] *= 1e15           # |w| > 2^40
+    w[1, 128:256] = 3e38 * torch.sign(w[1, 128:256])   # near the top of the fp32 / bf16 range
+    w[2, 256:384] *= 1e-30       # values far below 2^-40 (scale clamps to 1e-5 / qmax: plain divisor)
+    w[3, :128] = 0.0
+    w[4, 384:] *= 1e-42 if dt == 'f32' else 1e-38       # denormals (fp32) / near the smallest normals
+    w = w.to(TD[dt])
+    wn = w.float().numpy()
+    q = make_quantizer(4, sym, 'per_group', gs)
+    qmin, qmax = Q.int_range(4, sym)
+    w2 = Q.reshape_rows(wn, 'per_group', gs)
+    fq_ref, s_ref, z_ref = Q.fake_quant_dynamic(w2, dt, sym, qmin, qmax)
+    wd = w.cuda()
+    fq = q.fake_quant_weight_dynamic(wd)
+    np.testing.assert_array_equal(bits(host(fq)), bits(fq_ref.reshape(R, K)))
+    codes_ref, _, _ = Q.real_quant_dynamic(w2, dt, sym, qmin, qmax)
+    codes, rs, rz = q.real_quant_weight_dynamic(wd)
+    np.testing.assert_array_equal(codes.cpu().numpy().astype(np.int32), codes_ref.reshape(R, K))
+    np.testing.assert_array_equal(bits(host(rs).reshape(-1)), bits(s_ref.reshape(-1)))
+
+
 def test_ragged_and_tiny_shapes():
     # rows not a multiple of the wave's rows-per-wave, g not a multiple of the 16-B vector
     for (R, K, gran, gs) in [(3, 130, 'per_channel', 0), (1, 8, 'per_channel', 0), (7, 96, 'per_group', 32),
