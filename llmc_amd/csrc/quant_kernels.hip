@@ -184,11 +184,15 @@ __global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W
         float s = load_as_f32(scales, row, sdt);
         float z = zeros ? load_as_f32(zeros, row, zdt) : 0.0f;
         RowVec<T, VEC> v = load_vec<T, VEC>(W + row * g + c);
+        float am = 0.0f;   // bound of |x| over this thread's elements for the hoisted divisor (quant_math.h)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) am = fmaxf(am, fabsf(to_f32<T>(v.v[k])));
+        const Divisor dv = make_divisor(s, am);
         if constexpr (KIND == LLMC_OUT_FAKE) {
             RowVec<T, VEC> o;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float q = quant_code(to_f32<T>(v.v[k]), s, z, p1, p2, qmin, qmax);
+                float q = quant_code(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax);
                 o.v[k] = from_f32<T>(dequant_code(q, s, z, p2));
             }
             store_vec<T, VEC>((T*)out + row * g + c, o);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W
             RowVec<C, VEC> o;
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
-                o.v[k] = (C)quant_code(to_f32<T>(v.v[k]), s, z, p1, p2, qmin, qmax);
+                o.v[k] = (C)quant_code(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax);
             C* op = (C*)out + row * g + c;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) op[k] = o.v[k];
