@@ -395,6 +395,104 @@ __global__ __launch_bounds__(256) void k_sgemm_shortk(SgemmArgs a) {
     }
 }
 
+
+// Phased form of the short-K kernel for latency-critical products with few tiles (the part of K4's far update that the
+// next column group waits for): Kd = n * 128, C -= A[:, p] B[p, :] phase by phase exactly like k_sgemm's phased mode
+// (each phase: one accumulator per element from +0 in ascending k, then one rounding C - acc), but on 64x64 tiles,
+// i.e. 4x the workgroups, each streaming its panels in 128-deep chunks with the next chunk's loads in flight under
+// the current chunk's MFMAs.
+template <bool TA>
+__global__ __launch_bounds__(256) void k_sgemm_shortk_phased(SgemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[SKD * SLB];
+    __shared__ __attribute__((aligned(16))) float Bs[SKD * SLB];
+    const int M = a.M, N = a.N, Kd = a.Kd;
+    const int i0 = blockIdx.y * SB, j0 = blockIdx.x * SB;
+    if (a.c_upper_only && j0 + SB <= i0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    constexpr int LA = TA ? SLB : SLT;
+    const int col = j0 + wn * 32 + (lane & 31);
+    float cv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cv[r] = (row < M && col < N) ? a.C[(int64_t)row * a.ldc + col] : 0.0f;
+    }
+    float4 va[8], vb[8];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TA) {
+                const int k = kc + (idx >> 4), i = i0 + 4 * (idx & 15);
+                if (k < Kd) {
+                    const float* p = a.A + (int64_t)k * a.lda + i;
+                    if (i + 3 < M) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (i < M) v.x = p[0];
+                        if (i + 1 < M) v.y = p[1];
+                        if (i + 2 < M) v.z = p[2];
+                    }
+                }
+            } else {
+                const int i = i0 + (idx >> 5), k = kc + 4 * (idx & 31);
+                if (i < M && k + 3 < Kd) v = *reinterpret_cast<const float4*>(a.A + (int64_t)i * a.lda + k);
+            }
+            va[q] = v;
+            const int kb = kc + (idx >> 4), j = j0 + 4 * (idx & 15);
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kb < Kd) {
+                const float* p = a.B + (int64_t)kb * a.ldb + j;
+                if (j + 3 < N) w = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (j < N) w.x = p[0];
+                    if (j + 1 < N) w.y = p[1];
+                    if (j + 2 < N) w.z = p[2];
+                }
+            }
+            vb[q] = w;
+        }
+    };
+    gload(0);
+    const float* pa = As + (lane >> 5) * LA + wm * 32 + (lane & 31);
+    const float* pb = Bs + (lane >> 5) * SLB + wn * 32 + (lane & 31);
+    for (int kc = 0; kc < Kd; kc += SKD) {
+        if (kc) __syncthreads();   // the previous chunk's MFMAs have read the panels
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q;
+            if (TA) {
+                *reinterpret_cast<float4*>(As + (idx >> 4) * SLB + 4 * (idx & 15)) = va[q];
+            } else {
+                const int i = idx >> 5, k = 4 * (idx & 31);
+                As[(k + 0) * SLT + i] = va[q].x;
+                As[(k + 1) * SLT + i] = va[q].y;
+                As[(k + 2) * SLT + i] = va[q].z;
+                As[(k + 3) * SLT + i] = va[q].w;
+            }
+            *reinterpret_cast<float4*>(Bs + (idx >> 4) * SLB + 4 * (idx & 15)) = vb[q];
+        }
+        __syncthreads();
+        if (kc + SKD < Kd) gload(kc + SKD);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 8
+        for (int kk = 0; kk < SKD / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk * LA], pb[2 * kk * SLB], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = cv[r] - acc[r];
+    }
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M) a.C[(int64_t)row * a.ldc + col] = cv[r];
+        }
+    }
+}
+
 int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return LLMC_OK;
     LLMC_REQUIRE((a.lda % 4 == 0) && (a.ldb % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
@@ -406,6 +504,16 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
         dim3 sgrid((a.N + SB - 1) / SB, in_place ? 1 : (a.M + SB - 1) / SB, 1);
         if (TA) hipLaunchKernelGGL((k_sgemm_shortk<true>), sgrid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_sgemm_shortk<false>), sgrid, dim3(256), 0, st, a);
+        LLMC_LAUNCH_CHECK();
+        return LLMC_OK;
+    }
+    // few-tile phased products (phase = 128) on 64x64 tiles: the latency-critical slice of K4's far update
+    if (!TB && a.batch == 1 && a.epilogue == SG_SUB && a.phase_len == SKD && a.Kd % SKD == 0 && a.Kd > SKD &&
+        !a.a_upper && !a.a_lower && !a.b_upper && (TA || a.lda % 4 == 0) &&
+        (int64_t)((a.M + SB - 1) / SB) * ((a.N + SB - 1) / SB) <= 1024 && !getenv("LLMC_NO_SHORTK")) {
+        dim3 sgrid((a.N + SB - 1) / SB, (a.M + SB - 1) / SB, 1);
+        if (TA) hipLaunchKernelGGL((k_sgemm_shortk_phased<true>), sgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_sgemm_shortk_phased<false>), sgrid, dim3(256), 0, st, a);
         LLMC_LAUNCH_CHECK();
         return LLMC_OK;
     }
