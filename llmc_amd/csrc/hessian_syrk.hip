@@ -574,7 +574,10 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     a.sync = (unsigned*)((char*)ws + (size_t)S * ntp * TILE_FLOATS * sizeof(float));
     if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
     if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
-    static bool attr_set[2] = {false, false};
+    static bool attr_set_dev[64][2] = {};   // per device: the attribute belongs to the device's copy of the kernel
+    int dev_id = 0;
+    LLMC_HIP_CHECK(hipGetDevice(&dev_id));
+    bool* attr_set = attr_set_dev[dev_id & 63];
     // k_syrk2 (deeper LDS-DMA ring) measures within 2 % of k_syrk on MI355X (both ~60 % MFMA-busy, clock-limited
     // on random data: profiles/r01_syrk_variants.txt); k_syrk stays the default, LLMC_SYRK_V2=1 selects the ring.
     const bool use_v2 = getenv("LLMC_SYRK_V2") != nullptr;
