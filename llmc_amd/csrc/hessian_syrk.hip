@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
 static inline int choose_chunks(int ntiles_real, int nk, int64_t x_bytes, int ncu) {
     // pick S >= Smin minimising a simple time model (microseconds):
     //   rounds * (K-steps per unit * t_step + t_unit) + fixup traffic (S partial tiles written + read)
-    const double t_step = 0.9, t_unit = 6.0, fix_us_per_tile = 0.13;  // 2 x 256 KiB at ~4 TB/s
+    const double t_step = 0.9, t_unit = 6.0, fix_us_per_tile = 0.13;  // 2 x 256 KiB at ~4 TB/s. (A sweep with LLMC_SYRK_S at
+    // K = 4096, T = 262144 put S = 15 2 % ahead of the S = 9 this picks: within box-to-box noise, not adopted.)
     int smin = (int)(x_bytes / (1ll << 31)) + 1;
     if (smin > nk) smin = nk;
     if (smin < 1) smin = 1;
@@ -540,6 +541,7 @@ static int syrk_geometry(int64_t T, int64_t K, int64_t ldx, int* nb, int* ntp, i
     *nk = (int)ceil_div64(T, BK);
     int real = (*nb) * (*nb + 1) / 2;
     *S = choose_chunks(real, *nk, T * ldx * 2, 256);
+    if (const char* e = getenv("LLMC_SYRK_S")) *S = atoi(e);   // diagnostic: force the token-chunk count
     if (*S > *nk) *S = *nk;
     if (*S < 1) *S = 1;
     return 0;
