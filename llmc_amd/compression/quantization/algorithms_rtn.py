@@ -29,4 +29,4 @@ class RTN(BaseBlockwiseQuantization):
         return None
 
 
-ALGO_REGISTRY.bind('RTN', RTN)
+RTN = ALGO_REGISTRY(RTN)   # decorator protocol only: llmc's own Register has no other registration method

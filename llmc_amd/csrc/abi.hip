@@ -1,4 +1,7 @@
 // abi.hip — version / error entry points of libllmc_hip.so.
+#include <mutex>
+#include <set>
+#include <utility>
 #include "common.h"
 
 namespace llmc {
@@ -8,6 +11,36 @@ void set_last_error(const char* where, hipError_t e) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
 }
 void set_last_error_msg(const char* msg) { snprintf(g_last_error, sizeof(g_last_error), "%s", msg); }
+
+// ---- per-device facts and per-(device, kernel) function attributes ---------------------------------------
+// The only process-wide mutable state of the library besides the side-stream pool; both are guarded by a mutex so
+// that entry points may be called from several host threads (re-entrant).
+static std::mutex g_dev_mu;
+static int g_cu_count[LLMC_MAX_DEVICES] = {};
+static std::set<std::pair<int, const void*>> g_lds_attr_done;
+
+int device_cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LLMC_MAX_DEVICES) return 256;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_cu_count[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cu_count[dev] = n;
+    }
+    return g_cu_count[dev];
+}
+
+int ensure_dynamic_lds(const void* fn, int bytes) {
+    int dev = 0;
+    LLMC_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto key = std::make_pair(dev, fn);
+    if (g_lds_attr_done.count(key)) return LLMC_OK;
+    LLMC_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_lds_attr_done.insert(key);
+    return LLMC_OK;
+}
 }  // namespace llmc
 
 extern "C" int llmc_hip_abi_version(void) { return LLMC_HIP_ABI_VERSION; }

@@ -219,23 +219,11 @@ extern "C" int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_
     a.best_max = best_max; a.best_min = best_min;
     const size_t lds = (size_t)CG * CTOK * 2 + (size_t)(4 * CMAXS * CG + CROWS * CMAXS) * sizeof(float);
     dim3 grid((unsigned)a.ng, (unsigned)ceil_div64(R, CROWS));
-    static bool attr_dev[64][2] = {};   // per device: the attribute belongs to the device's copy of the kernel
-    int dev_id = 0;
-    LLMC_HIP_CHECK(hipGetDevice(&dev_id));
-    bool* attr = attr_dev[dev_id & 63];
     if (dt == LLMC_F16) {
-        if (!attr[0]) {
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_clip_search<f16_t>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr[0] = true;
-        }
+        if (int rc = ensure_dynamic_lds((const void*)k_clip_search<f16_t>, (int)lds)) return rc;
         hipLaunchKernelGGL((k_clip_search<f16_t>), grid, dim3(256), lds, st, a);
     } else {
-        if (!attr[1]) {
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_clip_search<bf16_t>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr[1] = true;
-        }
+        if (int rc = ensure_dynamic_lds((const void*)k_clip_search<bf16_t>, (int)lds)) return rc;
         hipLaunchKernelGGL((k_clip_search<bf16_t>), grid, dim3(256), lds, st, a);
     }
     LLMC_LAUNCH_CHECK();

@@ -512,15 +512,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
     LLMC_HIP_CHECK(hipMemsetAsync(info_dev, 0, 4, st));
-    static bool potrf_attr_dev[64] = {};   // per device: the attribute belongs to the device's copy of the kernel
-    int dev_id = 0;
-    LLMC_HIP_CHECK(hipGetDevice(&dev_id));
-    bool& potrf_attr = potrf_attr_dev[dev_id & 63];
-    if (!potrf_attr) {
-        LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_potrf_inv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (NB * PLD + 32 * PLD + 64) * (int)sizeof(float)));
-        potrf_attr = true;
-    }
+    if (int rc = ensure_dynamic_lds((const void*)k_potrf_inv, (NB * PLD + 32 * PLD + 64) * (int)sizeof(float))) return rc;
 
     dim3 tgrid((K + 31) / 32, (K + 31) / 32);
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);

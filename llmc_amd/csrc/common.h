@@ -39,6 +39,11 @@ void set_last_error_msg(const char* msg);
         }                                                      \
     } while (0)
 
+// per-device facts / attributes (abi.hip; mutex-guarded, safe from several host threads)
+static constexpr int LLMC_MAX_DEVICES = 64;
+int device_cu_count();                                  // CUs of the current device (256 on MI355X)
+int ensure_dynamic_lds(const void* fn, int bytes);      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
+
 static inline int dtype_size(int dt) { return dt == LLMC_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == LLMC_F16 || dt == LLMC_BF16 || dt == LLMC_F32; }
 

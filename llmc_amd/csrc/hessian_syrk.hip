@@ -467,6 +467,234 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk2(SyrkArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// k_syrk4 — one wave per SIMD: 4 waves as 2(M) x 2(N), each wave 128 x 128 = 4 x 4 MFMA 32x32x16 accumulators
+// (256 accumulator registers; the kernel uses the whole 512-entry file of its SIMD).
+//   * 8 fragment reads feed 16 MFMAs per 16-token slice (0.5 per MFMA; the 8-wave kernel's 128x64 wave tile
+//     needs 0.75), so the LDS moves a third fewer bytes per flop;
+//   * LDS ring of 4 stages of 32 tokens, up to 3 stages of LDS-DMA in flight, counted vmcnt (never 0 in the
+//     steady state); fragments double-buffered in registers at 16-token granularity; one s_barrier per stage,
+//     placed BETWEEN the stage's two MFMA bursts, so the matrix pipe always has 16 issued-ahead MFMAs' worth
+//     of operands in registers when the workgroup synchronises;
+//   * every MFMA is followed by one fragment read (2 ds_read_b64_tr_b16) or one LDS-DMA piece, pinned in that
+//     order: with a single wave per SIMD nothing else hides their issue.
+// Same units, same token order per accumulator and the same fragment-order partial tile as k_syrk: results
+// are bit-identical to k_syrk's.
+// ABL (lab builds only): bit 0 = no LDS-DMA, bit 1 = no fragment reads (times the other parts of the loop).
+// -----------------------------------------------------------------------------------------------------
+static constexpr int S4_THREADS = 256;
+static constexpr int S4_TOK = 32;
+static constexpr int S4_PANEL = S4_TOK * TM * 2;      // 16 KiB
+static constexpr int S4_STAGE = 2 * S4_PANEL;         // 32 KiB
+static constexpr int S4_RING = 4;
+static constexpr int S4_LDS = S4_RING * S4_STAGE;     // 128 KiB
+
+// LDS-DMA piece with a scalar byte offset: address = rsrc.base + soff + voff[lane]; the per-stage offset lives
+// in an SGPR (no VALU add per piece). M0 is not live across statements in these kernels (no save/restore).
+__device__ __forceinline__ void dma16s(i32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
+    asm volatile(
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %1, %2 offen lds"
+        :
+        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+        : "memory");
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// One unit (tile x token chunk). The loop body is uniform from the first stage to the last: a diagonal tile loads its
+// panel into both LDS panels (vB == vA), and stages past the end of the chunk are still requested (into slots nobody
+// reads; the buffer descriptor zero-fills past the end of X) and their first fragments still read — a few KiB per
+// unit of ~15 MB, in exchange for ONE loop with no branch: with 256 live accumulators any control flow inside the
+// unit made hipcc shuffle accumulators through scratch.
+template <int DT, int ABL>
+__device__ __forceinline__ void syrk4_unit(f32x16 (&acc)[4][4], LDS_AS char* lds, uint32_t lds_base, i32x4 rsrc,
+                                           uint32_t vA, uint32_t vB, uint32_t slab, uint32_t stage_bytes, int nst,
+                                           int wv, const int (&offA)[4], const int (&offB)[4], int lane) {
+    constexpr int PER = 8;              // LDS-DMA pieces per stage per wave
+    constexpr bool DMA = !(ABL & 1);
+    constexpr bool RD = !(ABL & 2);
+    // piece d of stage st: d = 0..3 A-panel KiB-block (d*4 + wv), d = 4..7 the same of the B panel
+    auto piece = [&](int st, auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (DMA) {
+            const uint32_t soff = (uint32_t)st * stage_bytes + (uint32_t)(d & 3) * slab;
+            const uint32_t dst = lds_base + (uint32_t)(st & (S4_RING - 1)) * S4_STAGE + (d >> 2) * S4_PANEL +
+                                 (uint32_t)((d & 3) * 4 + wv) * 1024;
+            dma16s(rsrc, d < 4 ? vA : vB, soff, dst);
+        }
+    };
+    s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    if constexpr (!RD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)(lane * 8 + e + i);
+            asm volatile("" : "+v"(v));
+            fa0[i] = fb0[i] = fa1[i] = fb1[i] = v;
+        }
+    }
+    // fragment f of slice (st, kk): order A0 B0 B1 B2 B3 A1 A2 A3 (the first MFMAs of a burst need A0 and B*)
+    auto frag = [&](int st, int kk, auto fc, s16x8 (&fa)[4], s16x8 (&fb)[4]) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr (RD) {
+            LDS_AS char* pa = lds + (st & (S4_RING - 1)) * S4_STAGE;
+            LDS_AS char* pb = pa + S4_PANEL;
+            if constexpr (f == 0) fa[0] = tr_frag(pa + offA[0], kk * 16 * TM * 2);
+            else if constexpr (f <= 4) fb[f - 1] = tr_frag(pb + offB[f - 1], kk * 16 * TM * 2);
+            else fa[f - 4] = tr_frag(pa + offA[f - 4], kk * 16 * TM * 2);
+        }
+    };
+    // one burst: 16 MFMAs on (fa, fb). Behind MFMA i: i in {0,1,2,4,5,6,8,9} -> the next fragment of slice
+    // (rd_st, rd_kk) into (na, nb) (all eight are back six MFMAs before the burst ends); i in {3,7,11,15} -> LDS-DMA
+    // piece dma_d0 + i/4 of stage dma_st (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread).
+    // No branch inside a burst; the order is pinned.
+    auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], int rd_st, int rd_kk,
+                     int dma_st, auto d0c) {
+        constexpr int D0 = decltype(d0c)::value;
+        static_for<0, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            acc[i >> 2][i & 3] = Mfma<DT>::run(fa[i >> 2], fb[i & 3], acc[i >> 2][i & 3]);
+            if constexpr ((i & 3) == 3) piece(dma_st, std::integral_constant<int, D0 + (i >> 2)>{});
+            else if constexpr (i < 10) frag(rd_st, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // prologue: stages 0..2 and the A half of stage 3 requested, stage 0 published, its first fragments fetched
+    for (int st = 0; st < S4_RING - 1; ++st) static_for<0, 8>([&](auto dc) { piece(st, dc); });
+    static_for<0, 4>([&](auto dc) { piece(S4_RING - 1, dc); });
+    dma_wait_upto<2 * PER + PER / 2>();
+    __builtin_amdgcn_s_barrier();
+    static_for<0, 8>([&](auto fc) { frag(0, 0, fc, fa0, fb0); });
+    for (int st = 0; st < nst; ++st) {
+        // slice 0 of stage st; fetches slice 1; requests the B half of stage st+3
+        burst(fa0, fb0, fa1, fb1, st, 1, st + S4_RING - 1, std::integral_constant<int, 4>{});
+        // this wave's pieces of stage st+1 have landed (st+2, st+3 may still be in flight); every wave has read
+        // the whole of stage st once its lgkmcnt(0) is behind the barrier
+        dma_wait_upto<2 * PER>();
+        lds_wait_all();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // slice 1; fetches slice 0 of stage st+1; requests the A half of stage st+4 into the slot stage st has left
+        burst(fa1, fb1, fa0, fb0, st + 1, 0, st + S4_RING, std::integral_constant<int, 0>{});
+    }
+}
+
+template <int DT, int ABL>
+__global__ __launch_bounds__(S4_THREADS) void k_syrk4(SyrkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+
+    // DMA: piece q (0..3) of wave wv fills KiB-block (q*4 + wv) of a 16-KiB panel = token rows 2*blk, 2*blk + 1
+    const int lr = lane >> 5;
+    const int c16 = lane & 31;
+    const int row_lo = 2 * wv + lr;                       // token row inside the 8-row slab of a piece index q
+    const int u_log = (c16 >> 2) ^ (row_lo & 3);          // 8-row slabs keep (row & 3)
+    const int ch_off = (u_log * 4 + (c16 & 3)) * 8;
+    const int64_t row_bytes = a.ldx * 2;
+
+    const int p = lane & 15;
+    const int trow = 8 * (lane >> 5) + (p >> 2);
+    const int sub = 32 * ((lane >> 4) & 1) + 8 * (p & 3);
+    int offA[4], offB[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) offA[m] = trow * (TM * 2) + (((4 * wm + m) ^ (p >> 2)) << 6) + sub;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) offB[n] = trow * (TM * 2) + (((4 * wn + n) ^ (p >> 2)) << 6) + sub;
+
+    const int G = gridDim.x;
+    const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int nunits = a.S * a.ntiles_p;
+    const int nrounds = (nunits + G - 1) / G;
+    const int nst_total = (int)((a.T + S4_TOK - 1) / S4_TOK);
+
+    for (int round = 0; round < nrounds; ++round) {
+        if (a.sync && round > 0) {
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = (unsigned)round * (unsigned)G;
+                int spins = 0;
+                while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                }
+            }
+            __syncthreads();
+        }
+        const int u = lw + round * G;
+        if (u >= nunits) continue;
+        const int s = u / a.ntiles_p;
+        const int ti = u - s * a.ntiles_p;
+        const TileIdx t = decode_tile(ti, a.nb);
+        if (!t.valid) continue;
+        // chunk boundaries in 64-token K-steps (same split as k_syrk: workspace layout and fixup are shared)
+        const int ks0 = (int)(((int64_t)s * a.nk) / a.S);
+        const int ks1 = (int)(((int64_t)(s + 1) * a.nk) / a.S);
+        const int st0 = 2 * ks0;
+        int st1 = 2 * ks1;
+        if (st1 > nst_total) st1 = nst_total;
+        const int nst = st1 - st0;
+
+        const char* base = a.X + (int64_t)st0 * S4_TOK * row_bytes;
+        int64_t rem_bytes = (a.T - (int64_t)st0 * S4_TOK) * row_bytes;
+        const uint32_t nrec = rem_bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)rem_bytes;
+        i32x4 rsrc;
+        rsrc[0] = (int)(uint32_t)(uintptr_t)base;
+        rsrc[1] = (int)((uint32_t)((uintptr_t)base >> 32) & 0xffffu);
+        rsrc[2] = (int)nrec;
+        rsrc[3] = 0x00020000;
+        const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
+        const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
+        const uint32_t slab = (uint32_t)(8 * row_bytes);
+        const uint32_t stage_bytes = (uint32_t)(S4_TOK * row_bytes);
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        syrk4_unit<DT, ABL>(acc, lds, lds_base, rsrc, vA, vB, slab, stage_bytes, nst, wv, offA, offB, lane);
+        lds_wait_all();                  // the trailing fragment reads
+        __builtin_amdgcn_s_barrier();    // ... of every wave, before the next unit's prologue overwrites the ring
+
+        // partial tile in k_syrk's fragment order: wave (wm, wn) x accumulator (m, n) of the 2x2 / 4x4 layout is
+        // wave (wm, 2*wn + n/2) x accumulator (m, n%2) of the 2x4 / 4x2 layout
+        float* slot = a.part + (int64_t)u * TILE_FLOATS;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2],
+                               acc[m][n][4 * q + 3]};
+                    const int wv8 = wm * 4 + wn * 2 + (n >> 1);
+                    int idx = ((((wv8 * 4 + m) * 2 + (n & 1)) * 4 + q) * 64 + lane);
+                    *reinterpret_cast<f32x4*>(slot + (int64_t)idx * 4) = v;
+                }
+        // the stores share the VM counter with the next unit's LDS-DMA: drain them before counting again
+        dma_wait_all();
+    }
+}
+
 // Sum the S partials of each tile (chunk order), H <- alpha*H + beta*sum, mirror to the upper triangle.
 // One thread per float4 of the fragment-order tile: idx -> (wv,m,n,q,lane) -> rows i0..i0+3, column j.
 __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ part, float* __restrict__ H,
@@ -576,41 +804,35 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     a.sync = (unsigned*)((char*)ws + (size_t)S * ntp * TILE_FLOATS * sizeof(float));
     if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
     if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
-    static bool attr_set_dev[64][2] = {};   // per device: the attribute belongs to the device's copy of the kernel
-    int dev_id = 0;
-    LLMC_HIP_CHECK(hipGetDevice(&dev_id));
-    bool* attr_set = attr_set_dev[dev_id & 63];
-    // k_syrk2 (deeper LDS-DMA ring) measures within 2 % of k_syrk on MI355X (both ~60 % MFMA-busy, clock-limited
-    // on random data: profiles/r01_syrk_variants.txt); k_syrk stays the default, LLMC_SYRK_V2=1 selects the ring.
-    const bool use_v2 = getenv("LLMC_SYRK_V2") != nullptr;
-    const bool use_ph8 = getenv("LLMC_SYRK_PH8") != nullptr;
-    if (dt == LLMC_BF16) {
-        if (!attr_set[0]) {
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk2<LLMC_BF16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK2_LDS));
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16, false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_BF16, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
-            attr_set[0] = true;
-        }
-        if (use_v2) hipLaunchKernelGGL((k_syrk2<LLMC_BF16>), dim3(256), dim3(SYRK_THREADS), SYRK2_LDS, st, a);
-        else if (use_ph8) hipLaunchKernelGGL((k_syrk<LLMC_BF16, true>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
-        else hipLaunchKernelGGL((k_syrk<LLMC_BF16, false>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+    const int grid = device_cu_count();   // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous)
+    // Kernel variant. Default k_syrk4 (one wave per SIMD, 128x128 wave tiles); LLMC_SYRK_V=8 selects the 8-wave
+    // kernel, =2 its 4-stage ring, =88 its phase-split schedule. All variants produce identical partial tiles.
+    int variant = 4, abl = 0;
+    if (const char* e = getenv("LLMC_SYRK_V")) variant = atoi(e);
+    if (const char* e = getenv("LLMC_SYRK_ABL")) abl = atoi(e) & 3;   // lab only (wrong results by design)
+    const bool bf = dt == LLMC_BF16;
+    const void* fn = nullptr;
+    int lds_bytes = SYRK_LDS, threads = SYRK_THREADS;
+    if (variant == 2) {
+        fn = bf ? (const void*)k_syrk2<LLMC_BF16> : (const void*)k_syrk2<LLMC_F16>;
+        lds_bytes = SYRK2_LDS;
+    } else if (variant == 88) {
+        fn = bf ? (const void*)k_syrk<LLMC_BF16, true> : (const void*)k_syrk<LLMC_F16, true>;
+    } else if (variant == 8) {
+        fn = bf ? (const void*)k_syrk<LLMC_BF16, false> : (const void*)k_syrk<LLMC_F16, false>;
     } else {
-        if (!attr_set[1]) {
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk2<LLMC_F16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK2_LDS));
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16, false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_syrk<LLMC_F16, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS));
-            attr_set[1] = true;
-        }
-        if (use_v2) hipLaunchKernelGGL((k_syrk2<LLMC_F16>), dim3(256), dim3(SYRK_THREADS), SYRK2_LDS, st, a);
-        else if (use_ph8) hipLaunchKernelGGL((k_syrk<LLMC_F16, true>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
-        else hipLaunchKernelGGL((k_syrk<LLMC_F16, false>), dim3(256), dim3(SYRK_THREADS), SYRK_LDS, st, a);
+        threads = S4_THREADS;
+        lds_bytes = S4_LDS;
+        if (!bf) fn = (const void*)k_syrk4<LLMC_F16, 0>;
+        else if (abl == 1) fn = (const void*)k_syrk4<LLMC_BF16, 1>;
+        else if (abl == 2) fn = (const void*)k_syrk4<LLMC_BF16, 2>;
+        else if (abl == 3) fn = (const void*)k_syrk4<LLMC_BF16, 3>;
+        else fn = (const void*)k_syrk4<LLMC_BF16, 0>;
     }
+    int rc = ensure_dynamic_lds(fn, lds_bytes);
+    if (rc) return rc;
+    void* kargs[] = {(void*)&a};
+    LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(threads), kargs, (size_t)lds_bytes, st));
     LLMC_LAUNCH_CHECK();
     *nb_o = nb;
     *ntp_o = ntp;

@@ -199,23 +199,11 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
     a.X = (const char*)X; a.W = (const char*)Wq; a.N = N; a.K = K; a.R = R; a.mode = mode;
     a.Y = (char*)Yout; a.Y0 = (const char*)Y0; a.part = (float*)ws;
     a.ntm = (int)ceil_div64(N, LT); a.ntn = (int)ceil_div64(R, LT);
-    static bool attr_dev[64][2] = {};   // per device: the attribute belongs to the device's copy of the kernel
-    int dev_id = 0;
-    LLMC_HIP_CHECK(hipGetDevice(&dev_id));
-    bool* attr = attr_dev[dev_id & 63];
     if (dt == LLMC_BF16) {
-        if (!attr[0]) {
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_linear_eval<LLMC_BF16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LLDS + 64));
-            attr[0] = true;
-        }
+        if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_BF16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_BF16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
     } else {
-        if (!attr[1]) {
-            LLMC_HIP_CHECK(hipFuncSetAttribute((const void*)k_linear_eval<LLMC_F16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LLDS + 64));
-            attr[1] = true;
-        }
+        if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_F16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_F16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
     }
     LLMC_LAUNCH_CHECK();

@@ -3,6 +3,7 @@
 // block (look-ahead). All work is fenced back into the caller's stream before the entry point returns, so the
 // C ABI keeps its contract: the call is complete, in stream order, on the stream that was passed in.
 #pragma once
+#include <mutex>
 #include "common.h"
 
 namespace llmc {
@@ -22,9 +23,11 @@ struct SideStream {
 
 // returns nullptr when helper resources cannot be created (callers then run everything on the main stream)
 inline SideStream* side_stream_for_current_device() {
-    static SideStream pool[16];
+    static SideStream pool[LLMC_MAX_DEVICES];   // `inline`: one pool per process, shared by every TU
+    static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LLMC_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
     SideStream* s = &pool[dev];
     if (!s->ok) {
         // lowest priority: the caller's stream carries the latency-bound critical path and must win the dispatcher

@@ -1,0 +1,170 @@
+// syrk_lab — standalone timing / equivalence lab for the K1 (Hessian SYRK) kernel variants of libllmc_hip.so.
+// No torch: starts in milliseconds, so one short GPU call can sweep variants x ablations x data fills.
+//   build: hipcc --offload-arch=gfx950 -O2 tools/probes/syrk_lab.hip -o tools/probes/syrk_lab -ldl
+//   run:   tools/probes/syrk_lab [T K [reps]] ...   (libllmc_hip.so is loaded from llmc_amd/csrc next to the repo root)
+// Variants are selected through the library's diagnostic environment (LLMC_SYRK_V, LLMC_SYRK_ABL), read per call.
+// Output: one line per (shape, fill, variant): median ms, contract TFLOP/s (T*K*(K+1)), fraction of 2.5 PF, and whether
+// the Hessian is bit-identical to the 8-wave kernel's on the same data.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(2);                                                               \
+        }                                                                          \
+    } while (0)
+
+typedef size_t (*ws_fn)(int64_t, int64_t, int64_t);
+typedef int (*part_fn)(const void*, int, int64_t, int64_t, int64_t, void*, void*);
+typedef int (*red_fn)(float*, int64_t, int64_t, int64_t, double, double, const void*, void*);
+typedef int (*err_fn)(char*, size_t);
+
+__device__ inline uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// fill: 0 zeros, 1 ones, 2 N(0,1) * exp(0.5*xi_k) with 8 channels x100 (SURVEY §8d activations), bf16
+__global__ void k_fill(uint16_t* x, int64_t n, int K, int mode, uint32_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    if (mode == 1) v = 1.f;
+    if (mode == 2) {
+        uint32_t h1 = hash32((uint32_t)i * 2u + seed), h2 = hash32((uint32_t)i * 2u + 1u + seed * 7u);
+        float u1 = ((h1 >> 8) + 1) * (1.0f / 16777217.0f), u2 = (h2 >> 8) * (1.0f / 16777216.0f);
+        float z = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+        int k = (int)(i % K);
+        uint32_t hk = hash32((uint32_t)k + 12345u), hk2 = hash32((uint32_t)k + 999u);
+        float uk1 = ((hk >> 8) + 1) * (1.0f / 16777217.0f), uk2 = (hk2 >> 8) * (1.0f / 16777216.0f);
+        float xi = sqrtf(-2.f * logf(uk1)) * cosf(6.2831853f * uk2);
+        float c = expf(0.5f * xi);
+        if ((hash32((uint32_t)k + 77u) % (uint32_t)K) < 8u) c *= 100.f;
+        v = z * c;
+    }
+    __bf16 h = (__bf16)v;
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    x[i] = u;
+}
+
+struct Lib {
+    ws_fn ws;
+    part_fn part;
+    red_fn red;
+    err_fn err;
+};
+
+static double run_variant(const Lib& L, const char* v, const char* abl, const void* X, int64_t T, int64_t K, void* ws,
+                          float* H, int reps, hipStream_t st) {
+    if (v) setenv("LLMC_SYRK_V", v, 1); else unsetenv("LLMC_SYRK_V");
+    if (abl) setenv("LLMC_SYRK_ABL", abl, 1); else unsetenv("LLMC_SYRK_ABL");
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    for (int r = 0; r < reps + 1; ++r) {
+        CK(hipEventRecord(e0, st));
+        int rc = L.part(X, 1, T, K, K, ws, st);
+        CK(hipEventRecord(e1, st));
+        if (rc) {
+            char buf[256];
+            L.err(buf, 256);
+            fprintf(stderr, "partials failed rc=%d: %s\n", rc, buf);
+            exit(3);
+        }
+        rc = L.red(H, T, K, K, 0.0, 1.0, ws, st);
+        if (rc) exit(4);
+        CK(hipStreamSynchronize(st));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        if (r > 0) ms.push_back(t);   // first = warm-up
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
+int main(int argc, char** argv) {
+    std::string root = ".";
+    if (const char* r = getenv("GRAFT_REPO_ROOT")) root = r;
+    std::string so = root + "/llmc_amd/csrc/libllmc_hip.so";
+    void* h = dlopen(so.c_str(), RTLD_NOW);
+    if (!h) { fprintf(stderr, "dlopen %s: %s\n", so.c_str(), dlerror()); return 1; }
+    Lib L;
+    L.ws = (ws_fn)dlsym(h, "llmc_hessian_accum_ws_bytes");
+    L.part = (part_fn)dlsym(h, "llmc_hessian_accum_partials");
+    L.red = (red_fn)dlsym(h, "llmc_hessian_accum_reduce");
+    L.err = (err_fn)dlsym(h, "llmc_hip_last_error");
+    if (!L.ws || !L.part || !L.red) { fprintf(stderr, "missing symbols\n"); return 1; }
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("# device %s, %d CUs\n", prop.gcnArchName, prop.multiProcessorCount);
+
+    struct Shape { int64_t T, K; };
+    std::vector<Shape> shapes;
+    int reps = 5;
+    for (int i = 1; i + 1 < argc; i += 2) shapes.push_back({atoll(argv[i]), atoll(argv[i + 1])});
+    if (shapes.empty()) shapes = {{262144, 4096}, {65536, 14336}};
+    if (const char* r = getenv("LAB_REPS")) reps = atoi(r);
+    const bool quick = getenv("LAB_QUICK") != nullptr;
+
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (auto sh : shapes) {
+        const int64_t T = sh.T, K = sh.K, n = T * K;
+        uint16_t* X;
+        CK(hipMalloc(&X, n * 2));
+        size_t wsb = L.ws(T, K, K);
+        void* ws;
+        CK(hipMalloc(&ws, wsb));
+        float *H0, *H1;
+        CK(hipMalloc(&H0, K * K * 4));
+        CK(hipMalloc(&H1, K * K * 4));
+        std::vector<float> h0((size_t)K * K), h1((size_t)K * K);
+        const double fl = (double)T * K * (K + 1);
+        for (int fill : {0, 2}) {
+            if (quick && fill == 0 && K > 4096) continue;
+            k_fill<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(X, n, (int)K, fill, 17u);
+            CK(hipStreamSynchronize(st));
+            const char* fname = fill == 0 ? "zeros" : "randn";
+            struct V { const char* name; const char* v; const char* abl; bool check; };
+            std::vector<V> vs = {{"k_syrk 8-wave", "8", nullptr, false},
+                                 {"k_syrk4", "4", nullptr, true},
+                                 {"k_syrk ph8", "88", nullptr, true},
+                                 {"k_syrk2 ring", "2", nullptr, true},
+                                 {"k_syrk4 no-dma", "4", "1", false},
+                                 {"k_syrk4 no-read", "4", "2", false},
+                                 {"k_syrk4 mfma-only", "4", "3", false}};
+            if (K > 4096) vs.resize(2);
+            for (size_t i = 0; i < vs.size(); ++i) {
+                const V& v = vs[i];
+                float* H = i == 0 ? H0 : H1;
+                double ms = run_variant(L, v.v, v.abl, X, T, K, ws, H, reps, st);
+                const char* same = "";
+                if (v.check) {
+                    CK(hipMemcpy(h0.data(), H0, (size_t)K * K * 4, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(h1.data(), H1, (size_t)K * K * 4, hipMemcpyDeviceToHost));
+                    size_t bad = 0;
+                    for (size_t j = 0; j < h0.size(); ++j) bad += memcmp(&h0[j], &h1[j], 4) != 0;
+                    same = bad ? "  MISMATCH vs 8-wave" : "  bit-identical to 8-wave";
+                    if (bad) printf("#   %zu of %zu elements differ\n", bad, h0.size());
+                }
+                printf("T=%lld K=%lld %-6s %-18s %8.3f ms  %7.1f TFLOP/s  %.3f of 2.5PF%s\n", (long long)T, (long long)K,
+                       fname, v.name, ms, fl / (ms * 1e-3) / 1e12, fl / (ms * 1e-3) / 2.5e15, same);
+                fflush(stdout);
+            }
+        }
+        CK(hipFree(X)); CK(hipFree(ws)); CK(hipFree(H0)); CK(hipFree(H1));
+    }
+    return 0;
+}
