@@ -85,7 +85,16 @@ struct SyrkArgs {
     int nk;            // ceil(T / 64)
     float* part;       // [S * ntiles_p][256*256] fp32, fragment order
     unsigned* sync;    // round barrier counter (zeroed before the launch), or null
+    int kalign;        // chunk boundaries are multiples of this many K-steps (k_syrk4 works in whole ring groups)
 };
+
+// First 64-token K-step of chunk s (s = S gives the end of the last one). Interior boundaries are rounded down to a
+// multiple of kalign, the end is rounded up: K-steps past ceil(T/64) read rows past T, which the buffer descriptor
+// zero-fills, so they add nothing.
+__host__ __device__ inline int chunk_begin(int s, int nk, int S, int kalign) {
+    if (s >= S) return (nk + kalign - 1) / kalign * kalign;
+    return (int)(((int64_t)s * nk) / S) / kalign * kalign;
+}
 
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -158,13 +167,14 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk(SyrkArgs a) {
         const TileIdx t = decode_tile(ti, a.nb);
         if (!t.valid) continue;
         const bool diag = t.bi == t.bj;
-        const int ks0 = (int)(((int64_t)s * a.nk) / a.S);
-        const int ks1 = (int)(((int64_t)(s + 1) * a.nk) / a.S);
+        const int ks0 = chunk_begin(s, a.nk, a.S, a.kalign);
+        const int ks1 = chunk_begin(s + 1, a.nk, a.S, a.kalign);
 
         // buffer descriptor over the chunk's rows: reads past row T return 0 (token tail), channel
         // overrun past K only pollutes outputs that the fixup never stores.
         const char* base = a.X + (int64_t)ks0 * BK * row_bytes;
         int64_t rem_bytes = (a.T - (int64_t)ks0 * BK) * row_bytes;
+        if (rem_bytes < 0) rem_bytes = 0;
         const uint32_t nrec = rem_bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)rem_bytes;
         i32x4 rsrc;
         rsrc[0] = (int)(uint32_t)(uintptr_t)base;
@@ -418,8 +428,8 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk2(SyrkArgs a) {
         const TileIdx t = decode_tile(ti, a.nb);
         if (!t.valid) continue;
         // chunk boundaries in 64-token K-steps (same split as k_syrk: ws layout and fixup are shared)
-        const int ks0 = (int)(((int64_t)s * a.nk) / a.S);
-        const int ks1 = (int)(((int64_t)(s + 1) * a.nk) / a.S);
+        const int ks0 = chunk_begin(s, a.nk, a.S, a.kalign);
+        const int ks1 = chunk_begin(s + 1, a.nk, a.S, a.kalign);
         const int st0 = 2 * ks0;
         int st1 = 2 * ks1;
         if (st1 > nst_total) st1 = nst_total;
@@ -427,6 +437,7 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk2(SyrkArgs a) {
 
         const char* base = a.X + (int64_t)st0 * ST_TOK * row_bytes;
         int64_t rem_bytes = (a.T - (int64_t)st0 * ST_TOK) * row_bytes;
+        if (rem_bytes < 0) rem_bytes = 0;
         const uint32_t nrec = rem_bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)rem_bytes;
         i32x4 rsrc;
         rsrc[0] = (int)(uint32_t)(uintptr_t)base;
@@ -472,34 +483,24 @@ __global__ __launch_bounds__(SYRK_THREADS) void k_syrk2(SyrkArgs a) {
 // (256 accumulator registers; the kernel uses the whole 512-entry file of its SIMD).
 //   * 8 fragment reads feed 16 MFMAs per 16-token slice (0.5 per MFMA; the 8-wave kernel's 128x64 wave tile
 //     needs 0.75), so the LDS moves a third fewer bytes per flop;
-//   * LDS ring of 4 stages of 32 tokens, up to 3 stages of LDS-DMA in flight, counted vmcnt (never 0 in the
-//     steady state); fragments double-buffered in registers at 16-token granularity; one s_barrier per stage,
-//     placed BETWEEN the stage's two MFMA bursts, so the matrix pipe always has 16 issued-ahead MFMAs' worth
-//     of operands in registers when the workgroup synchronises;
-//   * every MFMA is followed by one fragment read (2 ds_read_b64_tr_b16) or one LDS-DMA piece, pinned in that
-//     order: with a single wave per SIMD nothing else hides their issue.
+//   * LDS ring of NSLOT stages of 32 tokens (4 -> 128 KiB, 5 -> all 160 KiB), NSLOT-1 stages of LDS-DMA in flight,
+//     counted vmcnt (never 0 in the steady state); fragments double-buffered in registers at 16-token granularity;
+//     one s_barrier per stage, placed BETWEEN the stage's two MFMA bursts, so every wave arrives with 16 MFMAs' worth
+//     of operands already in registers;
+//   * the stage loop is unrolled NSLOT times: ring slots are compile-time, LDS-DMA destinations are immediates
+//     (the kernel owns the whole LDS, base 0), the scalar source offset of each piece lives in its own SGPR and is
+//     advanced right after use — a piece is  s_mov m0 / s_nop 0 / buffer_load ... lds / s_add  with no hazard padding;
+//   * every MFMA is followed by at most one fragment read (2 ds_read_b64_tr_b16) or one LDS-DMA piece, pinned in
+//     that order: with a single wave per SIMD nothing else hides their issue.
 // Same units, same token order per accumulator and the same fragment-order partial tile as k_syrk: results
 // are bit-identical to k_syrk's.
-// ABL (lab builds only): bit 0 = no LDS-DMA, bit 1 = no fragment reads (times the other parts of the loop).
+// ABL (lab builds only): 1 = no LDS-DMA, 2 = no fragment reads, 4 = LDS-DMA source pinned to the chunk's first stages
+// (L2-resident: separates issue cost from miss latency), 8 = pieces without their buffer_load (SALU only).
 // -----------------------------------------------------------------------------------------------------
 static constexpr int S4_THREADS = 256;
 static constexpr int S4_TOK = 32;
 static constexpr int S4_PANEL = S4_TOK * TM * 2;      // 16 KiB
 static constexpr int S4_STAGE = 2 * S4_PANEL;         // 32 KiB
-static constexpr int S4_RING = 4;
-static constexpr int S4_LDS = S4_RING * S4_STAGE;     // 128 KiB
-
-// LDS-DMA piece with a scalar byte offset: address = rsrc.base + soff + voff[lane]; the per-stage offset lives
-// in an SGPR (no VALU add per piece). M0 is not live across statements in these kernels (no save/restore).
-__device__ __forceinline__ void dma16s(i32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
-    asm volatile(
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "buffer_load_dwordx4 %0, %1, %2 offen lds"
-        :
-        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
-        : "memory");
-}
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -508,91 +509,32 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
     }
 }
 
-// One unit (tile x token chunk). The loop body is uniform from the first stage to the last: a diagonal tile loads its
-// panel into both LDS panels (vB == vA), and stages past the end of the chunk are still requested (into slots nobody
-// reads; the buffer descriptor zero-fills past the end of X) and their first fragments still read — a few KiB per
-// unit of ~15 MB, in exchange for ONE loop with no branch: with 256 live accumulators any control flow inside the
-// unit made hipcc shuffle accumulators through scratch.
-template <int DT, int ABL>
-__device__ __forceinline__ void syrk4_unit(f32x16 (&acc)[4][4], LDS_AS char* lds, uint32_t lds_base, i32x4 rsrc,
-                                           uint32_t vA, uint32_t vB, uint32_t slab, uint32_t stage_bytes, int nst,
-                                           int wv, const int (&offA)[4], const int (&offB)[4], int lane) {
-    constexpr int PER = 8;              // LDS-DMA pieces per stage per wave
-    constexpr bool DMA = !(ABL & 1);
-    constexpr bool RD = !(ABL & 2);
-    // piece d of stage st: d = 0..3 A-panel KiB-block (d*4 + wv), d = 4..7 the same of the B panel
-    auto piece = [&](int st, auto dc) {
-        constexpr int d = decltype(dc)::value;
-        if constexpr (DMA) {
-            const uint32_t soff = (uint32_t)st * stage_bytes + (uint32_t)(d & 3) * slab;
-            const uint32_t dst = lds_base + (uint32_t)(st & (S4_RING - 1)) * S4_STAGE + (d >> 2) * S4_PANEL +
-                                 (uint32_t)((d & 3) * 4 + wv) * 1024;
-            dma16s(rsrc, d < 4 ? vA : vB, soff, dst);
-        }
-    };
-    s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
-    if constexpr (!RD) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (short)(lane * 8 + e + i);
-            asm volatile("" : "+v"(v));
-            fa0[i] = fb0[i] = fa1[i] = fb1[i] = v;
-        }
-    }
-    // fragment f of slice (st, kk): order A0 B0 B1 B2 B3 A1 A2 A3 (the first MFMAs of a burst need A0 and B*)
-    auto frag = [&](int st, int kk, auto fc, s16x8 (&fa)[4], s16x8 (&fb)[4]) {
-        constexpr int f = decltype(fc)::value;
-        if constexpr (RD) {
-            LDS_AS char* pa = lds + (st & (S4_RING - 1)) * S4_STAGE;
-            LDS_AS char* pb = pa + S4_PANEL;
-            if constexpr (f == 0) fa[0] = tr_frag(pa + offA[0], kk * 16 * TM * 2);
-            else if constexpr (f <= 4) fb[f - 1] = tr_frag(pb + offB[f - 1], kk * 16 * TM * 2);
-            else fa[f - 4] = tr_frag(pa + offA[f - 4], kk * 16 * TM * 2);
-        }
-    };
-    // one burst: 16 MFMAs on (fa, fb). Behind MFMA i: i in {0,1,2,4,5,6,8,9} -> the next fragment of slice
-    // (rd_st, rd_kk) into (na, nb) (all eight are back six MFMAs before the burst ends); i in {3,7,11,15} -> LDS-DMA
-    // piece dma_d0 + i/4 of stage dma_st (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread).
-    // No branch inside a burst; the order is pinned.
-    auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], int rd_st, int rd_kk,
-                     int dma_st, auto d0c) {
-        constexpr int D0 = decltype(d0c)::value;
-        static_for<0, 16>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            acc[i >> 2][i & 3] = Mfma<DT>::run(fa[i >> 2], fb[i & 3], acc[i >> 2][i & 3]);
-            if constexpr ((i & 3) == 3) piece(dma_st, std::integral_constant<int, D0 + (i >> 2)>{});
-            else if constexpr (i < 10) frag(rd_st, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    // prologue: stages 0..2 and the A half of stage 3 requested, stage 0 published, its first fragments fetched
-    for (int st = 0; st < S4_RING - 1; ++st) static_for<0, 8>([&](auto dc) { piece(st, dc); });
-    static_for<0, 4>([&](auto dc) { piece(S4_RING - 1, dc); });
-    dma_wait_upto<2 * PER + PER / 2>();
-    __builtin_amdgcn_s_barrier();
-    static_for<0, 8>([&](auto fc) { frag(0, 0, fc, fa0, fb0); });
-    for (int st = 0; st < nst; ++st) {
-        // slice 0 of stage st; fetches slice 1; requests the B half of stage st+3
-        burst(fa0, fb0, fa1, fb1, st, 1, st + S4_RING - 1, std::integral_constant<int, 4>{});
-        // this wave's pieces of stage st+1 have landed (st+2, st+3 may still be in flight); every wave has read
-        // the whole of stage st once its lgkmcnt(0) is behind the barrier
-        dma_wait_upto<2 * PER>();
-        lds_wait_all();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // slice 1; fetches slice 0 of stage st+1; requests the A half of stage st+4 into the slot stage st has left
-        burst(fa1, fb1, fa0, fb0, st + 1, 0, st + S4_RING, std::integral_constant<int, 0>{});
-    }
+// One LDS-DMA piece: LDS destination = immediate DST + the wave's KiB offset (an SGPR; M0 is written by the add and
+// is not live across statements in this kernel), source = rsrc.base + soff + voff[lane]; soff then advances by
+// `inc` for the piece's next stage — written a whole stage before it is read again, so no hazard padding.
+template <int DST, bool LOAD, bool ADVANCE>
+__device__ __forceinline__ void dma16w(i32x4 rsrc, uint32_t voff, uint32_t& soff, uint32_t inc, uint32_t wvoff) {
+    if constexpr (LOAD && ADVANCE)
+        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\ts_add_u32 %0, %0, %5"
+                     : "+s"(soff) : "v"(voff), "s"(rsrc), "s"(wvoff), "n"(DST), "s"(inc) : "memory", "scc");
+    else if constexpr (LOAD)
+        asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
+                     : "+s"(soff) : "v"(voff), "s"(rsrc), "s"(wvoff), "n"(DST) : "memory", "scc");
+    else
+        asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\ts_add_u32 %0, %0, %3"
+                     : "+s"(soff) : "s"(wvoff), "n"(DST), "s"(inc) : "memory", "scc");
 }
 
-template <int DT, int ABL>
+template <int DT, int NSLOT, int ABL>
 __global__ __launch_bounds__(S4_THREADS) void k_syrk4(SyrkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LDS_AS char* lds = (LDS_AS char*)smem;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // DMA destinations are immediates: dynamic LDS must start at 0
+    constexpr int PER = 8;                  // LDS-DMA pieces per stage per wave (4 per panel)
+    constexpr bool DMA = !(ABL & 1);
+    constexpr bool RD = !(ABL & 2);
+    constexpr bool ADV = !(ABL & 4);
+    constexpr bool LOAD = !(ABL & 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -607,20 +549,28 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(SyrkArgs a) {
     const int ch_off = (u_log * 4 + (c16 & 3)) * 8;
     const int64_t row_bytes = a.ldx * 2;
 
+    // fragment addresses: slot j lives at j * 32 KiB; the ds_read offset field reaches 64 KiB, so one base register
+    // per PAIR of slots (+ immediate 0 / 32 KiB) covers the ring
     const int p = lane & 15;
     const int trow = 8 * (lane >> 5) + (p >> 2);
     const int sub = 32 * ((lane >> 4) & 1) + 8 * (p & 3);
-    int offA[4], offB[4];
+    constexpr int NPAIR = (NSLOT + 1) / 2;
+    int offA[NPAIR][4], offB[NPAIR][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) offA[m] = trow * (TM * 2) + (((4 * wm + m) ^ (p >> 2)) << 6) + sub;
+    for (int pr = 0; pr < NPAIR; ++pr)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) offB[n] = trow * (TM * 2) + (((4 * wn + n) ^ (p >> 2)) << 6) + sub;
+        for (int m = 0; m < 4; ++m) {
+            offA[pr][m] = pr * 2 * S4_STAGE + trow * (TM * 2) + (((4 * wm + m) ^ (p >> 2)) << 6) + sub;
+            offB[pr][m] = pr * 2 * S4_STAGE + S4_PANEL + trow * (TM * 2) + (((4 * wn + m) ^ (p >> 2)) << 6) + sub;
+        }
 
     const int G = gridDim.x;
     const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int nunits = a.S * a.ntiles_p;
     const int nrounds = (nunits + G - 1) / G;
-    const int nst_total = (int)((a.T + S4_TOK - 1) / S4_TOK);
+    const uint32_t slab = (uint32_t)(8 * row_bytes);
+    const uint32_t stage_bytes = (uint32_t)(S4_TOK * row_bytes);
+    const uint32_t wvoff = (uint32_t)wv * 1024u;
 
     for (int round = 0; round < nrounds; ++round) {
         if (a.sync && round > 0) {
@@ -642,26 +592,24 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(SyrkArgs a) {
         const int ti = u - s * a.ntiles_p;
         const TileIdx t = decode_tile(ti, a.nb);
         if (!t.valid) continue;
-        // chunk boundaries in 64-token K-steps (same split as k_syrk: workspace layout and fixup are shared)
-        const int ks0 = (int)(((int64_t)s * a.nk) / a.S);
-        const int ks1 = (int)(((int64_t)(s + 1) * a.nk) / a.S);
+        // chunk boundaries in 64-token K-steps, aligned so that a chunk is a whole number of NSLOT-stage groups
+        const int ks0 = chunk_begin(s, a.nk, a.S, a.kalign);
+        const int ks1 = chunk_begin(s + 1, a.nk, a.S, a.kalign);
         const int st0 = 2 * ks0;
-        int st1 = 2 * ks1;
-        if (st1 > nst_total) st1 = nst_total;
-        const int nst = st1 - st0;
+        const int ngroups = (2 * (ks1 - ks0)) / NSLOT;
 
         const char* base = a.X + (int64_t)st0 * S4_TOK * row_bytes;
         int64_t rem_bytes = (a.T - (int64_t)st0 * S4_TOK) * row_bytes;
+        if (rem_bytes < 0) rem_bytes = 0;
         const uint32_t nrec = rem_bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)rem_bytes;
         i32x4 rsrc;
         rsrc[0] = (int)(uint32_t)(uintptr_t)base;
         rsrc[1] = (int)((uint32_t)((uintptr_t)base >> 32) & 0xffffu);
         rsrc[2] = (int)nrec;
         rsrc[3] = 0x00020000;
+        // a diagonal tile loads its panel into both LDS panels (vB == vA): the loop below never branches
         const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
         const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
-        const uint32_t slab = (uint32_t)(8 * row_bytes);
-        const uint32_t stage_bytes = (uint32_t)(S4_TOK * row_bytes);
 
         f32x16 acc[4][4];
 #pragma unroll
@@ -671,9 +619,100 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(SyrkArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-        syrk4_unit<DT, ABL>(acc, lds, lds_base, rsrc, vA, vB, slab, stage_bytes, nst, wv, offA, offB, lane);
-        lds_wait_all();                  // the trailing fragment reads
-        __builtin_amdgcn_s_barrier();    // ... of every wave, before the next unit's prologue overwrites the ring
+        if (ngroups > 0) {
+            // scalar source offsets, one per piece: sA[q] belongs to the A half, sB[q] to the B half of a stage
+            uint32_t sA[4], sB[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sA[q] = sB[q] = (uint32_t)q * slab;
+            // piece d of the stage in ring slot SL: d = 0..3 A-panel KiB-block (d*4 + wv), d = 4..7 the same of B
+            auto piece = [&](auto slc, auto dc) {
+                constexpr int SL = decltype(slc)::value;
+                constexpr int d = decltype(dc)::value;
+                if constexpr (DMA) {
+                    constexpr int DSTB = SL * S4_STAGE + (d >> 2) * S4_PANEL + (d & 3) * 4 * 1024;
+                    if constexpr (d < 4) dma16w<DSTB, LOAD, ADV>(rsrc, vA, sA[d & 3], stage_bytes, wvoff);
+                    else dma16w<DSTB, LOAD, ADV>(rsrc, vB, sB[d & 3], stage_bytes, wvoff);
+                }
+            };
+            s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+            if constexpr (!RD) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s16x8 v, w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = (short)(lane * 8 + e + i);
+                        // TOGGLE: bf16 bit patterns with random sign / mantissa / a few exponent bits, different in
+                        // every register set, so that consecutive MFMAs see changing operands without any LDS read
+                        uint32_t hsh = (uint32_t)(lane * 977 + e * 131 + i * 7919 + 12345) * 2654435761u;
+                        w[e] = (short)((hsh >> 16 & 0x83ff) | 0x3c00 | ((hsh >> 3) & 0x0300));
+                    }
+                    asm volatile("" : "+v"(v), "+v"(w));
+                    fa0[i] = fb0[i] = fa1[i] = fb1[i] = v;
+                    if constexpr (ABL & 16) {
+                        fa0[i] = w;
+                        fb0[i] = w ^ (short)0x1234;
+                        fa1[i] = w ^ (short)0x0777;
+                        fb1[i] = w ^ (short)0x4321;
+                        asm volatile("" : "+v"(fa0[i]), "+v"(fb0[i]), "+v"(fa1[i]), "+v"(fb1[i]));
+                    }
+                }
+            }
+            // fragment f of slice kk of the stage in slot SL: order A0 B0 B1 B2 B3 A1 A2 A3 (the serpentine walk
+            // starts every burst at (0, 0) and needs row m's A fragment from step 4m on)
+            auto frag = [&](auto slc, int kk, auto fc, s16x8 (&fa)[4], s16x8 (&fb)[4]) {
+                constexpr int SL = decltype(slc)::value;
+                constexpr int f = decltype(fc)::value;
+                if constexpr (RD) {
+                    constexpr int IMM = (SL & 1) * S4_STAGE;
+                    if constexpr (f == 0) fa[0] = tr_frag(lds + offA[SL >> 1][0], IMM + kk * 16 * TM * 2);
+                    else if constexpr (f <= 4) fb[f - 1] = tr_frag(lds + offB[SL >> 1][f - 1], IMM + kk * 16 * TM * 2);
+                    else fa[f - 4] = tr_frag(lds + offA[SL >> 1][f - 4], IMM + kk * 16 * TM * 2);
+                }
+            };
+            // one burst: 16 MFMAs on (fa, fb). Behind MFMA i: i in {0,1,2,4,5,6,8,9} -> the next fragment of slice kk
+            // of slot RSL into (na, nb) (all eight are back six MFMAs before the burst ends); i in {3,7,11,15} ->
+            // LDS-DMA piece D0 + i/4 of slot DSL (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread)
+            auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, int rd_kk,
+                             auto dslc, auto d0c) {
+                constexpr int D0 = decltype(d0c)::value;
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    // serpentine walk of the 4x4 accumulator block: one operand changes per step
+                    constexpr int mi = i >> 2, ni = (mi & 1) ? 3 - (i & 3) : (i & 3);
+                    acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
+                    if constexpr ((i & 3) == 3) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{});
+                    else if constexpr (i < 10) frag(rslc, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            // prologue: stages 0 .. NSLOT-2 and the A half of stage NSLOT-1 requested, stage 0 published
+            static_for<0, NSLOT - 1>([&](auto slc) { static_for<0, 8>([&](auto dc) { piece(slc, dc); }); });
+            static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, NSLOT - 1>{}, dc); });
+            dma_wait_upto<(NSLOT - 2) * PER + PER / 2>();
+            __builtin_amdgcn_s_barrier();
+            static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, 0, fc, fa0, fb0); });
+            for (int g = 0; g < ngroups; ++g) {
+                static_for<0, NSLOT>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;              // stage st = g*NSLOT + J sits in slot J
+                    constexpr int JN = (J + 1) % NSLOT;                 // slot of stage st+1
+                    constexpr int JP = (J + NSLOT - 1) % NSLOT;         // slot of stage st+NSLOT-1 (= st-1)
+                    // slice 0 of stage st; fetches slice 1; requests the B half of stage st+NSLOT-1
+                    burst(fa0, fb0, fa1, fb1, jc, 1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{});
+                    // this wave's pieces of stage st+1 have landed (NSLOT-2 later stages may still be in flight);
+                    // every wave has read the whole of stage st once its lgkmcnt(0) is behind the barrier
+                    dma_wait_upto<(NSLOT - 2) * PER>();
+                    lds_wait_all();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // slice 1; fetches slice 0 of stage st+1; requests the A half of stage st+NSLOT into slot J
+                    burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{});
+                });
+            }
+            lds_wait_all();                  // the trailing fragment reads
+            __builtin_amdgcn_s_barrier();    // ... of every wave, before the next unit's prologue overwrites the ring
+        }
 
         // partial tile in k_syrk's fragment order: wave (wm, wn) x accumulator (m, n) of the 2x2 / 4x4 layout is
         // wave (wm, 2*wn + n/2) x accumulator (m, n%2) of the 2x4 / 4x2 layout
@@ -690,7 +729,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(SyrkArgs a) {
                     int idx = ((((wv8 * 4 + m) * 2 + (n & 1)) * 4 + q) * 64 + lane);
                     *reinterpret_cast<f32x4*>(slot + (int64_t)idx * 4) = v;
                 }
-        // the stores share the VM counter with the next unit's LDS-DMA: drain them before counting again
+        // the stores share the VM counter with the next unit's LDS-DMA: drain them (and the trailing requests)
         dma_wait_all();
     }
 }
@@ -736,6 +775,10 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
             if (i0 + r < K) H[(int64_t)j * K + i0 + r] = o[r];
     }
 }
+
+// default kernel and the chunk alignment it needs (a chunk = whole ring groups: 4 stages = 2 K-steps, 5 stages -> 5)
+static constexpr int SYRK_DEFAULT_VARIANT = 4;
+static constexpr int SYRK_KALIGN = SYRK_DEFAULT_VARIANT == 5 ? 5 : 2;
 
 static inline int choose_chunks(int ntiles_real, int nk, int64_t x_bytes, int ncu) {
     // pick S >= Smin minimising a simple time model (microseconds):
@@ -802,14 +845,17 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     a.nk = nk;
     a.part = (float*)ws;
     a.sync = (unsigned*)((char*)ws + (size_t)S * ntp * TILE_FLOATS * sizeof(float));
+    a.kalign = SYRK_KALIGN;
+    if (const char* e = getenv("LLMC_SYRK_KALIGN")) a.kalign = atoi(e) > 0 ? atoi(e) : SYRK_KALIGN;   // lab: 10 suits both rings
     if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
     if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
     const int grid = device_cu_count();   // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous)
-    // Kernel variant. Default k_syrk4 (one wave per SIMD, 128x128 wave tiles); LLMC_SYRK_V=8 selects the 8-wave
-    // kernel, =2 its 4-stage ring, =88 its phase-split schedule. All variants produce identical partial tiles.
-    int variant = 4, abl = 0;
+    // Kernel variant. Default k_syrk4 (one wave per SIMD, 128x128 wave tiles) with a 4-slot ring; LLMC_SYRK_V=5 its
+    // 5-slot ring (all 160 KiB of LDS), =8 the 8-wave kernel, =2 its 4-stage ring, =88 its phase-split schedule.
+    // All variants produce identical partial tiles for the same chunk alignment.
+    int variant = SYRK_DEFAULT_VARIANT, abl = 0;
     if (const char* e = getenv("LLMC_SYRK_V")) variant = atoi(e);
-    if (const char* e = getenv("LLMC_SYRK_ABL")) abl = atoi(e) & 3;   // lab only (wrong results by design)
+    if (const char* e = getenv("LLMC_SYRK_ABL")) abl = atoi(e);   // lab only (wrong results by design)
     const bool bf = dt == LLMC_BF16;
     const void* fn = nullptr;
     int lds_bytes = SYRK_LDS, threads = SYRK_THREADS;
@@ -820,15 +866,28 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
         fn = bf ? (const void*)k_syrk<LLMC_BF16, true> : (const void*)k_syrk<LLMC_F16, true>;
     } else if (variant == 8) {
         fn = bf ? (const void*)k_syrk<LLMC_BF16, false> : (const void*)k_syrk<LLMC_F16, false>;
+    } else if (variant == 5) {
+        threads = S4_THREADS;
+        lds_bytes = 5 * S4_STAGE;
+        if (!bf) fn = (const void*)k_syrk4<LLMC_F16, 5, 0>;
+        else if (abl == 4) fn = (const void*)k_syrk4<LLMC_BF16, 5, 4>;
+        else if (abl == 1) fn = (const void*)k_syrk4<LLMC_BF16, 5, 1>;
+        else fn = (const void*)k_syrk4<LLMC_BF16, 5, 0>;
     } else {
         threads = S4_THREADS;
-        lds_bytes = S4_LDS;
-        if (!bf) fn = (const void*)k_syrk4<LLMC_F16, 0>;
-        else if (abl == 1) fn = (const void*)k_syrk4<LLMC_BF16, 1>;
-        else if (abl == 2) fn = (const void*)k_syrk4<LLMC_BF16, 2>;
-        else if (abl == 3) fn = (const void*)k_syrk4<LLMC_BF16, 3>;
-        else fn = (const void*)k_syrk4<LLMC_BF16, 0>;
+        lds_bytes = 4 * S4_STAGE;
+        if (!bf) fn = (const void*)k_syrk4<LLMC_F16, 4, 0>;
+        else if (abl == 1) fn = (const void*)k_syrk4<LLMC_BF16, 4, 1>;
+        else if (abl == 2) fn = (const void*)k_syrk4<LLMC_BF16, 4, 2>;
+        else if (abl == 3) fn = (const void*)k_syrk4<LLMC_BF16, 4, 3>;
+        else if (abl == 4) fn = (const void*)k_syrk4<LLMC_BF16, 4, 4>;
+        else if (abl == 8) fn = (const void*)k_syrk4<LLMC_BF16, 4, 8>;
+        else if (abl == 19) fn = (const void*)k_syrk4<LLMC_BF16, 4, 19>;
+        else if (abl == 18) fn = (const void*)k_syrk4<LLMC_BF16, 4, 18>;
+        else fn = (const void*)k_syrk4<LLMC_BF16, 4, 0>;
     }
+    LLMC_REQUIRE(a.kalign % 2 == 0 || variant == 5, "hessian_accum: chunk alignment must be even for 4-slot rings");
+    LLMC_REQUIRE(variant != 5 || a.kalign % 5 == 0, "hessian_accum: the 5-slot ring needs LLMC_SYRK_KALIGN % 5 == 0");
     int rc = ensure_dynamic_lds(fn, lds_bytes);
     if (rc) return rc;
     void* kargs[] = {(void*)&a};

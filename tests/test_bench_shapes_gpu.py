@@ -150,8 +150,9 @@ def test_hessian_kernel_variants_bit_identical(monkeypatch):
     T, K, n_seq = 16384, 2304, 8
     x = synth_x(T, K, torch.bfloat16, 5)
     monkeypatch.delenv('LLMC_SYRK_V', raising=False)
+    monkeypatch.setenv('LLMC_SYRK_KALIGN', '10')     # chunk boundaries that suit the 4- and the 5-slot ring alike
     H4 = run_hessian(x, n_seq).clone()
-    for v in ('8', '2', '88'):
+    for v in ('8', '2', '88', '4', '5'):
         monkeypatch.setenv('LLMC_SYRK_V', v)
         Hv = run_hessian(x, n_seq)
         assert torch.equal(H4, Hv), v

@@ -106,6 +106,7 @@ int main(int argc, char** argv) {
     L.red = (red_fn)dlsym(h, "llmc_hessian_accum_reduce");
     L.err = (err_fn)dlsym(h, "llmc_hip_last_error");
     if (!L.ws || !L.part || !L.red) { fprintf(stderr, "missing symbols\n"); return 1; }
+    setenv("LLMC_SYRK_KALIGN", "10", 0);   // chunk boundaries that suit the 4- and the 5-slot ring alike
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("# device %s, %d CUs\n", prop.gcnArchName, prop.multiProcessorCount);
@@ -139,13 +140,17 @@ int main(int argc, char** argv) {
             const char* fname = fill == 0 ? "zeros" : "randn";
             struct V { const char* name; const char* v; const char* abl; bool check; };
             std::vector<V> vs = {{"k_syrk 8-wave", "8", nullptr, false},
-                                 {"k_syrk4", "4", nullptr, true},
-                                 {"k_syrk ph8", "88", nullptr, true},
-                                 {"k_syrk2 ring", "2", nullptr, true},
-                                 {"k_syrk4 no-dma", "4", "1", false},
-                                 {"k_syrk4 no-read", "4", "2", false},
-                                 {"k_syrk4 mfma-only", "4", "3", false}};
-            if (K > 4096) vs.resize(2);
+                                 {"k_syrk4 ring4", "4", nullptr, true},
+                                 {"k_syrk4 ring5", "5", nullptr, true},
+                                 {"ring4 no-dma", "4", "1", false},
+                                 {"ring4 dma-L2res", "4", "4", false},
+                                 {"ring5 dma-L2res", "5", "4", false},
+                                 {"ring4 dma-noload", "4", "8", false},
+                                 {"ring4 no-read", "4", "2", false},
+                                 {"ring4 mfma-only", "4", "3", false},
+                                 {"mfma-only toggle", "4", "19", false},
+                                 {"no-read toggle", "4", "18", false}};
+            if (K > 4096) vs.resize(3);
             for (size_t i = 0; i < vs.size(); ++i) {
                 const V& v = vs[i];
                 float* H = i == 0 ? H0 : H1;
