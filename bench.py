@@ -4,19 +4,27 @@
 One "step" = GPTQ of one transformer block's seven Linear layers (q,k,v,o,gate,up,down; four distinct
 inputs) from 128 x 2048 resident calibration tokens: Hessian (MFMA) -> actorder/dead/damp -> Cholesky +
 inverse -> blocked column loop -> scales/zeros/compensated weights.  Synthetic inputs.
-N > 1: one process per GPU (torchrun), every rank quantizes its own blocks (layer-sharded, no data-path
-collective); value = layers of all ranks / max-over-ranks time.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 without a launcher: bench.py re-executes itself under `python -m torch.distributed.run` with N ranks (one per
+GPU, RCCL); under a launcher (WORLD_SIZE set) it is a rank.
+  --mode independent (default, weak scaling): every rank quantizes its own blocks, no data-path collective;
+          value = layers of all ranks / max-over-ranks time.
+  --mode cooperative (strong scaling): all ranks work on ONE block per step (llmc_amd/dist/layer_shard.py):
+          subsets with K <= 8192 — rank 0 broadcasts the Hessian (layers sharing an input) or the activations over
+          RCCL and the subset's layers are dealt round-robin; wider subsets (down_proj) — every rank accumulates the
+          Hessian of its own sequences, ONE all_reduce, redundant factorisation, row-sharded column loop, all_gather.
+  --dry   GPU-less plumbing check (gloo, CPU stand-ins instead of kernels, tiny shapes): spawn, collectives, timing
+          and the JSON line are exercised by tests/test_bench_spawn.py; the number it prints means nothing.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value + roofline + cpu_baseline.
 """
 import argparse
 import json
-import math
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,7 +48,53 @@ def block_groups(model):
             ('down_in', ffn, [('down_proj', h)])]
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--model', default='llama3-8b', choices=list(MODELS))
+    ap.add_argument('--n-seq', type=int, default=128)
+    ap.add_argument('--seq-len', type=int, default=2048)
+    ap.add_argument('--calib-bs', type=int, default=128,
+                    help='sequences per add_batch call (reference calib.bs; 128 = one call per input, 1 = the '
+                         "reference config's per-sample hook calls)")
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
+                    help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
+                         'vllm: sym g128 static groups + INT4 pack (configs/quantization/backend/vllm/gptq_w4a16.yml)')
+    ap.add_argument('--mode', default='independent', choices=['independent', 'cooperative'])
+    ap.add_argument('--overlap', type=int, default=4,
+                    help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); '
+                         '0 = one after the other on the current stream')
+    ap.add_argument('--dry', action='store_true', help='GPU-less plumbing check (gloo + CPU stand-ins)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# self-spawn: `python bench.py --gpus N` on a bare shell launches N ranks of itself
+# ---------------------------------------------------------------------------------------------------------------
+def maybe_spawn(args):
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return None
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------
 def synth_weight(R, K, seed, device, dtype):
+    import torch
     g = torch.Generator(device=device).manual_seed(1000 + seed)
     w = torch.randn(R, K, generator=g, device=device, dtype=torch.float32) * 0.02
     n_out = max(1, K // 1000)
@@ -50,6 +104,7 @@ def synth_weight(R, K, seed, device, dtype):
 
 
 def synth_acts(n_seq, seq, K, seed, device, dtype):
+    import torch
     g = torch.Generator(device=device).manual_seed(2000 + seed)
     c = torch.exp(0.5 * torch.randn(K, generator=g, device=device))
     idx = torch.randperm(K, generator=g, device=device)[:8]
@@ -62,17 +117,53 @@ def synth_acts(n_seq, seq, K, seed, device, dtype):
     return x
 
 
-def cpu_baseline(model, n_seq, seq, cfg):
-    """The oracle (a CPU port of the reference path) timed on the host cores on a bounded sample."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference itself (oracle/_ref, built by __graft_entry__.build()) or, failing that, the port
+# ---------------------------------------------------------------------------------------------------------------
+def _block_model(model, n_seq, t_h_seq, t_chol, t_loop, K):
+    """One block as the reference executes it (7 Hessians / factorisations / loops), pieces scaled by flop count."""
+    t_block, layers = 0.0, 0
+    for _, k, ls in block_groups(model):
+        for _, r in ls:
+            t_block += t_h_seq * n_seq * (k / K) ** 2 + t_chol * (k / K) ** 3 + t_loop * (r / K) * (k / K) ** 2
+            layers += 1
+    return layers / t_block
+
+
+def cpu_baseline_reference(model, n_seq, seq):
+    cores = os.cpu_count() or 1
+    h = MODELS[model][0]
+    K = min(h, 4096)
+    nb = 4
+    script = os.path.join(ROOT, 'oracle', 'ref_baseline.py')
+    if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'llmc')):
+        raise RuntimeError('oracle/_ref missing (built by __graft_entry__.build() where /root/reference exists)')
+    r = subprocess.run([sys.executable, script, '--K', str(K), '--seq', str(seq), '--batches', str(nb)],
+                       capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    if r.returncode != 0 or not line:
+        raise RuntimeError('reference baseline failed: ' + (r.stderr or r.stdout)[-400:])
+    t = json.loads(line[-1])
+    return {
+        'value': _block_model(model, n_seq, t['t_hessian_per_seq'], t['t_factor'], t['t_loop'], K),
+        'unit': 'layers/s', 'cores': t['threads'], 'kind': 'reference',
+        'sample': (f"llmc's own GPTQ (oracle/_ref = /root/reference after its ci_check/change_files.py CPU rewrite), torch "
+                   f"CPU on {t['threads']} threads: add_batch on {nb} of {n_seq} sequences of one {K}-channel input "
+                   f"({t['t_hessian_per_seq']:.3f} s/seq), process_hessian_and_weights ({t['t_factor']:.2f} s) and "
+                   f"weight_transform ({t['t_loop']:.2f} s) of one {K}x{K} layer in full; other shapes scaled by flop "
+                   'count; 7 Hessians per block as the reference executes them'),
+    }
+
+
+def cpu_baseline_port(model, n_seq, seq, cfg):
+    """Fallback: the oracle (a CPU port of the reference path) timed on the host cores on a bounded sample."""
     import numpy as np
 
     from oracle import gptq_ref as G
     from oracle import quant_ref as Q
     cores = os.cpu_count() or 1
-    h, kv, ffn, _ = MODELS[model]
-    K = min(h, 4096)
+    K = min(MODELS[model][0], 4096)
     rng = np.random.RandomState(0)
-    # Hessian: 4 sequences of the K-channel input (fp32 sgemm like the reference), scaled to n_seq
     nb = 4
     H = np.zeros((K, K), dtype=np.float32)
     n = 0
@@ -91,113 +182,236 @@ def cpu_baseline(model, n_seq, seq, cfg):
     t0 = time.time()
     G.weight_transform(Wp, U, cfg.symmetric, qmin, qmax, cfg.group_size)
     t_loop = time.time() - t0
-    # model of one block, as the reference executes it (7 Hessians / factorisations / loops per block),
-    # scaling the measured K-wide pieces by their flop counts
-    def hess(k):
-        return t_h_seq * n_seq * (k / K) ** 2
-
-    def chol(k):
-        return t_chol * (k / K) ** 3
-
-    def loop(r, k):
-        return t_loop * (r / K) * (k / K) ** 2
-
-    t_block = 0.0
-    layers = 0
-    for _, k, ls in block_groups(model):
-        for _, r in ls:
-            t_block += hess(k) + chol(k) + loop(r, k)
-            layers += 1
     return {
-        'value': layers / t_block, 'unit': 'layers/s', 'cores': cores, 'kind': 'port',
+        'value': _block_model(model, n_seq, t_h_seq, t_chol, t_loop, K), 'unit': 'layers/s', 'cores': cores,
+        'kind': 'port',
         'sample': (f'numpy/C oracle on {cores} host threads: Hessian = {nb} of {n_seq} sequences of one {K}-channel '
                    f'input ({t_h_seq:.3f} s/seq), factorisation ({t_chol:.2f} s) and column loop ({t_loop:.2f} s) of '
-                   f'one {K}x{K} layer in full; other shapes scaled by flop count; 7 Hessians per block as the '
-                   'reference executes them'),
+                   f'one {K}x{K} layer in full; other shapes scaled by flop count'),
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--model', default='llama3-8b', choices=list(MODELS))
-    ap.add_argument('--n-seq', type=int, default=128)
-    ap.add_argument('--seq-len', type=int, default=2048)
-    ap.add_argument('--calib-bs', type=int, default=128,
-                    help='sequences per Hessian launch (reference calib.bs; 128 = one launch per input)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
-    ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
-                    help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
-                         'vllm: sym g128 static groups + INT4 pack (configs/quantization/backend/vllm/gptq_w4a16.yml)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+def cpu_baseline(model, n_seq, seq, cfg):
+    try:
+        return cpu_baseline_reference(model, n_seq, seq)
+    except Exception as e:
+        out = cpu_baseline_port(model, n_seq, seq, cfg)
+        out['sample'] += f' [reference baseline unavailable: {type(e).__name__}: {str(e)[:120]}]'
+        return out
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# compute back ends: the HIP path (product) and CPU stand-ins for --dry
+# ---------------------------------------------------------------------------------------------------------------
+class HipOps:
+    """The product path: llmc_amd classes over libllmc_hip.so. Raises without an MI355X."""
+
+    def __init__(self, dev, cfg, variant):
+        import torch
+
+        from llmc_amd.compression.quantization import IntegerQuantizer, pack_lsb
+        from llmc_amd.compression.quantization import gptq_pipeline as P
+        from llmc_amd.compression.quantization.hessian import HessianAccumulator
+        self.torch, self.dev, self.cfg, self.variant = torch, dev, cfg, variant
+        self.P, self.Acc, self.pack_lsb = P, HessianAccumulator, pack_lsb
+        self.wq = IntegerQuantizer(cfg.bit, cfg.symmetric, 'per_group', group_size=cfg.group_size)
+        self.accs, self.hwork, self.streams = {}, {}, {}
+        self.timing = None
+
+    def acc(self, name, K):
+        if name not in self.accs:
+            self.accs[name] = self.Acc(K, self.dev)
+            self.hwork[name] = self.torch.empty((K, K), dtype=self.torch.float32, device=self.dev)
+        a = self.accs[name]
+        a.timing = self.timing
+        return a
+
+    def hessian(self, name, K, x, calib_bs):
+        a = self.acc(name, K)
+        a.reset()
+        for i in range(0, x.shape[0], calib_bs):
+            a.add(x[i:i + calib_bs])
+        return a.H
+
+    def static_qparams(self, weights):
+        if not self.cfg.static_groups:
+            return None
+        out = []   # collect_block_qparams (base_blockwise_quantization.py:338-365): RTN qparams of the original weights
+        for w in weights:
+            _, s, z, _, _ = self.wq.get_tensor_qparams(w)
+            out.append((s, None if self.cfg.symmetric else z))
+        return out
+
+    def quantize(self, name, weights, H, rows=None):
+        static = self.static_qparams(weights)
+        res = self.P.quantize_stacked(weights, H, self.cfg, static_qparams=static, h_work=self.hwork.get(name), rows=rows)
+        outs = [{'weight': r.weight, 'scales': r.scales, 'zeros': r.zeros, 'perm': r.perm, 'loss': r.loss} for r in res]
+        if self.variant == 'vllm' and rows is None:
+            for r, (s, _) in zip(res, static):
+                a = {'scales': s, 'zeros': self.torch.tensor(0.0), 'qmax': self.wq.qmax, 'qmin': self.wq.qmin}
+                codes, _, _ = self.wq.real_quant_weight_static(r.weight, a)     # GPTQ.w_q (gptq.py:412-422)
+                outs.append(self.pack_lsb(codes, self.cfg.bit))
+        return outs
+
+    def stream(self, i):
+        if i not in self.streams:
+            self.streams[i] = self.torch.cuda.Stream(device=self.dev)
+        return self.streams[i]
+
+    def helper_streams(self, enable):
+        from llmc_amd import _ffi
+        return _ffi.helper_streams(enable)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+class DryOps:
+    """CPU stand-ins with the same call shapes (plumbing check only: no kernel, no parity claim)."""
+
+    def __init__(self, cfg):
+        import torch
+        self.torch, self.cfg, self.timing = torch, cfg, None
+
+    def hessian(self, name, K, x, calib_bs):
+        xf = x.reshape(-1, K).float()
+        return (xf.T @ xf) * (2.0 / x.shape[0])
+
+    def quantize(self, name, weights, H, rows=None):
+        w = self.torch.cat([t.float() for t in weights], 0)
+        if rows is not None:
+            w = w[rows[0]:rows[1]]
+        s = w.abs().amax(1, keepdim=True).clamp(min=1e-5) / 7
+        return [{'weight': (w / s).round().clamp(-8, 7) * s + 0 * H.diagonal().mean()}]
+
+    def stream(self, i):
+        return None
+
+    def sync(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    rc = maybe_spawn(args)
+    if rc is not None:
+        sys.exit(rc)
+
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback in llmc_amd)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if args.gpus != world and 'WORLD_SIZE' in os.environ and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but launcher world size is {world}; using {world}', file=sys.stderr)
+    if args.dry:
+        dev = torch.device('cpu')
+        args.model, args.n_seq, args.seq_len = 'tiny', max(world, 4), 64
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X (no CPU fallback in llmc_amd); --dry checks the plumbing only')
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f'rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.dry:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
-    from llmc_amd.compression.quantization import IntegerQuantizer, pack_lsb
-    from llmc_amd.compression.quantization.gptq_pipeline import GptqConfig, quantize_stacked
-    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    from llmc_amd.compression.quantization.gptq_pipeline import GptqConfig
+    from llmc_amd.dist import layer_shard as LS
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
+    if args.dry:
+        dtype = torch.float32
     if args.variant == 'w_only':
         cfg = GptqConfig(bit=4, symmetric=False, group_size=128, actorder=True, static_groups=False)
     else:
         cfg = GptqConfig(bit=4, symmetric=True, group_size=128, actorder=True, static_groups=True)
     groups = block_groups(args.model)
-
-    # ---- resident synthetic data (different seeds per rank: every rank owns different blocks)
-    acts, weights, accs, hwork = {}, {}, {}, {}
-    for gi, (name, K, layers) in enumerate(groups):
-        acts[name] = synth_acts(args.n_seq, args.seq_len, K, rank * 64 + gi, dev, dtype)
-        weights[name] = [synth_weight(R, K, rank * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
-        accs[name] = HessianAccumulator(K, dev)
-        hwork[name] = torch.empty((K, K), dtype=torch.float32, device=dev)
-    wq = IntegerQuantizer(cfg.bit, cfg.symmetric, 'per_group', group_size=cfg.group_size)
+    ops = DryOps(cfg) if args.dry else HipOps(dev, cfg, args.variant)
+    coop = args.mode == 'cooperative' and world > 1
     n_layers_block = sum(len(ls) for _, _, ls in groups)
+
+    # ---- resident synthetic data. independent: every rank owns different blocks (different seeds).
+    # cooperative: one block; rank 0 holds the full activations of the broadcast subsets, every rank holds its own
+    # sequences (rank::world) of the sample-sharded ones; weights are the same on every rank (same seed).
+    acts, weights, plan = {}, {}, {}
+    for gi, (name, K, layers) in enumerate(groups):
+        seed_r = 0 if coop else rank
+        plan[name] = ('sample' if K > 8192 else 'broadcast') if coop else 'local'
+        if plan[name] == 'sample':
+            n_mine = len(range(rank, args.n_seq, world))
+            acts[name] = synth_acts(n_mine, args.seq_len, K, 64 * rank + gi, dev, dtype)
+        elif plan[name] == 'broadcast':
+            acts[name] = synth_acts(args.n_seq, args.seq_len, K, gi, dev, dtype) if rank == 0 else None
+        else:
+            acts[name] = synth_acts(args.n_seq, args.seq_len, K, seed_r * 64 + gi, dev, dtype)
+        weights[name] = [synth_weight(R, K, seed_r * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
 
     timing = []
 
-    def step(record):
+    def step_independent(record):
+        ops.timing = timing if record else None
+        outs = []
+        Hs = {}
+        for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
+            Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+        if args.overlap <= 1 or args.dry:
+            for name, K, layers in groups:
+                outs.append(ops.quantize(name, weights[name], Hs[name]))
+            return outs
+        # the four subsets' factorisations and column loops are independent latency-bound chains: one stream each,
+        # widest first (its chain is the longest)
+        cur = torch.cuda.current_stream()
+        order = sorted(range(len(groups)), key=lambda i: -groups[i][1] * sum(r for _, r in groups[i][2]))
+        evs = []
+        for si, gi in enumerate(order):
+            name = groups[gi][0]
+            st = ops.stream(si % args.overlap)
+            if si < args.overlap:
+                st.wait_stream(cur)
+            # one stream per chain and no internal helper streams: measured 94.5 ms/step, against 96.3 with a helper for
+            # the longest chain and 108 without overlap (more streams than hardware queues start to serialise)
+            with torch.cuda.stream(st), ops.helper_streams(False):
+                outs.append(ops.quantize(name, weights[name], Hs[name]))
+            evs.append(st)
+        for st in set(evs):
+            cur.wait_stream(st)
+        return outs
+
+    def step_cooperative(record):
+        ops.timing = timing if record else None
         outs = []
         for name, K, layers in groups:
-            acc = accs[name]
-            acc.timing = timing if record else None
-            acc.reset()
-            x = acts[name]
-            for i in range(0, args.n_seq, args.calib_bs):
-                acc.add(x[i:i + args.calib_bs])
-            static = None
-            if cfg.static_groups:
-                # collect_block_qparams (base_blockwise_quantization.py:338-365): RTN qparams of the original weights
-                static = []
-                for w in weights[name]:
-                    _, s, z, _, _ = wq.get_tensor_qparams(w)
-                    static.append((s, None if cfg.symmetric else z))
-            res = quantize_stacked(weights[name], acc.H, cfg, static_qparams=static, h_work=hwork[name])
-            if args.variant == 'vllm':
-                for r, (s, _) in zip(res, static):
-                    a = {'scales': s, 'zeros': torch.tensor(0.0), 'qmax': wq.qmax, 'qmin': wq.qmin}
-                    codes, _, _ = wq.real_quant_weight_static(r.weight, a)     # GPTQ.w_q (gptq.py:412-422)
-                    outs.append(pack_lsb(codes, cfg.bit))
-            outs.append(res)
+            shape = (args.n_seq, args.seq_len, K)
+            if plan[name] == 'sample':
+                outs.append(LS.run_subset_sample_sharded(
+                    acts[name], weights[name],
+                    hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs),
+                    quantize_rows_fn=lambda ws, H, rows, n=name: ops.quantize(n, ws, H, rows=rows)))
+            else:
+                ids = list(range(len(layers)))
+                share = 'hessian' if len(layers) > 1 else 'activations'
+                outs.append(LS.run_block_cooperative(
+                    ids, acts[name], 0,
+                    lambda li, shared, n=name, k=K, sh=share: ops.quantize(
+                        n + str(li), [weights[n][li]],
+                        shared if sh == 'hessian' else ops.hessian(n, k, shared, args.calib_bs)),
+                    (shape, dtype, dev), share=share,
+                    hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=0, to_cpu=False))
         return outs
+
+    step = step_cooperative if coop else step_independent
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        ops.sync()
 
     for _ in range(args.warmup):
         step(False)
@@ -212,49 +426,58 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- roofline of the dominant kernel (k_syrk), HIP events on the launch stream, this rank
-    fl = sum(T * K * (K + 1) for (_, _, T, K) in timing)
-    ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _) in timing)
+    # ---- roofline of the dominant kernel (k_syrk4), HIP events on the launch stream, this rank
+    fl = sum(T * K * (K + 1) for (_, _, _, T, K) in timing)
+    ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _, _) in timing)
+    ms_fix = sum(e1.elapsed_time(e2) for (_, e1, e2, _, _) in timing)
     n_launch = len(timing)
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    achieved_fix = fl / ((ms + ms_fix) * 1e-3) / 1e12 if ms > 0 else 0.0
 
     # HBM-side bytes of the dominant kernel come from PMC passes that cannot run inside the timed process
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_bench.sh); the committed summary is reported with its source.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
     if args.model == 'llama3-8b' and args.n_seq == 128 and args.seq_len == 2048 and args.calib_bs == 128 \
             and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))['k_syrk']
-            traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json (' + tj['note'] + ')'
+            traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic.json (' + tj['note'] + ')'
         except Exception:
             traffic = None
 
     if rank == 0:
-        total_layers = n_layers_block * args.steps * world
+        layers_step = n_layers_block * (1 if coop else world)
+        total_layers = layers_step * args.steps
         out = {
             'metric': 'layers/sec (GPTQ W4A16, %s Linear shapes, %dx%d calib)' % (
                 {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B'}.get(args.model, args.model), args.n_seq,
                 args.seq_len),
             'value': total_layers / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'scaling': 'strong' if coop else 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'dry-run (CPU stand-ins, no kernels): plumbing only' if args.dry else 'synthetic',
             'config': {
                 'workload': (f'GPTQ W4A16 g128 ({args.variant}) on {args.model}-shaped random-init Linear layers, '
-                             f'1 transformer block (7 Linear, 4 distinct inputs) per step per GPU'),
+                             + ('1 transformer block (7 Linear, 4 distinct inputs) per step shared by all GPUs'
+                                if coop else '1 transformer block (7 Linear, 4 distinct inputs) per step per GPU')),
                 'n_seq': args.n_seq, 'seq_len': args.seq_len, 'calib_bs': args.calib_bs,
                 'symmetric': cfg.symmetric, 'actorder': cfg.actorder, 'static_groups': cfg.static_groups,
-                'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU',
+                'subset_overlap_streams': 0 if (args.dry or coop) else args.overlap,
+                'parallelism': ('single GPU' if world == 1 else
+                                (f'cooperative x{world}: Hessian/activation broadcast + sample-sharded all_reduce, '
+                                 'row-sharded column loop' if coop else f'layer-sharded x{world}')),
             },
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                 'frac': achieved * 1e12 / PEAK_MFMA_16BIT, 'traffic': traffic, 'traffic_source': traffic_src,
-                'kernel': 'k_syrk (llmc_hessian_accum_partials)', 'launches': n_launch,
+                'kernel': 'k_syrk4 (llmc_hessian_accum_partials)', 'launches': n_launch,
                 'algorithmic_flops_per_launch': fl / max(1, n_launch),
                 'avg_launch_ms': ms / max(1, n_launch),
+                'achieved_incl_fixup': achieved_fix, 'avg_fixup_ms': ms_fix / max(1, n_launch),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dry:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.model, args.n_seq, args.seq_len, cfg)
             except Exception as e:  # the baseline must never take the GPU number down with it

@@ -48,6 +48,13 @@ int llmc_hip_abi_version(void);
 /* copies the last HIP error string of the calling thread into buf (NUL-terminated); returns its length */
 int llmc_hip_last_error(char* buf_host, size_t n);
 
+/* Per calling-thread switch: may llmc_chol_inv_upper / llmc_gptq_quantize use an internal low-priority helper stream
+ * to overlap their large trailing updates with their latency-bound chains (default 1)? A caller that already runs
+ * several of them side by side on its own streams (the subsets of a block) turns it off for all but the longest
+ * chain: every entry point still completes, in stream order, on the stream it was given. Returns the previous value.
+ * No reference counterpart (the reference runs one default stream). */
+int llmc_hip_set_helper_streams(int enable);
+
 /* ------------------------------------------------------------------------------------------------
  * Quantizer arithmetic (llmc/compression/quantization/quant.py)
  * ---------------------------------------------------------------------------------------------- */

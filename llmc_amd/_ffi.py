@@ -20,6 +20,7 @@ _i64, _i32, _f32, _f64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_double, C.
 SIGNATURES = {
     'llmc_hip_abi_version': (_i32, []),
     'llmc_hip_last_error': (_i32, [C.c_char_p, _sz]),
+    'llmc_hip_set_helper_streams': (_i32, [_i32]),
     'llmc_minmax_qparams_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_minmax_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     'llmc_mse_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -135,3 +136,18 @@ def workspace(nbytes, device):
     if nbytes <= 0:
         return None
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+class helper_streams:
+    """with _ffi.helper_streams(False): ...  — K3/K4 entry points called inside keep all their work on the caller's
+    stream (llmc_hip_set_helper_streams): for callers that overlap several subsets on streams of their own."""
+
+    def __init__(self, enable):
+        self.enable = int(bool(enable))
+
+    def __enter__(self):
+        self.prev = lib().llmc_hip_set_helper_streams(self.enable)
+
+    def __exit__(self, *exc):
+        lib().llmc_hip_set_helper_streams(self.prev)
+        return False

@@ -51,7 +51,7 @@ def chol_inv_upper(H, check=True):
     L = _ffi.lib()
     K = H.shape[0]
     need = L.llmc_chol_inv_upper_ws_bytes(K)
-    key = (H.device, )
+    key = (H.device, _ffi.stream())          # one workspace per stream: factorisations on different streams may overlap
     ws = _chol_ws.get(key)
     if ws is None or ws.numel() < need + 256:
         ws = torch.empty(need + 256, dtype=torch.uint8, device=H.device)

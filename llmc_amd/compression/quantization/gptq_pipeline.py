@@ -52,14 +52,25 @@ def factor_from_hessian(H, cfg, h_work=None):
     return perm, U
 
 
-def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_losses=True):
+def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_losses=True, rows=None):
     """W_list: weights [R_i, K] (model dtype or fp32) of layers sharing the input whose Hessian is H.
     static_qparams: list of (scales [R_i, ng], zeros [R_i, ng] | None) in ORIGINAL column order, required
-    when cfg.static_groups or per_channel. Returns a list of GptqResult."""
+    when cfg.static_groups or per_channel. Returns a list of GptqResult.
+    rows = (r0, r1): quantize only that row range of the stacked matrix (row-sharded multi-GPU mode: rows are
+    independent given Hinv); the result is ONE GptqResult for the slice."""
     _ffi.require_gpu(H, *W_list)
     K = H.shape[0]
-    rows = [w.shape[0] for w in W_list]
     Wcat = torch.cat([w.reshape(w.shape[0], -1) for w in W_list], dim=0) if len(W_list) > 1 else W_list[0]
+    if rows is not None:
+        if static_qparams is not None:
+            sc = torch.cat([s.reshape(w.shape[0], -1) for (s, _), w in zip(static_qparams, W_list)], 0)[rows[0]:rows[1]]
+            zr = None
+            if static_qparams[0][1] is not None:
+                zr = torch.cat([z.reshape(w.shape[0], -1) for (_, z), w in zip(static_qparams, W_list)], 0)[rows[0]:rows[1]]
+            static_qparams = [(sc, zr)]
+        W_list = [Wcat[rows[0]:rows[1]]]
+        Wcat = W_list[0]
+    rows = [w.shape[0] for w in W_list]
     # dead flags must come from the un-fixed diagonal, so W is gathered in the same call that fixes H
     perm = None
     if cfg.actorder:

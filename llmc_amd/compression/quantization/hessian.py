@@ -13,7 +13,7 @@ class HessianAccumulator:
         self.H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
         self.nsamples = 0
         self._ws = None
-        self.timing = None   # optional list of (start_event, end_event, T) around the MFMA kernel
+        self.timing = None   # optional list of (e0, e1, e2, T, K): e0..e1 around the MFMA kernel, e1..e2 the reduction
 
     def add(self, inp):
         _ffi.require_gpu(inp)
@@ -41,10 +41,13 @@ class HessianAccumulator:
                    'llmc_hessian_accum_partials')
         if self.timing is not None:
             e1.record()
-            self.timing.append((e0, e1, T, K))
         _ffi.check(L.llmc_hessian_accum_reduce(_ffi.ptr(self.H), T, K, ldx, float(self.nsamples),
                                                float(self.nsamples + b), _ffi.ptr(self._ws), st),
                    'llmc_hessian_accum_reduce')
+        if self.timing is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record()
+            self.timing.append((e0, e1, e2, T, K))
         self.nsamples += b
         return self.H
 

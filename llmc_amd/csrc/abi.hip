@@ -6,6 +6,8 @@
 
 namespace llmc {
 static thread_local char g_last_error[512] = "";
+static thread_local int g_helper_streams = 1;
+bool helper_streams_enabled() { return g_helper_streams != 0; }
 
 void set_last_error(const char* where, hipError_t e) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
@@ -42,6 +44,12 @@ int ensure_dynamic_lds(const void* fn, int bytes) {
     return LLMC_OK;
 }
 }  // namespace llmc
+
+extern "C" int llmc_hip_set_helper_streams(int enable) {
+    int prev = llmc::g_helper_streams;
+    llmc::g_helper_streams = enable ? 1 : 0;
+    return prev;
+}
 
 extern "C" int llmc_hip_abi_version(void) { return LLMC_HIP_ABI_VERSION; }
 

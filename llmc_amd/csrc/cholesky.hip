@@ -524,7 +524,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     // beyond it receive ONE symmetric update with Kd = 512 per outer block, which is where the flops are and
     // runs the fp32-MFMA GEMM at its long-K efficiency instead of its short-K one (tools/bench_sgemm.py).
     const int NBO = 4 * NB;
-    SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
+    SideStream* side = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : side_stream_for(st);
     bool pending_side = false;
     // The large products of K3 (far updates, triangular-inverse levels >= 512) run as split-bf16 products on the 16-bit
     // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on

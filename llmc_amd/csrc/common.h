@@ -42,7 +42,8 @@ void set_last_error_msg(const char* msg);
 // per-device facts / attributes (abi.hip; mutex-guarded, safe from several host threads)
 static constexpr int LLMC_MAX_DEVICES = 64;
 int device_cu_count();                                  // CUs of the current device (256 on MI355X)
-int ensure_dynamic_lds(const void* fn, int bytes);      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
+int ensure_dynamic_lds(const void* fn, int bytes);
+bool helper_streams_enabled();                          // llmc_hip_set_helper_streams (per calling thread)      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
 
 static inline int dtype_size(int dt) { return dt == LLMC_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == LLMC_F16 || dt == LLMC_BF16 || dt == LLMC_F32; }

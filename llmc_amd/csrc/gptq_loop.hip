@@ -457,7 +457,7 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
     hipStream_t st = (hipStream_t)stream;
     const int ELD = BS * GRP;
     float* ErrBuf[2] = {(float*)ws, (float*)ws + (size_t)R * ELD};   // [R, GRP*128] x 2: err columns of a group
-    SideStream* side = getenv("LLMC_NO_SIDE_STREAM") ? nullptr : side_stream_for_current_device();
+    SideStream* side = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : side_stream_for(st);
     bool pending_side = false;
     const int force_generic = getenv("LLMC_GPTQ_GENERIC") ? 1 : 0;
     // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as

@@ -3,7 +3,9 @@
 // block (look-ahead). All work is fenced back into the caller's stream before the entry point returns, so the
 // C ABI keeps its contract: the call is complete, in stream order, on the stream that was passed in.
 #pragma once
+#include <map>
 #include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace llmc {
@@ -21,23 +23,28 @@ struct SideStream {
     }
 };
 
-// returns nullptr when helper resources cannot be created (callers then run everything on the main stream)
-inline SideStream* side_stream_for_current_device() {
-    static SideStream pool[LLMC_MAX_DEVICES];   // `inline`: one pool per process, shared by every TU
+// One helper stream per (device, caller stream): concurrent entry points on different caller streams (the subsets of
+// a block factorised side by side) must not share a helper, or each one's join would wait for the others' work.
+// Returns nullptr when helper resources cannot be created (callers then run everything on the main stream).
+inline SideStream* side_stream_for(hipStream_t main_st) {
+    static std::map<std::pair<int, hipStream_t>, SideStream*> pool;   // `inline`: one pool per process
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LLMC_MAX_DEVICES) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    SideStream* s = &pool[dev];
-    if (!s->ok) {
-        // lowest priority: the caller's stream carries the latency-bound critical path and must win the dispatcher
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-        if (hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
-        for (int i = 0; i < 8; ++i)
-            if (hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        s->ok = true;
-    }
+    auto key = std::make_pair(dev, main_st);
+    auto it = pool.find(key);
+    if (it != pool.end()) return it->second->ok ? it->second : nullptr;
+    if (pool.size() >= 64) return nullptr;                             // bounded: callers cycle through few streams
+    SideStream* s = new SideStream();
+    pool[key] = s;
+    // lowest priority: the caller's stream carries the latency-bound critical path and must win the dispatcher
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    for (int i = 0; i < 8; ++i)
+        if (hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    s->ok = true;
     return s;
 }
 

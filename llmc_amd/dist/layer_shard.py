@@ -52,13 +52,18 @@ def broadcast_tensor(t, src, shape=None, dtype=None, device=None):
     return t
 
 
-def run_independent(n_units, fn, gather_to=0):
+def run_independent(n_units, fn, gather_to=0, to_cpu=True):
     """Every rank runs fn(unit) for the units it owns; rank `gather_to` receives all results in unit order
-    (other ranks get their own). `fn` returns any picklable / tensor payload (moved to CPU for the gather)."""
+    (other ranks get their own). `fn` returns a payload: tensors / None / numbers nested in dicts, lists, tuples.
+    to_cpu=True: payloads travel as pickled CPU objects (gather_object; any backend, what the Gloo tests use).
+    to_cpu=False: tensors stay on their device and travel point-to-point (RCCL send/recv over xGMI); only their
+    shapes / dtypes are exchanged as objects."""
     rank, world = world_info()
     mine = [ShardedResult(u, fn(u)) for u in units_of(rank, n_units, world)]
     if world == 1:
         return [r.payload for r in mine]
+    if not to_cpu:
+        return _gather_p2p(mine, n_units, gather_to)
     cpu = [ShardedResult(r.unit, _to_cpu(r.payload)) for r in mine]
     gathered = [None] * world if rank == gather_to else None
     dist.gather_object(cpu, gathered, dst=gather_to)
@@ -69,7 +74,64 @@ def run_independent(n_units, fn, gather_to=0):
     return [r.payload for r in flat]
 
 
-def run_block_cooperative(layers, x_or_none, src, fn, x_meta, share='activations', hessian_fn=None, gather_to=0):
+def _flatten(p, out):
+    """payload -> skeleton with tensor placeholders ('T', index); tensors appended to `out`."""
+    if torch.is_tensor(p):
+        out.append(p)
+        return ('T', len(out) - 1)
+    if isinstance(p, dict):
+        return {k: _flatten(v, out) for k, v in p.items()}
+    if isinstance(p, (list, tuple)):
+        return type(p)(_flatten(v, out) for v in p)
+    return p
+
+
+def _unflatten(sk, tensors):
+    if isinstance(sk, tuple) and len(sk) == 2 and sk[0] == 'T' and isinstance(sk[1], int):
+        return tensors[sk[1]]
+    if isinstance(sk, dict):
+        return {k: _unflatten(v, tensors) for k, v in sk.items()}
+    if isinstance(sk, (list, tuple)):
+        return type(sk)(_unflatten(v, tensors) for v in sk)
+    return sk
+
+
+def _gather_p2p(mine, n_units, gather_to):
+    rank, world = world_info()
+    flat = []
+    for r in mine:
+        ts = []
+        sk = _flatten(r.payload, ts)
+        flat.append((r.unit, sk, [t.contiguous() for t in ts]))
+    meta = [(u, sk, [(tuple(t.shape), t.dtype) for t in ts]) for u, sk, ts in flat]
+    metas = [None] * world
+    dist.all_gather_object(metas, meta)
+    if rank != gather_to:
+        for u, sk, ts in flat:
+            for t in ts:
+                dist.send(t, dst=gather_to)
+        return [r.payload for r in mine]
+    dev = None
+    for _, _, ts in flat:
+        for t in ts:
+            dev = t.device
+    results = {u: p.payload for u, p in ((r.unit, r) for r in mine)}
+    for src in range(world):
+        if src == gather_to:
+            continue
+        for u, sk, shapes in metas[src]:
+            ts = []
+            for shp, dt in shapes:
+                buf = torch.empty(shp, dtype=dt, device=dev if dev is not None else 'cpu')
+                dist.recv(buf, src=src)
+                ts.append(buf)
+            results[u] = _unflatten(sk, ts)
+    assert sorted(results) == list(range(n_units)), 'every unit exactly once'
+    return [results[u] for u in range(n_units)]
+
+
+def run_block_cooperative(layers, x_or_none, src, fn, x_meta, share='activations', hessian_fn=None, gather_to=0,
+                          to_cpu=True):
     """One subset, several ranks. `layers`: list of layer ids of the subset (same order on every rank);
     `x_or_none`: the subset's input on rank `src` (None elsewhere); `x_meta` = (shape, dtype, device) for receivers.
     share='activations': broadcast X, every rank computes its own Hessian for the layers it owns;
@@ -82,8 +144,34 @@ def run_block_cooperative(layers, x_or_none, src, fn, x_meta, share='activations
         shared = broadcast_tensor(shared, src, (K, K), torch.float32, x_meta[2])
     else:
         shared = broadcast_tensor(x_or_none, src, *x_meta)
-    out = run_independent(len(layers), lambda i: fn(layers[i], shared), gather_to=gather_to)
+    out = run_independent(len(layers), lambda i: fn(layers[i], shared), gather_to=gather_to, to_cpu=to_cpu)
     return out
+
+
+def row_range(rank, world, n_rows, align=16):
+    """Rows [r0, r1) of a stacked weight matrix owned by `rank`: near-equal, boundaries multiples of `align`."""
+    per = -(-n_rows // world)
+    per = -(-per // align) * align
+    r0 = min(n_rows, rank * per)
+    return r0, min(n_rows, r0 + per)
+
+
+def run_subset_sample_sharded(x_local, weights, hessian_fn, quantize_rows_fn):
+    """One subset, several ranks, calibration samples sharded (the reference's data-parallel semantics,
+    gptq.py:292-295, and SURVEY.md §8e's plan for the widest inputs): every rank accumulates the Hessian of ITS
+    sequences (each rank holds the same number), ONE all_reduce replaces the reference's per-batch one, every rank
+    factors the identical H (same kernels, same bits), and the rows of the stacked weights — independent given
+    Hinv — are split across ranks. Returns this rank's rows' payload and the row range; the caller gathers or saves.
+    hessian_fn(x_local) -> H [K, K] fp32 (scaled by 2 / local sequences); quantize_rows_fn(weights, H, (r0, r1))."""
+    rank, world = world_info()
+    H = hessian_fn(x_local)
+    if world > 1:
+        dist.all_reduce(H, op=dist.ReduceOp.SUM)
+        H.div_(world)
+    n_rows = sum(int(w.shape[0]) for w in weights)
+    rows = row_range(rank, world, n_rows)
+    payload = quantize_rows_fn(weights, H, rows) if rows[1] > rows[0] else None
+    return {'rows': rows, 'payload': payload}
 
 
 def _to_cpu(p):

@@ -1,0 +1,76 @@
+"""Time the REFERENCE's GPTQ path (oracle/_ref, built by oracle/build_ref.py) on the host cores; print one JSON line.
+
+What is timed (SURVEY.md §8d "CPU reference timed beside it"), with torch.set_num_threads(os.cpu_count()):
+  * GPTQ.add_batch (gptq.py:254-295) on `--batches` sequences of [1, seq, K] (the op is a fixed-shape GEMM per batch:
+    scaled linearly to the calibration set),
+  * GPTQ.process_hessian_and_weights (:128-176) and GPTQ.weight_transform (:199-244) of one K x K layer in full.
+Run as a subprocess by bench.py's cpu_baseline leg; test infrastructure, never imported by the product."""
+import argparse
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '_shims'))
+sys.path.insert(0, os.path.join(HERE, '_ref'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--K', type=int, default=4096)
+    ap.add_argument('--seq', type=int, default=2048)
+    ap.add_argument('--batches', type=int, default=4)
+    ap.add_argument('--threads', type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    cores = a.threads or os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29617')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    os.environ.setdefault('RANK', '0')
+    dist.init_process_group('gloo', rank=0, world_size=1)        # add_batch all-reduces H (gptq.py:292-295)
+    from llmc.compression.quantization.gptq import GPTQ
+    from llmc.compression.quantization.quant import IntegerQuantizer
+
+    K = a.K
+    wq = IntegerQuantizer(4, False, 'per_group', group_size=128)
+    g = GPTQ.__new__(GPTQ)                                         # numeric methods only
+    g.dev = torch.device('cpu')
+    g.wquantizer, g.actorder, g.static_groups, g.percdamp, g.blocksize = wq, True, False, 0.01, 128
+    g.chunk_num, g.owq, g.layers_cache, g.model_dtype, g.act_static = 1, False, {}, torch.bfloat16, False
+    g.need_perm = True
+    gen = torch.Generator().manual_seed(0)
+    layer = torch.nn.Linear(K, K, bias=False).to(torch.bfloat16)
+    layer.weight.data = (torch.randn(K, K, generator=gen) * 0.02).to(torch.bfloat16)
+    _, s0, z0, qmax, qmin = wq.get_tensor_qparams(layer.weight.data)
+    for n, v in (('buf_scales', s0), ('buf_zeros', z0), ('buf_qmax', torch.tensor(qmax)), ('buf_qmin', torch.tensor(qmin))):
+        layer.register_buffer(n, v.detach() if torch.is_tensor(v) else v)
+    g.layers_cache['fc'] = {}
+    g.layer_init(layer, 'fc')
+    xs = [(torch.randn(1, a.seq, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(torch.bfloat16)
+          for _ in range(a.batches)]
+    g.add_batch(layer, 'fc', xs[0], None)                          # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    for x in xs:
+        g.add_batch(layer, 'fc', x, None)
+    t_h = (time.perf_counter() - t0) / a.batches
+    g.layers_cache['fc']['H'] += 0.1 * torch.eye(K)
+    g.initialize_qparams_and_prepare_weights(layer, 'fc')
+    t0 = time.perf_counter()
+    W, Hinv = g.process_hessian_and_weights(layer, 'fc')
+    t_c = time.perf_counter() - t0
+    Losses, tmp = torch.zeros_like(W), torch.zeros_like(W)
+    t0 = time.perf_counter()
+    g.weight_transform(W, Hinv, Losses, tmp)
+    t_l = time.perf_counter() - t0
+    print(json.dumps({'K': K, 'seq': a.seq, 'batches': a.batches, 'threads': cores, 't_hessian_per_seq': t_h,
+                      't_factor': t_c, 't_loop': t_l, 'blas': torch.__config__.parallel_info().split('\n')[0:3],
+                      'finite': bool(torch.isfinite(tmp).all())}), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

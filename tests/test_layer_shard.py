@@ -40,6 +40,32 @@ def _worker(rank, world, port, q):
     if rank == 0:
         xr = torch.arange(24, dtype=torch.float32).reshape(-1, 4)
         assert all(o[1] == (4, 4) and abs(o[2] - float((xr.T @ xr).trace())) < 1e-3 for o in out)
+    # tensors travel point-to-point (the RCCL path of bench.py --mode cooperative), nested payloads survive
+    res = LS.run_independent(5, lambda u: {'w': torch.full((3,), float(u)), 'meta': [u, None, (torch.ones(2) * rank,)]},
+                             to_cpu=False)
+    if rank == 0:
+        assert [float(r['w'][0]) for r in res] == [0.0, 1.0, 2.0, 3.0, 4.0]
+        assert [r['meta'][0] for r in res] == list(range(5)) and all(r['meta'][1] is None for r in res)
+        assert [float(r['meta'][2][0][0]) for r in res] == [float(u % world) for u in range(5)]
+    # sample-sharded subset: each rank's Hessian of its own sequences, one all_reduce, row-sharded quantization
+    K, R = 8, 40
+    xs = torch.arange(4 * 6 * K, dtype=torch.float32).reshape(4, 6, K) / 100.0
+    mine = xs[rank::world]
+    ws = [torch.arange(R * K, dtype=torch.float32).reshape(R, K)[:24], torch.arange(R * K, dtype=torch.float32).reshape(R, K)[24:]]
+    seen = {}
+
+    def quant_rows(weights, H, rows):
+        seen['H'] = H.clone()
+        return torch.cat(weights, 0)[rows[0]:rows[1]] * 2
+    out = LS.run_subset_sample_sharded(
+        mine, ws, lambda x: (x.reshape(-1, K).T @ x.reshape(-1, K)) * (2.0 / x.shape[0]), quant_rows)
+    full = (xs.reshape(-1, K).T @ xs.reshape(-1, K)) * (2.0 / 4)
+    assert torch.allclose(seen['H'], full, rtol=1e-6)                    # mean of per-rank Hessians = global Hessian
+    r0, r1 = out['rows']
+    assert (r0, r1) == LS.row_range(rank, world, R) and torch.equal(out['payload'], torch.cat(ws, 0)[r0:r1] * 2)
+    parts = [None] * world
+    dist.all_gather_object(parts, (r0, r1))
+    assert parts[0][0] == 0 and parts[-1][1] == R and all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, 'ok'))
