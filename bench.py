@@ -139,7 +139,7 @@ def cpu_baseline_reference(model, n_seq, seq):
     if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'llmc')):
         raise RuntimeError('oracle/_ref missing (built by __graft_entry__.build() where /root/reference exists)')
     r = subprocess.run([sys.executable, script, '--K', str(K), '--seq', str(seq), '--batches', str(nb)],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=240)
     line = [l for l in r.stdout.splitlines() if l.startswith('{')]
     if r.returncode != 0 or not line:
         raise RuntimeError('reference baseline failed: ' + (r.stderr or r.stdout)[-400:])
@@ -148,7 +148,8 @@ def cpu_baseline_reference(model, n_seq, seq):
         'value': _block_model(model, n_seq, t['t_hessian_per_seq'], t['t_factor'], t['t_loop'], K),
         'unit': 'layers/s', 'cores': t['threads'], 'kind': 'reference',
         'sample': (f"llmc's own GPTQ (oracle/_ref = /root/reference after its ci_check/change_files.py CPU rewrite), torch "
-                   f"CPU on {t['threads']} threads: add_batch on {nb} of {n_seq} sequences of one {K}-channel input "
+                   f"CPU, {t['threads']} threads for the Hessian GEMM and {t.get('threads_small_ops', t['threads'])} for the "
+                   f"factorisations / column loop (more threads make those slower): add_batch on {nb} of {n_seq} sequences of one {K}-channel input "
                    f"({t['t_hessian_per_seq']:.3f} s/seq), process_hessian_and_weights ({t['t_factor']:.2f} s) and "
                    f"weight_transform ({t['t_loop']:.2f} s) of one {K}x{K} layer in full; other shapes scaled by flop "
                    'count; 7 Hessians per block as the reference executes them'),
@@ -245,7 +246,7 @@ class HipOps:
     def quantize(self, name, weights, H, rows=None):
         static = self.static_qparams(weights)
         res = self.P.quantize_stacked(weights, H, self.cfg, static_qparams=static, h_work=self.hwork.get(name), rows=rows)
-        outs = [{'weight': r.weight, 'scales': r.scales, 'zeros': r.zeros, 'perm': r.perm, 'loss': r.loss} for r in res]
+        outs = [{'weight': r.weight, 'scales': r.scales, 'zeros': r.zeros, 'perm': r.perm, 'loss': r.loss, 'info': r.info} for r in res]
         if self.variant == 'vllm' and rows is None:
             for r, (s, _) in zip(res, static):
                 a = {'scales': s, 'zeros': self.torch.tensor(0.0), 'qmax': self.wq.qmax, 'qmin': self.wq.qmin}
@@ -413,14 +414,28 @@ def main():
             torch.distributed.barrier()
         ops.sync()
 
+    last = None
     for _ in range(args.warmup):
         step(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        last = step(True)
     barrier()
     dt = time.perf_counter() - t0
+    # deferred positive-definiteness check of the factorisations (the classes check once per subset; here after timing)
+    def _infos(o):
+        if isinstance(o, dict):
+            if torch.is_tensor(o.get('info')):
+                yield o['info']
+            for v in o.values():
+                yield from _infos(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                yield from _infos(v)
+    bad = [int(t.item()) for t in _infos(last) if int(t.item()) != 0]
+    if bad:
+        raise SystemExit(f'bench.py: a Hessian was not positive definite (leading minors {bad}): results invalid')
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -35,6 +35,10 @@ extern "C" {
 #define LLMC_F16 0
 #define LLMC_BF16 1
 #define LLMC_F32 2
+/* OR-ed into the dtype code of llmc_quant_static's scales / zeros: the operand is a 0-dim tensor in the reference
+ * (per_tensor qparams): it is used at its own precision but ATen leaves it out of type promotion, so every op still
+ * rounds to the weight dtype (quant.py:699-717 with the 0-dim scales of quant.py:132-136,555-556). */
+#define LLMC_SCALAR_QPARAM 16
 
 /* integer code container for llmc_quant_static / llmc_quant_dynamic */
 #define LLMC_OUT_FAKE 0 /* dequantised values, written in the weight dtype              */

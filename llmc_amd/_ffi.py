@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libllmc_hip.so')
 
 F16, BF16, F32 = 0, 1, 2
 OUT_FAKE, OUT_I32, OUT_I8, OUT_U8 = 0, 1, 2, 3
+SCALAR_QPARAM = 16   # LLMC_SCALAR_QPARAM
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 
@@ -115,6 +116,7 @@ def dt(t):
 
 def require_gpu(*tensors):
     """The product path runs on the GPU only; refuse anything else loudly."""
+    cur = None
     for t in tensors:
         if t is None:
             continue
@@ -122,6 +124,12 @@ def require_gpu(*tensors):
             raise LlmcHipError(
                 'llmc_amd operators run on MI355X only (tensor is on '
                 f'{t.device}); there is no CPU fallback. Use oracle/ for CPU checks in tests.')
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            # the C side launches on the CURRENT device's stream and keys helper streams / attributes on it
+            raise LlmcHipError(f'tensor lives on {t.device} but the current device is cuda:{cur}: wrap the call in '
+                               '`with torch.cuda.device(tensor.device)` (hipSetDevice is the caller\'s job)')
 
 
 def ptr(t):

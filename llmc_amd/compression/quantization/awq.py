@@ -1,11 +1,15 @@
 """Awq with llmc's operator surface (llmc/compression/quantization/awq.py:28-372), arithmetic in HIP.
 
-search_scale_subset keeps the reference's semantics for the shipped default (one calibration batch, weight-only):
-20-point ratio grid, fake-quant of the scaled weights in the model dtype, loss on the inspected module's output,
-rank-wise winner-takes-all (all_reduce MIN / MAX + broadcast, awq.py:255-273). On the accelerated path the
-inspected module is the subset's Linear layers themselves (outputs concatenated) — the case BASELINE.json's
-AWQ config names; a subset whose `inspect` is a larger module (whole attention / MLP) is evaluated the same way
-on its Linear layers, which is logged once."""
+search_scale_subset keeps the reference's semantics: 20-point ratio grid, fake-quant of the scaled weights in the
+model dtype, loss on the INSPECTED module's output, per-batch best bookkeeping (awq.py:229-248), padding
+mask, rank-wise winner-takes-all (all_reduce MIN / MAX + broadcast, awq.py:255-273). Two routes, same arithmetic:
+  * fused (search_scale_stacked): the inspected module IS the subset's single Linear (o_proj, down_proj in Llama),
+    one calibration batch, no kwargs / mask — scale, fake-quant, x/s, GEMM and MSE run as HIP kernels, the 20 losses
+    stay on the device;
+  * general (inspect_module_forward): any inspected module (whole attention for q/k/v, whole MLP for gate/up,
+    llmc/models/llama.py:62,79), any number of batches — scales, weight fake-quant and input scaling are the same
+    HIP kernels, the module's own forward runs in torch with the subset's Linear layers routed through the HIP GEMM
+    (llmc_linear_eval) for the duration of the search, the loss is formed exactly as calculate_loss does."""
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -17,6 +21,41 @@ from .awq_pipeline import search_scale_stacked
 from .base_blockwise_quantization import BaseBlockwiseQuantization, _world
 from .module_utils import (_LLMC_LINEAR_TYPES_, _LLMC_LN_TYPES_, _TRANSFORMERS_LINEAR_TYPES_,
                            _TRANSFORMERS_LN_TYPES_, FakeQuantLinear)
+
+
+class _hip_linear_forward:
+    """While active, `layers` (plain Linear modules of the inspected module) compute y = x W^T (+ b) with the HIP GEMM
+    (llmc_linear_eval mode 0) instead of the vendor BLAS behind F.linear; shapes the kernel does not take
+    (K % 64 != 0, operands >= 4 GiB) keep the module's own forward."""
+
+    def __init__(self, layers):
+        self.layers = [l for l in layers if isinstance(l, nn.Linear)]
+        self.saved = []
+
+    @staticmethod
+    def _forward(layer, x):
+        w = layer.weight
+        ok = (x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.float16, torch.bfloat16) and w.dim() == 2
+              and w.shape[1] % 64 == 0 and x.numel() * 2 < (1 << 32) and w.numel() * 2 < (1 << 32)
+              and x.numel() // w.shape[1] * w.shape[0] * 2 < (1 << 32))
+        if not ok:
+            return nn.functional.linear(x, w, layer.bias)
+        y = awq_ops.linear_out(x, w.data)
+        return y if layer.bias is None else y + layer.bias
+
+    def __enter__(self):
+        for l in self.layers:
+            self.saved.append((l, l.__dict__.get('forward')))
+            l.forward = (lambda x, _l=l: _hip_linear_forward._forward(_l, x))
+        return self
+
+    def __exit__(self, *exc):
+        for l, f in self.saved:
+            if f is None:
+                l.__dict__.pop('forward', None)
+            else:
+                l.forward = f
+        return False
 
 
 @ALGO_REGISTRY
@@ -53,26 +92,109 @@ class Awq(BaseBlockwiseQuantization):
             raise NotImplementedError('GQA v-proj -> o-proj transformation is outside the hot path')
         return awq_ops.awq_scales(self.get_act_scale(x), w_max, ratio, self.trans_version)
 
+    # ---- the reference's helper surface (awq.py:110-145), used by the general route ---------------------------
+    def inspect_module_forward(self, x, inspect_module, kwargs):
+        if self._bs == x.shape[0]:
+            out = inspect_module(x, **kwargs)
+            return out[0] if isinstance(out, tuple) else out
+        outs = []
+        for num in range(x.shape[0] // self._bs):
+            out = inspect_module(x[num * self._bs:(num + 1) * self._bs], **kwargs)
+            outs.append(out[0] if isinstance(out, tuple) else out)
+        return torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def get_original_out(self, x, inspect_module, subset_kwargs):
+        return self.inspect_module_forward(x, inspect_module, subset_kwargs)
+
+    def calculate_loss(self, org_out, out):
+        """mean((org - out)^2) in fp32, averaged over sub-batches of awq_bs (awq.py:134-145); a 0-dim device tensor
+        (the reference calls .item() here: 20 x batches host syncs; the comparison below needs one per grid point)."""
+        if out.shape[0] == self._bs:
+            return (org_out - out).float().pow(2).mean()
+        total, b_num = 0.0, org_out.shape[0] // self._bs
+        for num in range(b_num):
+            sl = slice(num * self._bs, (num + 1) * self._bs)
+            total = total + (org_out[sl] - out[sl]).float().pow(2).mean()
+        return total / b_num
+
+    def _act_scale_batched(self, x):
+        """get_act_scale (awq.py:74-85): mean of sub-batch means when awq_bs splits the batch."""
+        if x.shape[0] == self._bs:
+            return awq_ops.act_mean(x)
+        means = [awq_ops.act_mean(x[n * self._bs:(n + 1) * self._bs]) for n in range(x.shape[0] // self._bs)]
+        return sum(means) / len(means)
+
+    def _fused_route_ok(self, layers_dict, input, inspect_module, subset_kwargs):
+        layers = list(layers_dict.values())
+        if len(input) != 1 or len(layers) != 1 or inspect_module is not layers[0]:
+            return False
+        if self.padding_mask or (isinstance(subset_kwargs, dict) and subset_kwargs) or isinstance(subset_kwargs, list):
+            return False
+        if getattr(layers[0], 'bias', None) is not None:
+            return False       # a bias cancels in org - out, but the fused loss kernel takes the bias-free product
+        return self.awq_bs is None or self.awq_bs == input[0].shape[0]
+
     @torch.no_grad()
     def search_scale_subset(self, prev_op, layers_dict, input, inspect_module, is_gqa, subset_kwargs):
         if is_gqa:
             raise NotImplementedError('GQA v-proj -> o-proj transformation is outside the hot path')
-        if len(input) != 1:
-            raise NotImplementedError('Awq scale search: one calibration batch (calib.bs = -1), the shipped default')
-        x = input[0]
-        weights = [fc.weight.data for fc in layers_dict.values()]
-        best_scales, losses, n = search_scale_stacked(weights, x, self.wquantizer, self.trans_version,
-                                                      return_losses=True)
+        self._bs = input[0].shape[0] if self.awq_bs is None else self.awq_bs
+        if self._fused_route_ok(layers_dict, input, inspect_module, subset_kwargs):
+            x = input[0]
+            weights = [fc.weight.data for fc in layers_dict.values()]
+            best_scales, losses, n = search_scale_stacked(weights, x, self.wquantizer, self.trans_version,
+                                                          return_losses=True)
+            best_error = losses[n].reshape(1).clone()
+        else:
+            best_scales, best_error = self._search_scale_general(layers_dict, input, inspect_module, subset_kwargs)
         if _world() > 1:   # winner-takes-all across ranks (awq.py:255-273)
-            best = losses[n].reshape(1).clone()
-            gbest = best.clone()
+            gbest = best_error.clone()
             dist.all_reduce(gbest, op=dist.ReduceOp.MIN)
-            rank = torch.tensor([dist.get_rank() if abs(float(best) - float(gbest)) < 1e-5 else -1],
-                                device=x.device)
+            rank = torch.tensor([dist.get_rank() if abs(float(best_error) - float(gbest)) < 1e-5 else -1],
+                                device=best_scales.device)
             dist.all_reduce(rank, op=dist.ReduceOp.MAX)
             best_scales = best_scales.clone()
             dist.broadcast(best_scales, src=int(rank.item()))
         return best_scales
+
+    @torch.no_grad()
+    def _search_scale_general(self, layers_dict, input, inspect_module, subset_kwargs, n_grid=20):
+        """awq.py:189-253 with the module kept on the device: weights are restored from a device copy after every
+        evaluation (the reference reloads a CPU state dict), everything else in the reference's order."""
+        layers = list(layers_dict.values())
+        w_max = self.get_weight_scale(layers_dict)
+        org_w = [fc.weight.data.clone() for fc in layers]
+        best_error, best_scales = float('inf'), None
+        org_out_dict = {}
+        dev = org_w[0].device
+        with _hip_linear_forward(layers):
+            for n in range(n_grid):
+                loss_mean, scales_mean = 0, 0
+                for i in range(len(input)):
+                    x = input[i] = input[i].to(dev)
+                    kwargs = subset_kwargs[i] if isinstance(subset_kwargs, list) else (subset_kwargs or {})
+                    if i not in org_out_dict:
+                        org_out_dict[i] = self.get_original_out(x, inspect_module, kwargs)
+                    org_out = org_out_dict[i]
+                    ratio = n * 1 / n_grid
+                    scales = awq_ops.awq_scales(self._act_scale_batched(x), w_max, ratio, self.trans_version)
+                    for fc, w0 in zip(layers, org_w):      # fake_quantize_weight (awq.py:147-164)
+                        fc.weight.data = awq_ops.scale_fakequant(w0, scales, self.wquantizer)
+                    x_tmp = awq_ops.div_cols(x, scales)   # scaling_input (base_blockwise_quantization.py:877-889)
+                    out = self.inspect_module_forward(x_tmp, inspect_module, kwargs)
+                    if self.padding_mask and org_out.shape[1] == self.padding_mask[i].shape[-1]:
+                        m = self.padding_mask[i].unsqueeze(dim=-1).to(org_out.device)
+                        org_out, out = org_out * m, out * m
+                    loss = float(self.calculate_loss(org_out, out))
+                    n_samples = x.shape[0] if len(input) == 1 else self.n_samples
+                    loss_mean += x.shape[0] * 1.0 / n_samples * loss
+                    scales_mean += x.shape[0] * 1.0 / n_samples * scales   # in place from the 2nd batch on: `best_scales` below aliases it, like the reference
+                    for fc, w0 in zip(layers, org_w):      # inspect_module.load_state_dict(org_sd)
+                        fc.weight.data = w0
+                    if loss_mean < best_error:             # inside the batch loop, like the reference (SURVEY G6)
+                        best_error, best_scales = loss_mean, scales_mean
+        return best_scales, torch.tensor([best_error], dtype=torch.float32, device=dev)
 
     @torch.no_grad()
     def block_transform(self, block, input_feat, block_kwargs):

@@ -20,6 +20,7 @@ import torch.nn as nn
 from llmc_amd.utils.registry_factory import ALGO_REGISTRY
 
 from .base_blockwise_quantization import BaseBlockwiseQuantization, _world
+from . import gptq_ops
 from .gptq_pipeline import GptqConfig, quantize_stacked
 from .hessian import HessianAccumulator
 from .module_utils import _LLMC_LINEAR_TYPES_, _TRANSFORMERS_LINEAR_TYPES_, FakeQuantLinear
@@ -32,7 +33,7 @@ class GPTQ(BaseBlockwiseQuantization):
         self.model_dtype = next(self.model.model.parameters()).dtype
         self.add_quant_config()
         self.layers_cache = {}
-        self._leader = {}
+        self._groups, self._group_of = {}, {}
         self.collect_model_qparams()
 
     @torch.no_grad()
@@ -65,78 +66,125 @@ class GPTQ(BaseBlockwiseQuantization):
         if self.act_static:
             super().cache_input_hook(m, inp, out, name, feat_dict)
 
+    # ---- Hessian groups -----------------------------------------------------------------------------------------
+    # The layers of a subset are set up as ONE group sharing one accumulator (q/k/v and gate/up see the same tensor;
+    # the reference accumulates the identical H once per layer). The sharing is only KEPT for layers whose hooked
+    # input is provably the very tensor the group's accumulator was fed with on the same calibration call: a layer
+    # that sees anything else on its first call — the experts and the router of a Mixtral / Qwen2-MoE / DeepSeek
+    # subset each see their own routed tokens (mixtral.py:65-66, qwen2moe.py:81-84, deepseekv2.py:130-135) — leaves the
+    # group and accumulates its own Hessian, exactly like the reference.
+    @staticmethod
+    def _input_signature(inp):
+        """What makes two hooked inputs THE SAME tensor (not merely equal): storage, view geometry, version."""
+        return (inp.data_ptr(), tuple(inp.shape), tuple(inp.stride()), inp.dtype, inp._version)
+
+    def _new_group(self, names, K, device):
+        gid = self._next_gid = getattr(self, '_next_gid', 0) + 1
+        acc = HessianAccumulator(K, device)
+        self._groups[gid] = {'acc': acc, 'feed': {}, 'members': list(names)}
+        for n in names:
+            self._group_of[n] = gid
+            self.layers_cache[n] = {'acc': acc, 'H': acc.H, 'nsamples': 0, 'columns': K, 'calls': 0}
+        return gid
+
     @torch.no_grad()
     def add_batch(self, layer, name, inp, out):
-        """gptq.py:254-295. Layers that share an input share the accumulator; only the subset's first layer
-        feeds it (the others would add the same X^T X to the same matrix)."""
-        if self._leader.get(name, name) != name:
-            return
-        self.layers_cache[name]['acc'].add(inp)
-        self.layers_cache[name]['nsamples'] = self.layers_cache[name]['acc'].nsamples
+        """gptq.py:254-295 (running-mean Hessian of the layer's input), fed once per distinct input tensor."""
+        c = self.layers_cache[name]
+        c['calls'] += 1
+        call = c['calls']
+        g = self._groups[self._group_of[name]]
+        if len(g['members']) > 1:
+            sig = self._input_signature(inp)
+            seen = g['feed'].get(call)
+            if seen is None:
+                g['feed'] = {call: sig}                      # first member called this time feeds the group
+            elif seen == sig:
+                c['nsamples'] = g['acc'].nsamples             # the very same tensor is already in H
+                return
+            elif call == 1:                                   # a different input from the start: its own Hessian
+                g['members'].remove(name)
+                calls = c['calls']
+                self._new_group([name], c['columns'], layer.weight.device)
+                c = self.layers_cache[name]
+                c['calls'] = calls
+                g = self._groups[self._group_of[name]]
+            else:
+                raise RuntimeError(f'GPTQ: layer {name} shared its Hessian on earlier calibration calls but now sees a '
+                                   'different input tensor than its subset; per-layer Hessians cannot be recovered')
+        g['acc'].add(inp)
+        for m in g['members']:
+            self.layers_cache[m]['nsamples'] = g['acc'].nsamples
 
     def _group_layers(self, named_layers, block=None):
-        """name -> leader name, from the model's subset table (layers of one subset see the same input)."""
-        leader = {n: n for n in named_layers}
+        """lists of layer names that start out sharing a Hessian: the model's subsets (same-shaped inputs only)."""
+        groups, seen = [], set()
         if block is not None:
             for subset in self.model.get_subsets_in_block(block):
-                names = [n for n in subset['layers'] if n in named_layers]
-                for n in names:
-                    leader[n] = names[0]
-        return leader
+                by_k = {}
+                for n in subset['layers']:
+                    if n in named_layers and n not in seen:
+                        by_k.setdefault(self._in_features(named_layers[n]), []).append(n)
+                        seen.add(n)
+                groups.extend(by_k.values())
+        groups.extend([n] for n in named_layers if n not in seen)
+        return groups
+
+    @staticmethod
+    def _in_features(layer):
+        return layer.weight.shape[1] if layer.weight.dim() == 2 else layer.weight[0].numel()
 
     @torch.no_grad()
     def layer_init(self, layer, name):
-        K = layer.weight.shape[1] if layer.weight.dim() == 2 else layer.weight[0].numel()
-        lead = self._leader.get(name, name)
-        if lead == name:
-            acc = HessianAccumulator(K, layer.weight.device)
-        else:
-            acc = self.layers_cache[lead]['acc']
-        self.layers_cache[name] = {'acc': acc, 'H': acc.H, 'nsamples': 0, 'columns': K}
+        self._new_group([name], self._in_features(layer), layer.weight.device)
 
     @torch.no_grad()
     def subset_init(self, subset):
         self.named_layers = subset['layers']
-        names = list(self.named_layers)
-        self._leader.update({n: names[0] for n in names})
-        for n in names:
-            self.layer_init(self.named_layers[n], n)
+        by_k = {}
+        for n, l in self.named_layers.items():
+            by_k.setdefault(self._in_features(l), []).append(n)
+        for K, names in by_k.items():
+            self._new_group(names, K, self.named_layers[names[0]].weight.device)
 
     @torch.no_grad()
     def block_init(self, block):
         self.named_layers = self.model.get_block_linears(block)
-        self._leader = self._group_layers(self.named_layers, block)
-        for n in sorted(self.named_layers, key=lambda k: self._leader[k] != k):   # leaders first
-            self.layer_init(self.named_layers[n], n)
+        for names in self._group_layers(self.named_layers, block):
+            l0 = self.named_layers[names[0]]
+            self._new_group(names, self._in_features(l0), l0.weight.device)
 
-    def _sync_hessian(self, name):
+    def _sync_hessian(self, gid):
         """One reduction per Hessian at the end of accumulation (the reference all-reduces per batch, gptq.py:292)."""
-        if _world() > 1:
-            H = self.layers_cache[name]['acc'].H
+        g = self._groups[gid]
+        if _world() > 1 and not g.get('synced'):
+            H = g['acc'].H
             dist.all_reduce(H, op=dist.ReduceOp.SUM)
             H.div_(_world())
+            g['synced'] = True
 
     # ---- transform ---------------------------------------------------------------------------------
     @torch.no_grad()
     def subset_transform(self, subset, input_feat, subset_kwargs):
         layers_dict = {n: l for n, l in subset['layers'].items()
                        if isinstance(l, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_))}
-        groups = {}
+        by_group = {}
         for n in layers_dict:
-            groups.setdefault(self._leader.get(n, n), []).append(n)
-        for lead, names in groups.items():
-            self._sync_hessian(lead)
-            self._transform_group(lead, [layers_dict[n] for n in names], names)
+            by_group.setdefault(self._group_of[n], []).append(n)
+        for gid, names in by_group.items():
+            self._sync_hessian(gid)
+            self._transform_group(gid, [layers_dict[n] for n in names], names)
             for n in names:
                 self.free(n)
 
     @torch.no_grad()
     def layer_transform(self, layer, name):
-        self._sync_hessian(self._leader.get(name, name))
-        self._transform_group(self._leader.get(name, name), [layer], [name])
+        gid = self._group_of[name]
+        self._sync_hessian(gid)
+        self._transform_group(gid, [layer], [name])
 
-    def _transform_group(self, lead, layers, names):
-        H = self.layers_cache[lead]['acc'].H
+    def _transform_group(self, gid, layers, names):
+        H = self._groups[gid]['acc'].H
         static = None
         if self.gcfg.static_groups or not self.gcfg.group_size:
             static = []
@@ -144,6 +192,9 @@ class GPTQ(BaseBlockwiseQuantization):
                 z = l.buf_zeros if (torch.is_tensor(l.buf_zeros) and l.buf_zeros.dim() > 0) else None
                 static.append((l.buf_scales, z))
         results = quantize_stacked([l.weight.data for l in layers], H, self.gcfg, static_qparams=static)
+        # one host sync per subset (the reference has one per layer: `.item()` of the loss, gptq.py:184): a Hessian that
+        # is not positive definite must raise like torch.linalg.cholesky does, not write garbage into the layer
+        gptq_ops.raise_if_not_pd(results[0].info, 'GPTQ: Hessian of ' + ', '.join(names))
         self.last_losses = {}
         for l, n, r in zip(layers, names, results):
             l.weight.data = r.weight.reshape(l.weight.shape)          # fp32, like the reference (G3)
@@ -197,3 +248,10 @@ class GPTQ(BaseBlockwiseQuantization):
     @torch.no_grad()
     def free(self, name):
         self.layers_cache.pop(name, None)
+        gid = self._group_of.pop(name, None)
+        if gid is not None and gid in self._groups:
+            g = self._groups[gid]
+            if name in g['members']:
+                g['members'].remove(name)
+            if not g['members']:
+                del self._groups[gid]

@@ -45,8 +45,10 @@ def gather_cols(src, idx):
 _chol_ws = {}
 
 
-def chol_inv_upper(H, check=True):
-    """gptq.py:172-174 in one call: returns U upper with H^-1 = U^T U. H is overwritten."""
+def chol_inv_upper(H, check=True, return_info=False):
+    """gptq.py:172-174 in one call: returns U upper with H^-1 = U^T U. H is overwritten.
+    check=True synchronises and raises when H is not positive definite (torch.linalg.cholesky raises there);
+    return_info=True hands back the device flag (0 = ok, k = leading minor k failed) for a deferred check."""
     _ffi.require_gpu(H)
     L = _ffi.lib()
     K = H.shape[0]
@@ -64,7 +66,16 @@ def chol_inv_upper(H, check=True):
         i = int(info.item())
         if i != 0:
             raise RuntimeError(f'chol_inv_upper: matrix is not positive definite (leading minor {i})')
-    return H
+    return (H, info) if return_info else H
+
+
+def raise_if_not_pd(info, what='Hessian'):
+    """Deferred form of the check: one host sync. The reference's torch.linalg.cholesky raises on a non-PD matrix
+    (bad calibration data, percdamp too small); silently continuing would write garbage weights."""
+    i = int(info.item())
+    if i != 0:
+        raise RuntimeError(f'{what} is not positive definite (leading minor {i}): more calibration data or a larger '
+                           'percdamp is needed (torch.linalg.cholesky raises here in the reference, gptq.py:172)')
 
 
 def release_workspaces():

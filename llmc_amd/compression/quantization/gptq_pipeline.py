@@ -39,6 +39,7 @@ class GptqResult:
     zeros: torch.Tensor            # [R, ng] fp32 | None
     perm: torch.Tensor             # [K] int64 | None
     loss: torch.Tensor             # 0-dim fp32 on device: sum(Losses) (the reference logs it, gptq.py:184)
+    info: torch.Tensor = None      # int32[1] on device: 0, or the leading minor at which the factorisation failed
 
 
 def factor_from_hessian(H, cfg, h_work=None):
@@ -76,7 +77,7 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
     if cfg.actorder:
         perm = torch.argsort(torch.diagonal(H), descending=True)
     Hp, Wp = gptq_ops.hessian_prep(H, Wcat, perm, cfg.percdamp, want_h=True, h_out=h_work)
-    U = gptq_ops.chol_inv_upper(Hp, check=False)
+    U, info = gptq_ops.chol_inv_upper(Hp, check=False, return_info=True)   # callers check `info` at their next sync
     qmin, qmax = cfg.qrange
     static_mode = cfg.static_groups or not cfg.group_size
     scales = zeros = col_group = None
@@ -100,7 +101,7 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
     for r in rows:
         sl = slice(r0, r0 + r)
         out.append(GptqResult(weight=tmp[sl], scales=s[sl], zeros=None if z is None else z[sl], perm=perm,
-                              loss=losses[sl].sum() if losses is not None else None))
+                              loss=losses[sl].sum() if losses is not None else None, info=info))
         r0 += r
     return out
 

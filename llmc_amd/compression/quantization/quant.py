@@ -125,10 +125,27 @@ class BaseQuantizer(object):
             return torch.min(tensor), torch.max(tensor)
         return tensor.amin(dim=-1, keepdim=True), tensor.amax(dim=-1, keepdim=True)
 
+    def _per_tensor_asym_qparams(self, tensor):
+        """per_tensor + asymmetric (quant.py:132-136,555-556): min / max are 0-dim tensors of the tensor dtype and
+        (qmax - qmin) is a 0-dim fp32 tensor, so type promotion makes scales and zeros fp32 0-dim. Four scalar ops
+        on the device after one min/max pass — nothing to accelerate; written with the reference's dtypes."""
+        _ffi.require_gpu(tensor)
+        mn, mx = torch.aminmax(tensor)
+        qmin, qmax = self.qmin.to(tensor.device), self.qmax.to(tensor.device)
+        scales = (mx - mn).clamp(min=1e-5) / (qmax - qmin)
+        if self.round_zp:
+            zeros = (qmin - torch.round(mn / scales)).clamp(qmin, qmax)
+        else:
+            zeros = qmin - (mn / scales)
+        return scales, zeros
+
     def _minmax_qparams(self, tensor):
-        """tensor: reshaped, contiguous, on GPU. Returns (scales, zeros) in tensor dtype (fp32 for calib_algo mse)."""
+        """tensor: reshaped, contiguous, on GPU. Returns (scales, zeros) in tensor dtype (fp32 for calib_algo mse and
+        for per_tensor asymmetric)."""
         if self.calib_algo == 'mse':
             return self._mse_qparams(tensor)
+        if self.granularity == 'per_tensor' and not self.sym:
+            return self._per_tensor_asym_qparams(tensor)
         _ffi.require_gpu(tensor)
         L = _ffi.lib()
         tensor = tensor.contiguous()
@@ -182,6 +199,10 @@ class IntegerQuantizer(BaseQuantizer):
         tensor = tensor.contiguous()
         g = tensor.shape[-1] if self.granularity != 'per_tensor' else tensor.numel()
         G = tensor.numel() // g
+        # a 0-dim operand keeps its precision (opmath) but does not take part in type promotion against a dimensioned
+        # tensor: every op still rounds to the tensor dtype (per_tensor qparams: fp32 0-dim scale, 16-bit weight)
+        s_flag = _ffi.SCALAR_QPARAM if (scales.dim() == 0 and tensor.dim() > 0) else 0
+        z_flag = _ffi.SCALAR_QPARAM if (torch.is_tensor(zeros) and zeros.dim() == 0 and tensor.dim() > 0) else 0
         scales_f = scales.reshape(-1)
         if scales_f.numel() == 1 and G > 1:
             scales_f = scales_f.expand(G)
@@ -197,7 +218,8 @@ class IntegerQuantizer(BaseQuantizer):
             if not zt.is_floating_point():
                 zt = zt.to(scales_f.dtype)
         elif torch.is_tensor(zeros) and zeros.dim() == 0 and float(zeros) != 0.0:
-            zt = torch.full((G,), float(zeros), dtype=scales_f.dtype, device=tensor.device)
+            zdt = zeros.dtype if zeros.is_floating_point() else scales_f.dtype
+            zt = torch.full((G,), float(zeros), dtype=zdt, device=tensor.device)
         elif not torch.is_tensor(zeros) and zeros not in (None, 0, 0.0):
             zt = torch.full((G,), float(zeros), dtype=scales_f.dtype, device=tensor.device)
         if out_kind == _ffi.OUT_FAKE:
@@ -206,8 +228,8 @@ class IntegerQuantizer(BaseQuantizer):
             odt = {_ffi.OUT_I32: torch.int32, _ffi.OUT_I8: torch.int8, _ffi.OUT_U8: torch.uint8}[out_kind]
             out = torch.empty(tensor.shape, dtype=odt, device=tensor.device)
         _ffi.check(L.llmc_quant_static(
-            _ffi.ptr(tensor), _ffi.dt(tensor), G, g, _ffi.ptr(scales_f), _ffi.dt(scales_f),
-            _ffi.ptr(zt), _ffi.dt(zt) if zt is not None else 0, float(qmin), float(qmax), out_kind,
+            _ffi.ptr(tensor), _ffi.dt(tensor), G, g, _ffi.ptr(scales_f), _ffi.dt(scales_f) | s_flag,
+            _ffi.ptr(zt), (_ffi.dt(zt) | z_flag) if zt is not None else 0, float(qmin), float(qmax), out_kind,
             _ffi.ptr(out), _ffi.stream()), 'llmc_quant_static')
         return out
 
@@ -232,6 +254,13 @@ class IntegerQuantizer(BaseQuantizer):
     # ---- dynamic (fused min/max + quant) -----------------------------------------------------------
     def _dynamic(self, tensor, out_kind, want_qparams):
         _ffi.require_gpu(tensor)
+        if self.granularity == 'per_tensor' and not self.sym and self.calib_algo != 'mse':
+            tensor = tensor.contiguous()
+            scales, zeros = self._per_tensor_asym_qparams(tensor)
+            out = self._static(tensor, scales, zeros, self.qmax, self.qmin, out_kind)
+            if not want_qparams:
+                return out, None, None
+            return out, scales, zeros
         if self.calib_algo == 'mse':   # searched range first, then the static arithmetic with its fp32 qparams
             tensor = tensor.contiguous()
             scales, zeros = self._mse_qparams(tensor)

@@ -173,16 +173,18 @@ __global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W
                                                          const void* __restrict__ zeros, int zdt,
                                                          float qmin, float qmax, void* __restrict__ out) {
     constexpr int WDT = dt_of<T>::value;
-    const int p1 = promote(WDT, sdt);
-    const int p2 = zeros ? promote(p1, zdt) : p1;
+    // LLMC_SCALAR_QPARAM: a 0-dim operand keeps its own precision but does not take part in type promotion
+    const int sd = sdt & 3, zd = zdt & 3;
+    const int p1 = (sdt & LLMC_SCALAR_QPARAM) ? WDT : promote(WDT, sd);
+    const int p2 = (zeros && !(zdt & LLMC_SCALAR_QPARAM)) ? promote(p1, zd) : p1;
     const int64_t nvec_row = g / VEC;
     const int64_t total = G * nvec_row;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * kBlock) {
         int64_t row = i / nvec_row;
         int64_t c = (i - row * nvec_row) * VEC;
-        float s = load_as_f32(scales, row, sdt);
-        float z = zeros ? load_as_f32(zeros, row, zdt) : 0.0f;
+        float s = load_as_f32(scales, row, sd);
+        float z = zeros ? load_as_f32(zeros, row, zd) : 0.0f;
         RowVec<T, VEC> v = load_vec<T, VEC>(W + row * g + c);
         float am = 0.0f;   // bound of |x| over this thread's elements for the hoisted divisor (quant_math.h)
 #pragma unroll
@@ -593,7 +595,8 @@ static int quant_static_t(const void* W, int64_t G, int64_t g, const void* scale
 extern "C" int llmc_quant_static(const void* W, int wdt, int64_t G, int64_t g, const void* scales, int sdt,
                                  const void* zeros, int zdt, float qmin, float qmax, int out_kind,
                                  void* out, llmc_stream_t stream) {
-    LLMC_REQUIRE(dtype_ok(wdt) && dtype_ok(sdt) && (!zeros || dtype_ok(zdt)), "quant_static: bad dtype");
+    LLMC_REQUIRE(dtype_ok(wdt) && dtype_ok(sdt & ~LLMC_SCALAR_QPARAM) && (!zeros || dtype_ok(zdt & ~LLMC_SCALAR_QPARAM)),
+                 "quant_static: bad dtype");
     LLMC_REQUIRE(W && scales && out && G > 0 && g > 0, "quant_static: null/empty argument");
     hipStream_t st = (hipStream_t)stream;
     switch (wdt) {

@@ -152,6 +152,31 @@ def suite_quant():
     save('quant', **out)
 
 
+def suite_quant_pt():
+    """per_tensor ASYMMETRIC IntegerQuantizer: min/max are 0-dim tensors and (qmax - qmin) is a 0-dim fp32 tensor, so
+    type promotion makes scales / zeros fp32 whatever the tensor dtype (quant.py:132-136,555-556)."""
+    gen = torch.Generator().manual_seed(4321)
+    out = {}
+    cases = [(dt, bit) for dt in ('f16', 'bf16', 'f32') for bit in (8, 4)]
+    for ci, (dt, bit) in enumerate(cases):
+        q = IntegerQuantizer(bit, False, 'per_tensor')
+        w = rand_weight(gen, 16, 384, dt)
+        t, s, z, qmax, qmin = q.get_tensor_qparams(w)
+        fq = q.fake_quant_weight_dynamic(w)
+        rw, rs, rz = q.real_quant_weight_dynamic(w)
+        p = f'c{ci}_'
+        out[p + 'w'] = f32(w)
+        out[p + 'scales'], out[p + 'zeros'] = f32(s).reshape(-1), f32(z).reshape(-1)
+        out[p + 'scales_dtype'], out[p + 'zeros_dtype'] = np.array(str(s.dtype)), np.array(str(z.dtype))
+        out[p + 'fake'], out[p + 'fake_dtype'] = f32(fq), np.array(str(fq.dtype))
+        out[p + 'codes'], out[p + 'codes_dtype'] = rw.numpy().astype(np.int32), np.array(str(rw.dtype))
+        out[p + 'rscales'], out[p + 'rzeros'] = f32(rs).reshape(-1), rz.numpy().astype(np.int32).reshape(-1)
+        out[p + 'meta'] = np.array([bit, float(qmin), float(qmax)], dtype=np.float64)
+        out[p + 'dt'] = np.array(dt)
+    out['n'] = np.array(len(cases))
+    save('quant_pt', **out)
+
+
 def suite_pack():
     """VllmRealQuantLinear.pack and AutoawqRealQuantLinear.gemm_pack (never run by the reference's CI)."""
     from easydict import EasyDict
@@ -404,6 +429,79 @@ def suite_awq():
     save('awq', **out)
 
 
+def suite_awq_inspect():
+    """Awq.search_scale_subset with an inspected module that is NOT the Linear layers themselves (the Llama gate/up
+    subset inspects the whole MLP, llmc/models/llama.py:79), two calibration batches (per-batch best bookkeeping,
+    awq.py:242-248) and a padding mask (awq.py:229-231)."""
+    import torch.distributed as dist
+    from llmc.compression.quantization.awq import Awq
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29593', rank=0, world_size=1)
+
+    class MLP(torch.nn.Module):
+        def __init__(self, K, R, dt):
+            super().__init__()
+            self.gate_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.up_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.down_proj = torch.nn.Linear(R, K, bias=False).to(dt)
+
+        def forward(self, x):
+            return self.down_proj(torch.nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()      # GPU semantics of `org_sd = {k: v.cpu()}` (see suite_awq)
+    out = {}
+    gen = torch.Generator().manual_seed(777)
+    cfgs = [('bf16_sym_g128_mlp_2batch_mask', 'bf16', True, 128, 'v2', True),
+            ('f16_asym_g64_mlp_2batch', 'f16', False, 64, 'v2', False)]
+    for name, dt, sym, gs, ver, use_mask in cfgs:
+        K, R, B, S = 256, 192, 2, 48
+        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.aquantizer, a.w_only, a.awq_bs, a.save_mem = wq, None, True, None, False
+        a.trans_version, a.n_samples, a.has_gqa, a.do_gqa_trans = ver, 2 * B, False, False
+        mlp = MLP(K, R, DT[dt])
+        for l in (mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+            wt = torch.randn(l.weight.shape, generator=gen) * 0.05
+            if l is not mlp.down_proj:
+                wt[:, torch.randperm(K, generator=gen)[:4]] *= 10
+            l.weight.data = wt.to(DT[dt])
+        c = torch.exp(0.5 * torch.randn(K, generator=gen))
+        c[torch.randperm(K, generator=gen)[:8]] *= 30.0
+        xs = [(torch.randn(B, S, K, generator=gen) * c).to(DT[dt]) for _ in range(2)]
+        masks = None
+        if use_mask:
+            masks = [(torch.rand(B, S, generator=gen) > 0.2).to(torch.int64) for _ in range(2)]
+        a.padding_mask = masks
+        losses = []
+        orig = a.calculate_loss
+
+        def rec(org_out, o, _orig=orig):
+            v = _orig(org_out, o)
+            losses.append(v)
+            return v
+        a.calculate_loss = rec
+        layers_dict = {'gate_proj': mlp.gate_proj, 'up_proj': mlp.up_proj}
+        w0 = {n: l.weight.data.clone() for n, l in mlp.named_modules() if isinstance(l, torch.nn.Linear)}
+        best = a.search_scale_subset(None, layers_dict, [x.clone() for x in xs], mlp, False, {})
+        for n, l in mlp.named_modules():
+            if isinstance(l, torch.nn.Linear):
+                assert torch.equal(l.weight.data, w0[n]), 'reference must restore the weights'
+        p = name + '/'
+        for n, w in w0.items():
+            out[p + 'w_' + n] = f32(w)
+        for i, x in enumerate(xs):
+            out[p + f'x{i}'] = f32(x)
+            if masks is not None:
+                out[p + f'mask{i}'] = masks[i].numpy()
+        out[p + 'best_scales'] = f32(best)
+        out[p + 'losses'] = np.array(losses, dtype=np.float64)          # order: grid point major, batch minor
+        out[p + 'meta'] = np.array([int(sym), gs, K, R, int(use_mask)], dtype=np.int64)
+        out[p + 'dt'] = np.array(dt)
+        out[p + 'ver'] = np.array(ver)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('awq_inspect', **out)
+
+
 def suite_clip():
     """AutoClipper.auto_clip_layer / apply_clip (clip_version v1, w_only)."""
     from llmc.compression.quantization.auto_clip import AutoClipper
@@ -562,7 +660,7 @@ def suite_mse():
     save('mse', **out)
 
 SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8, 'e2e': suite_e2e}
+          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

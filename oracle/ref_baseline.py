@@ -25,13 +25,18 @@ def main():
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
+    # the Hessian GEMM scales with the cores; the factorisations and the column loop (thousands of small ATen ops) get
+    # SLOWER beyond a handful of threads (256 threads: > 3 minutes for what 16 do in seconds) — each stage runs with the
+    # thread count that suits it best, capped at the box's cores
     cores = a.threads or os.cpu_count() or 1
+    small = min(cores, 16)
     torch.set_num_threads(cores)
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29617')
     os.environ.setdefault('WORLD_SIZE', '1')
     os.environ.setdefault('RANK', '0')
-    dist.init_process_group('gloo', rank=0, world_size=1)        # add_batch all-reduces H (gptq.py:292-295)
+    # add_batch all-reduces H across ranks (gptq.py:292-295). One rank here: the collective is the identity, and a Gloo
+    # rendezvous would depend on the box's hostname resolving — stub the two calls instead of opening a process group.
+    dist.all_reduce = lambda *a, **k: None
+    dist.get_world_size = lambda *a, **k: 1
     from llmc.compression.quantization.gptq import GPTQ
     from llmc.compression.quantization.quant import IntegerQuantizer
 
@@ -57,6 +62,7 @@ def main():
     for x in xs:
         g.add_batch(layer, 'fc', x, None)
     t_h = (time.perf_counter() - t0) / a.batches
+    torch.set_num_threads(small)
     g.layers_cache['fc']['H'] += 0.1 * torch.eye(K)
     g.initialize_qparams_and_prepare_weights(layer, 'fc')
     t0 = time.perf_counter()
@@ -66,10 +72,9 @@ def main():
     t0 = time.perf_counter()
     g.weight_transform(W, Hinv, Losses, tmp)
     t_l = time.perf_counter() - t0
-    print(json.dumps({'K': K, 'seq': a.seq, 'batches': a.batches, 'threads': cores, 't_hessian_per_seq': t_h,
+    print(json.dumps({'K': K, 'seq': a.seq, 'batches': a.batches, 'threads': cores, 'threads_small_ops': small, 't_hessian_per_seq': t_h,
                       't_factor': t_c, 't_loop': t_l, 'blas': torch.__config__.parallel_info().split('\n')[0:3],
                       'finite': bool(torch.isfinite(tmp).all())}), flush=True)
-    dist.destroy_process_group()
 
 
 if __name__ == '__main__':

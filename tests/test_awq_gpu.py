@@ -187,3 +187,62 @@ def test_pack_awq_gemm_vs_reference_golden():
         np.testing.assert_array_equal(qw.cpu().numpy(), g[f'a{ci}_qweight'])
         np.testing.assert_array_equal(qz.cpu().numpy(), g[f'a{ci}_qzeros'])
         np.testing.assert_array_equal(host(sc), g[f'a{ci}_qscales'])
+
+
+def test_search_with_inspected_mlp_two_batches_and_mask_matches_reference_golden():
+    """General route of Awq.search_scale_subset (inspected module = a whole MLP, two calibration batches, padding mask):
+    same per-(grid point, batch) loss curve, same winner, scales within 2 ulp of the reference's (awq.py:179-253)."""
+    from llmc_amd.compression.quantization.awq import Awq
+
+    class MLP(torch.nn.Module):
+        def __init__(self, K, R, dt):
+            super().__init__()
+            self.gate_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.up_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.down_proj = torch.nn.Linear(R, K, bias=False).to(dt)
+
+        def forward(self, x):
+            return self.down_proj(torch.nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+
+    g = load_golden('awq_inspect')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        sym, gs, K, R, use_mask = [int(v) for v in g[p + 'meta']]
+        dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
+        mlp = MLP(K, R, TD[dt]).cuda()
+        for n in ('gate_proj', 'up_proj', 'down_proj'):
+            getattr(mlp, n).weight.data = dev(g[p + 'w_' + n], dt)
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.w_only, a.awq_bs, a.save_mem = make_q(sym, gs), True, None, False
+        a.trans_version, a.n_samples = ver, 4
+        a.padding_mask = [torch.from_numpy(g[p + f'mask{i}']).cuda() for i in range(2)] if use_mask else None
+        rec = []
+        orig = Awq.calculate_loss
+        a.calculate_loss = lambda org_out, out, _a=a: rec.append(orig(_a, org_out, out)) or rec[-1]
+        layers = {'gate_proj': mlp.gate_proj, 'up_proj': mlp.up_proj}
+        w_before = {n: l.weight.data.clone() for n, l in layers.items()}
+        xs = [dev(g[p + f'x{i}'], dt) for i in range(2)]
+        best = Awq.search_scale_subset(a, None, layers, xs, mlp, False, {})
+        for n, l in layers.items():
+            assert torch.equal(l.weight.data, w_before[n]), name          # weights restored
+            assert 'forward' not in l.__dict__, name                      # HIP forward patch removed
+        ours = np.array([float(v) for v in rec])
+        ref = g[p + 'losses']
+        assert ours.shape == ref.shape == (40,), name
+        np.testing.assert_allclose(ours, ref, rtol=3e-2, err_msg=name)
+        u = ulps(host(best), g[p + 'best_scales'], dt)
+        assert u.max() <= 2, (name, u.max())
+
+
+def test_fused_route_only_for_single_inspected_linear():
+    from llmc_amd.compression.quantization.awq import Awq
+    a = Awq.__new__(Awq)
+    a.padding_mask, a.awq_bs = None, None
+    l1, l2 = torch.nn.Linear(64, 64, bias=False), torch.nn.Linear(64, 64, bias=False)
+    x = [torch.zeros(2, 4, 64)]
+    assert a._fused_route_ok({'o': l1}, x, l1, {})
+    assert not a._fused_route_ok({'q': l1, 'k': l2}, x, torch.nn.Sequential(l1), {})   # inspect = larger module
+    assert not a._fused_route_ok({'o': l1}, x + x, l1, {})                              # several batches
+    assert not a._fused_route_ok({'o': l1}, x, l1, {'attention_mask': None})            # module kwargs
+    a.padding_mask = [torch.ones(2, 4)]
+    assert not a._fused_route_ok({'o': l1}, x, l1, {})

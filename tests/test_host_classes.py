@@ -77,3 +77,58 @@ def test_out_of_scope_config_is_rejected_loudly():
            'kvcache': {'method': 'Naive'}}
     with pytest.raises(NotImplementedError):
         Q.RTN(model, cfg, calib_input(model), None, {})
+
+
+def test_gptq_hessian_sharing_needs_the_same_input_tensor(monkeypatch):
+    """layers of one subset share a Hessian only while their hooked inputs are the very same
+    tensor. MoE-style subset: two experts see different (routed) tokens, the router sees all of them."""
+    import types
+
+    import llmc_amd.compression.quantization.gptq as gq
+
+    class FakeAcc:
+        def __init__(self, K, dev):
+            self.K, self.nsamples, self.fed = K, 0, []
+            self.H = torch.zeros(K, K)
+
+        def add(self, inp):
+            self.fed.append(inp)
+            self.nsamples += inp.shape[0]
+    monkeypatch.setattr(gq, 'HessianAccumulator', FakeAcc)
+    g = gq.GPTQ.__new__(gq.GPTQ)
+    g.layers_cache, g._groups, g._group_of = {}, {}, {}
+    lin = lambda: torch.nn.Linear(8, 4, bias=False)  # noqa: E731
+    layers = {'experts.0.w1': lin(), 'experts.0.w3': lin(), 'experts.1.w1': lin(), 'experts.1.w3': lin(), 'gate': lin()}
+    g.subset_init({'layers': layers})
+    assert len(g._groups) == 1                                     # same in_features: one group to start with
+    for step in range(2):
+        x_all = torch.randn(1, 6, 8)
+        x0, x1 = x_all[:, :4], x_all[:, 4:]                         # routed tokens: different views
+        for n, x in (('gate', x_all), ('experts.0.w1', x0), ('experts.0.w3', x0), ('experts.1.w1', x1),
+                     ('experts.1.w3', x1)):
+            g.add_batch(layers[n], n, x, None)
+    gids = {n: g._group_of[n] for n in layers}
+    assert len(set(gids.values())) == 5
+    # the router keeps the original group; each expert's w1 left it; w3 saw a different tensor than the router too
+    assert gids['gate'] != gids['experts.0.w1'] != gids['experts.1.w1']
+    for n in layers:
+        acc = g.layers_cache[n]['acc']
+        assert len(acc.fed) == 2 and acc.nsamples == 2, n           # every layer's own Hessian saw both batches
+    assert g.layers_cache['gate']['acc'].fed[0].shape[1] == 6 and g.layers_cache['experts.1.w3']['acc'].fed[0].shape[1] == 2
+    # Llama-style subset: the same tensor object -> one accumulator, fed once per call
+    g2 = gq.GPTQ.__new__(gq.GPTQ)
+    g2.layers_cache, g2._groups, g2._group_of = {}, {}, {}
+    qkv = {'q': lin(), 'k': lin(), 'v': lin()}
+    g2.subset_init({'layers': qkv})
+    for step in range(3):
+        h = torch.randn(1, 5, 8)
+        for n in qkv:
+            g2.add_batch(qkv[n], n, h, None)
+    assert len(g2._groups) == 1
+    acc = g2.layers_cache['q']['acc']
+    assert acc is g2.layers_cache['v']['acc'] and len(acc.fed) == 3 and g2.layers_cache['k']['nsamples'] == 3
+    # a member that changes its mind later cannot be repaired: loud failure
+    with pytest.raises(RuntimeError):
+        h = torch.randn(1, 5, 8)
+        g2.add_batch(qkv['q'], 'q', h, None)
+        g2.add_batch(qkv['k'], 'k', h.clone(), None)

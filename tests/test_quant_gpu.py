@@ -198,3 +198,31 @@ def test_cpu_tensor_is_refused():
     q = make_quantizer(4, True, 'per_group', 128)
     with pytest.raises(_ffi.LlmcHipError):
         q.fake_quant_weight_dynamic(torch.randn(4, 128).half())
+
+
+def test_per_tensor_asymmetric_qparams_are_fp32_like_the_reference():
+    """per_tensor + asymmetric — 0-dim min/max against the 0-dim fp32 (qmax - qmin) promote scales / zeros
+    to fp32 (quant.py:132-136,555-556); fake-quant output stays in the weight dtype, codes match bit for bit."""
+    from conftest import load_golden
+    from llmc_amd.compression.quantization import IntegerQuantizer
+    TDm = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}
+    g = load_golden('quant_pt')
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        bit = int(g[p + 'meta'][0])
+        dt = TDm[str(g[p + 'dt'])]
+        q = IntegerQuantizer(bit, False, 'per_tensor')
+        w = torch.from_numpy(g[p + 'w']).to(dt).cuda()
+        _, s, z, _, _ = q.get_tensor_qparams(w)
+        assert str(s.dtype) == str(g[p + 'scales_dtype']) and str(z.dtype) == str(g[p + 'zeros_dtype']), ci
+        assert s.dim() == 0 and z.dim() == 0
+        np.testing.assert_array_equal(s.reshape(-1).cpu().numpy().view(np.uint32), g[p + 'scales'].view(np.uint32))
+        np.testing.assert_array_equal(z.reshape(-1).cpu().numpy(), g[p + 'zeros'])
+        fq = q.fake_quant_weight_dynamic(w)
+        assert str(fq.dtype) == str(g[p + 'fake_dtype'])
+        np.testing.assert_array_equal(fq.float().cpu().numpy().view(np.uint32), g[p + 'fake'].view(np.uint32), err_msg=str(ci))
+        codes, rs, rz = q.real_quant_weight_dynamic(w)
+        assert str(codes.dtype) == str(g[p + 'codes_dtype'])
+        np.testing.assert_array_equal(codes.cpu().numpy().astype(np.int32), g[p + 'codes'], err_msg=str(ci))
+        np.testing.assert_array_equal(rs.float().reshape(-1).cpu().numpy().view(np.uint32), g[p + 'rscales'].view(np.uint32))
+        np.testing.assert_array_equal(rz.reshape(-1).cpu().numpy().astype(np.int32), g[p + 'rzeros'])
