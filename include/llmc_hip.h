@@ -218,7 +218,8 @@ int llmc_mul_cols(void* W, const void* s, int dt, int64_t R, int64_t K, llmc_str
 
 /* The fake-quant W4A16 matmul of Awq.search_scale_subset (awq.py:110-145, 229-236):
  *   Y = X [N, K] . Wq [R, K]^T  (16-bit in, fp32 accumulate on MFMA, rounded to dt like F.linear)
- * mode 0: store Y to Yout [N, R] (dt)                       -- get_original_out
+ * mode 0: store Y to Yout [N, R] (dt); Y0, when not NULL, is a bias [R] (dt) added to the fp32 sum before the single
+ *         rounding, like F.linear / addmm    -- get_original_out, FakeQuantLinear.forward (module_utils.py:619-644)
  * mode 1: loss += sum((Y0 - Y)^2), diff formed in dt like the reference, squared and summed in fp32;
  *         *loss_sum (device fp32, caller zeroes) ; mean = loss_sum / (N*R) is taken by the caller. */
 size_t llmc_linear_eval_ws_bytes(int64_t N, int64_t K, int64_t R);

@@ -35,13 +35,9 @@ class _hip_linear_forward:
     @staticmethod
     def _forward(layer, x):
         w = layer.weight
-        ok = (x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.float16, torch.bfloat16) and w.dim() == 2
-              and w.shape[1] % 64 == 0 and x.numel() * 2 < (1 << 32) and w.numel() * 2 < (1 << 32)
-              and x.numel() // w.shape[1] * w.shape[0] * 2 < (1 << 32))
-        if not ok:
+        if not awq_ops.linear_supported(x, w):
             return nn.functional.linear(x, w, layer.bias)
-        y = awq_ops.linear_out(x, w.data)
-        return y if layer.bias is None else y + layer.bias
+        return awq_ops.linear_out(x, w.data, None if layer.bias is None else layer.bias.data)
 
     def __enter__(self):
         for l in self.layers:

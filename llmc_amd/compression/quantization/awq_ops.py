@@ -87,16 +87,29 @@ def clamp_groups_(w, min_val, max_val, group_size):
     return w
 
 
-def linear_out(x, wq):
-    """F.linear(x, wq) for the inspected Linear: [N, K] x [R, K]^T -> [N, R] in the model dtype."""
-    _ffi.require_gpu(x, wq)
+def linear_supported(x, w):
+    """Shapes / dtypes llmc_linear_eval takes: 16-bit operands of one dtype, K % 64 == 0, every operand < 4 GiB."""
+    if not (x.is_cuda and w.is_cuda and x.dtype == w.dtype and x.dtype in (torch.float16, torch.bfloat16) and w.dim() == 2):
+        return False
+    K, R = w.shape[1], w.shape[0]
+    if x.shape[-1] != K or K % 64 != 0 or x.numel() == 0:
+        return False
+    N = x.numel() // K
+    return max(N * K, R * K, N * R) * 2 < (1 << 32)
+
+
+def linear_out(x, wq, bias=None):
+    """F.linear(x, wq, bias) on the HIP GEMM: [N, K] x [R, K]^T (+ b) -> [N, R], rounded once to the model dtype."""
+    _ffi.require_gpu(x, wq, bias)
     L = _ffi.lib()
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     wq = wq.contiguous()
     N, K = x2.shape
     R = wq.shape[0]
     y = torch.empty((N, R), dtype=x.dtype, device=x.device)
-    _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 0, _ffi.ptr(y), 0, 0, 0,
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 0, _ffi.ptr(y), _ffi.ptr(bias), 0, 0,
                                   _ffi.stream()), 'llmc_linear_eval')
     return y.reshape(*x.shape[:-1], R)
 

@@ -351,8 +351,27 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
 
     @torch.no_grad()
     def save_model(self, path):
+        """base_blockwise_quantization.py:1016-1038: rank 0 writes the (deployed) model + tokenizer. HF models go through
+        their own `save_pretrained` (safetensors + config.json, the files vLLM / AutoAWQ load); any other module is
+        written the same way — `model.safetensors` of the state dict and a `config.json` for the exporters to extend."""
         if int(os.environ.get('RANK', '0')) != 0:
             return
-        self.model.get_model().save_pretrained(path)
+        for t in list(self.model.get_model().parameters()) + list(self.model.get_model().buffers()):
+            if not t.is_contiguous():                          # contiguous_params (base_blockwise_quantization.py:996-1013)
+                t.data = t.data.contiguous()
+        net = self.model.get_model()
+        if hasattr(net, 'save_pretrained'):
+            net.save_pretrained(path)
+        else:
+            import json
+
+            from safetensors.torch import save_file
+            os.makedirs(path, exist_ok=True)
+            sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items() if torch.is_tensor(v)}
+            save_file(sd, os.path.join(path, 'model.safetensors'))
+            cfg = dict(vars(getattr(self.model, 'model_config', None) or object()) if hasattr(self.model, 'model_config') else {})
+            cfg = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool, list, type(None)))}
+            with open(os.path.join(path, 'config.json'), 'w') as f:
+                json.dump(cfg, f, indent=4)
         if getattr(self.model, 'tokenizer', None) is not None:
             self.model.tokenizer.save_pretrained(path)

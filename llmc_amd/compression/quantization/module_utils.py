@@ -10,6 +10,21 @@ import torch.nn as nn
 from .quant import pack_awq_gemm, pack_lsb
 
 
+def hip_linear(x, weight, bias):
+    """y = x W^T + b for the fake-quant wrappers (module_utils.py:619-644, 706-741): the HIP MFMA GEMM
+    (llmc_linear_eval mode 0, fp32 accumulation, one rounding) where its shape rules hold; GPU shapes it does not
+    take (K % 64 != 0, fp32 activations, operands >= 4 GiB) use the framework's GPU linear. Never the CPU."""
+    from llmc_amd import _ffi
+
+    from . import awq_ops
+    _ffi.require_gpu(x, weight)
+    if weight.dtype != x.dtype:
+        weight = weight.to(x.dtype)
+    if awq_ops.linear_supported(x, weight):
+        return awq_ops.linear_out(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def _func_name(f):
     return f.func.__name__ if isinstance(f, partial) else f.__name__
 
@@ -74,7 +89,7 @@ class FakeQuantLinear(nn.Module):
         elif self.dynamic_quant_weight or self.dynamic_quant_tmp_weight:
             self.tmp_weight = self.w_qdq(self)
             self.tmp_bias = self.bias
-        return torch.nn.functional.linear(x, self.tmp_weight.to(x.dtype), self.tmp_bias)
+        return hip_linear(x, self.tmp_weight, self.tmp_bias)
 
     @classmethod
     @torch.no_grad()
@@ -109,7 +124,7 @@ class EffcientFakeQuantLinear(nn.Module):
     def forward(self, x):
         if self.a_qdq is not None:
             x = self.a_qdq(x, self)
-        return torch.nn.functional.linear(x, self.weight, self.bias)
+        return hip_linear(x, self.weight, self.bias)
 
     @classmethod
     @torch.no_grad()

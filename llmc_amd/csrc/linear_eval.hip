@@ -26,7 +26,7 @@ struct LinArgs {
     int64_t N, K, R;
     int mode;         // 0 store Y, 1 loss vs Y0
     char* Y;          // [N, R] dt (mode 0)
-    const char* Y0;   // [N, R] dt (mode 1)
+    const char* Y0;   // [N, R] dt (mode 1); optional bias [R] dt (mode 0)
     float* part;      // [ntiles] partial loss sums (mode 1)
     int ntm, ntn;
 };
@@ -136,10 +136,12 @@ __global__ __launch_bounds__(LTHREADS) void k_linear_eval(LinArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int64_t tok = (int64_t)tm * LT + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (tok < a.N && col < a.R) {
-                        const float y = rndc<DT>(acc[m][n][r]);
                         if (a.mode == 0) {
-                            store_from_f32(a.Y, tok * a.R + col, DT, y);
+                            // optional bias [R] rides in Y0: added to the fp32 sum before the single rounding (addmm)
+                            const float b = a.Y0 ? load_as_f32(a.Y0, col, DT) : 0.0f;
+                            store_from_f32(a.Y, tok * a.R + col, DT, rndc<DT>(acc[m][n][r] + b));
                         } else {
+                            const float y = rndc<DT>(acc[m][n][r]);
                             const float y0 = load_as_f32(a.Y0, tok * a.R + col, DT);
                             const float d = rndc<DT>(y0 - y);
                             lsum += d * d;

@@ -246,3 +246,40 @@ def test_fused_route_only_for_single_inspected_linear():
     assert not a._fused_route_ok({'o': l1}, x, l1, {'attention_mask': None})            # module kwargs
     a.padding_mask = [torch.ones(2, 4)]
     assert not a._fused_route_ok({'o': l1}, x, l1, {})
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('bias', [False, True])
+def test_fake_quant_linear_forward_runs_on_the_hip_gemm(dt, bias, monkeypatch):
+    """FakeQuantLinear / EffcientFakeQuantLinear.forward (module_utils.py:619-644,706-741) go through llmc_linear_eval:
+    same values as F.linear to <= 1 ulp of the model dtype (one rounding of an fp32 sum either way), bias included."""
+    from llmc_amd.compression.quantization import awq_ops
+    from llmc_amd.compression.quantization.module_utils import EffcientFakeQuantLinear, FakeQuantLinear
+    K, R = 512, 384
+    gen = torch.Generator().manual_seed(5)
+    lin = torch.nn.Linear(K, R, bias=bias).to(TD[dt]).cuda()
+    lin.weight.data = (torch.randn(R, K, generator=gen) * 0.05).to(TD[dt]).cuda()
+    if bias:
+        lin.bias.data = torch.randn(R, generator=gen).to(TD[dt]).cuda()
+    q = make_q(True, 128)
+    w_qdq = lambda m: q.fake_quant_weight_dynamic(m.weight.data)  # noqa: E731
+    x = torch.randn(3, 100, K, generator=gen).to(TD[dt]).cuda()
+    calls = []
+    orig = awq_ops.linear_out
+    monkeypatch.setattr(awq_ops, 'linear_out', lambda *a, **k: calls.append(1) or orig(*a, **k))
+    for cls in (FakeQuantLinear, EffcientFakeQuantLinear):
+        m = cls.new(lin, w_qdq, None)
+        y = m(x)
+        wq = w_qdq(lin)
+        ref32 = x.float() @ wq.float().T + (lin.bias.data.float() if bias else 0.0)
+        ref = ref32.to(TD[dt])
+        assert y.shape == ref.shape and y.dtype == TD[dt]
+        err = (y.float() - ref.float()).abs()
+        eps = 2.0 ** -7 if dt == 'bf16' else 2.0 ** -10
+        assert bool((err <= eps * ref.float().abs() + 1e-5 * ref32.abs().max()).all())
+        assert (ulps(host(y), host(ref), dt) > 1).mean() < 1e-3
+    assert len(calls) == 2                                   # both wrappers took the HIP path
+    # shapes the kernel does not take fall back to the framework's linear (K % 64 != 0)
+    lin2 = torch.nn.Linear(100, 16, bias=False).to(TD[dt]).cuda()
+    m2 = EffcientFakeQuantLinear.new(lin2, lambda m: m.weight.data, None)
+    assert m2(torch.randn(2, 100).to(TD[dt]).cuda()).shape == (2, 16) and len(calls) == 2
