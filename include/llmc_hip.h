@@ -182,6 +182,13 @@ int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sy
                        float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
                        float* scales, float* zeros, float* Wout, float* losses, int blocksize,
                        void* ws, llmc_stream_t stream);
+/* OWQ form of the same loop (gptq.py:44-56, 66-83, 199-244 with n_nonout < columns): only the first n_quant columns are
+ * visited; the trailing K - n_quant columns (kept in floating point) still receive every block's error feedback.
+ * Dynamic groups are clipped at n_quant like `min(i + group_size, columns - n_out)` (gptq.py:216-221). */
+int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, int64_t K, int64_t n_quant, int sym, float qmin,
+                       float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
+                       float* scales, float* zeros, float* Wout, float* losses, int blocksize,
+                       void* ws, llmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * AWQ (llmc/compression/quantization/awq.py, auto_clip.py)

@@ -41,6 +41,8 @@ SIGNATURES = {
     'llmc_gptq_quantize_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_gptq_quantize': (_i32, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                   _i32, _vp, _vp]),
+    'llmc_gptq_quantize_cols': (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _f32, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
+                                       _i32, _vp, _vp]),
     'llmc_awq_act_mean_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_awq_act_mean': (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     'llmc_awq_weight_mean_ws_bytes': (_sz, [_i64, _i64]),

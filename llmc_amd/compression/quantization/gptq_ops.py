@@ -83,9 +83,12 @@ def release_workspaces():
 
 
 def gptq_quantize(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, col_group=None, scales=None,
-                  zeros=None, want_losses=True, blocksize=128):
+                  zeros=None, want_losses=True, blocksize=128, n_quant=None, init_scales=None, init_zeros=None):
     """gptq.py:199-244. W [R,K] fp32 (overwritten with the running weights), Hinv [K,K] fp32 upper.
-    Returns (tmp [R,K], losses [R,K] | None, scales [R,ng], zeros [R,ng] | None)."""
+    Returns (tmp [R,K], losses [R,K] | None, scales [R,ng], zeros [R,ng] | None).
+    n_quant < K (OWQ): only the first n_quant columns are quantized, the rest keep receiving the error feedback and
+    are left in W; tmp / losses are zero there and dynamic-group qparams of never-visited groups keep
+    init_scales / init_zeros (the reference's `self.groups` starts from the layer's RTN qparams, gptq.py:380-395)."""
     _ffi.require_gpu(W, Hinv)
     L = _ffi.lib()
     R, K = W.shape
@@ -100,15 +103,22 @@ def gptq_quantize(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, col
         elif not sym:
             raise ValueError('gptq_quantize: zeros required for asymmetric static qparams')
     else:
-        scales = torch.empty((R, ng), dtype=torch.float32, device=dev)
-        zeros = torch.empty((R, ng), dtype=torch.float32, device=dev)
+        if init_scales is not None:
+            scales = init_scales.to(device=dev, dtype=torch.float32).reshape(R, ng).contiguous().clone()
+            zeros = (init_zeros.to(device=dev, dtype=torch.float32).reshape(R, ng).contiguous().clone()
+                     if init_zeros is not None else torch.zeros((R, ng), dtype=torch.float32, device=dev))
+        else:
+            scales = torch.empty((R, ng), dtype=torch.float32, device=dev)
+            zeros = torch.empty((R, ng), dtype=torch.float32, device=dev)
     if col_group is not None:
         col_group = col_group.to(device=dev, dtype=torch.int32).contiguous()
-    tmp = torch.empty_like(W)
-    losses = torch.empty_like(W) if want_losses else None
+    nq = K if n_quant is None else int(n_quant)
+    partial = nq < K
+    tmp = torch.zeros_like(W) if partial else torch.empty_like(W)
+    losses = (torch.zeros_like(W) if partial else torch.empty_like(W)) if want_losses else None
     ws = _ffi.workspace(L.llmc_gptq_quantize_ws_bytes(R, K), dev)
-    _ffi.check(L.llmc_gptq_quantize(
-        _ffi.ptr(W), _ffi.ptr(Hinv), R, K, int(bool(sym)), float(qmin), float(qmax), int(group_size or 0),
+    _ffi.check(L.llmc_gptq_quantize_cols(
+        _ffi.ptr(W), _ffi.ptr(Hinv), R, K, nq, int(bool(sym)), float(qmin), float(qmax), int(group_size or 0),
         int(bool(static_groups)), _ffi.ptr(col_group), _ffi.ptr(scales), _ffi.ptr(zeros), _ffi.ptr(tmp),
-        _ffi.ptr(losses), int(blocksize), _ffi.ptr(ws), _ffi.stream()), 'llmc_gptq_quantize')
+        _ffi.ptr(losses), int(blocksize), _ffi.ptr(ws), _ffi.stream()), 'llmc_gptq_quantize_cols')
     return tmp, losses, scales, zeros

@@ -106,6 +106,48 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
     return out
 
 
+def owq_permutation(h_diag, n_out):
+    """hessian_sorting with OWQ (gptq.py:66-83; OWQ forces actorder off): the non-outlier columns in their original
+    order, then the n_out columns with the largest Hessian diagonal, largest first."""
+    K = h_diag.shape[0]
+    desc = torch.argsort(h_diag, descending=True)
+    keep = torch.ones(K, dtype=torch.bool, device=h_diag.device)
+    keep[desc[:n_out]] = False
+    return torch.cat([torch.arange(K, device=h_diag.device)[keep], desc[:n_out]])
+
+
+def quantize_owq(W, H, cfg, n_out, wquantizer, rtn_scales=None, rtn_zeros=None, h_work=None):
+    """GPTQ + OWQ for ONE layer (gptq.py:44-56, 128-196): n_out outlier columns (largest Hessian diagonal) are moved
+    last, kept in floating point and only receive the error feedback. Returns a GptqResult whose `weight` already has
+    the compensated fp outlier columns in place and is back in the original column order; `n_nonout` rides in `extra`."""
+    _ffi.require_gpu(H, W)
+    K = H.shape[0]
+    n_nonout = K - int(n_out)
+    perm = owq_permutation(torch.diagonal(H), int(n_out))
+    Hp, Wp = gptq_ops.hessian_prep(H, W, perm, cfg.percdamp, want_h=True, h_out=h_work)
+    U, info = gptq_ops.chol_inv_upper(Hp, check=False, return_info=True)
+    qmin, qmax = cfg.qrange
+    R = Wp.shape[0]
+    if cfg.group_size:
+        ng = K // cfg.group_size
+        init_s = rtn_scales.reshape(R, ng) if rtn_scales is not None else None
+        init_z = rtn_zeros.reshape(R, ng) if (rtn_zeros is not None and rtn_zeros.dim() > 0) else None
+        tmp, losses, s, z = gptq_ops.gptq_quantize(Wp, U, cfg.symmetric, qmin, qmax, cfg.group_size, n_quant=n_nonout,
+                                                   init_scales=init_s, init_zeros=init_z, blocksize=cfg.blocksize)
+    else:
+        # per_channel: qparams of the permuted, dead-zeroed non-outlier columns in fp32 (gptq.py:157-164)
+        _, s, z, _, _ = wquantizer.get_tensor_qparams(Wp[:, :n_nonout].contiguous())
+        tmp, losses, s, z = gptq_ops.gptq_quantize(Wp, U, cfg.symmetric, qmin, qmax, 0, scales=s,
+                                                   zeros=None if cfg.symmetric else z, n_quant=n_nonout,
+                                                   blocksize=cfg.blocksize)
+    tmp[:, n_nonout:] = Wp[:, n_nonout:]                     # gptq.py:187: the compensated fp outlier columns
+    invperm = torch.argsort(perm)
+    K4 = tmp.shape[1]
+    tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= 16384) else tmp.index_select(1, invperm)
+    return GptqResult(weight=tmp, scales=s, zeros=None if cfg.symmetric else z, perm=perm,
+                      loss=losses.sum() if losses is not None else None, info=info)
+
+
 def hessian_from_activations(X, acc=None):
     """X [n_seq, seq, K] (or [tokens, K]) 16-bit on the GPU -> H fp32 [K, K] with add_batch's scaling."""
     K = X.shape[-1]

@@ -438,7 +438,21 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
                                   float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
                                   float* scales, float* zeros, float* Wout, float* losses, int blocksize,
                                   void* ws, llmc_stream_t stream) {
+    return llmc_gptq_quantize_cols(W, Hinv, R, K, K, sym, qmin, qmax, group_size, static_groups, col_group, scales,
+                                   zeros, Wout, losses, blocksize, ws, stream);
+}
+
+// OWQ form (gptq.py:44-56,199-244 with n_nonout < columns): only the first n_quant columns are visited by the column
+// loop; the trailing K - n_quant columns (the outlier columns OWQ keeps in floating point) still receive every
+// block's error feedback `W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:]`. Groups are clipped at n_quant like the reference's
+// `min(i + group_size, columns - n_out)`.
+extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, int64_t K, int64_t n_quant, int sym,
+                                       float qmin, float qmax, int64_t group_size, int static_groups,
+                                       const int32_t* col_group, float* scales, float* zeros, float* Wout,
+                                       float* losses, int blocksize, void* ws, llmc_stream_t stream) {
     LLMC_REQUIRE(W && Hinv && Wout && scales && ws && R > 0 && K > 0, "gptq_quantize: null/empty argument");
+    LLMC_REQUIRE(n_quant > 0 && n_quant <= K, "gptq_quantize: n_quant must be in (0, K]");
+    const int64_t NQ = n_quant;
     LLMC_REQUIRE(blocksize == BS, "gptq_quantize: blocksize must be 128");
     LLMC_REQUIRE(K % 4 == 0 && K < (1 << 30), "gptq_quantize: K must be a multiple of 4");
     LLMC_REQUIRE(sym || zeros, "gptq_quantize: zeros required for asymmetric");
@@ -467,11 +481,14 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
     // The far update is split: the next group's columns on the main stream, everything beyond on a side stream,
     // overlapped with the next group's latency-bound in-block kernels (the order per element is unchanged).
     int gidx = 0;
-    for (int64_t g0 = 0; g0 < K; g0 += (int64_t)BS * GRP, ++gidx) {
-        const int64_t gend = g0 + (int64_t)BS * GRP < K ? g0 + (int64_t)BS * GRP : K;
+    for (int64_t g0 = 0; g0 < NQ; g0 += (int64_t)BS * GRP, ++gidx) {
+        const int64_t gend = g0 + (int64_t)BS * GRP < NQ ? g0 + (int64_t)BS * GRP : NQ;
+        // columns updated right after every block: up to the end of the outer group; in the LAST group also the
+        // never-visited columns beyond n_quant (their group-wide phased update could start on a ragged phase)
+        const int64_t near_end = gend == NQ ? K : gend;
         float* Err = ErrBuf[gidx & 1];
         for (int64_t i1 = g0; i1 < gend; i1 += BS) {
-            const int count = (int)(K - i1 < BS ? K - i1 : BS);
+            const int count = (int)(NQ - i1 < BS ? NQ - i1 : BS);
             GptqBlockArgs a;
             a.W = W; a.U = Hinv; a.Wout = Wout; a.losses = losses;
             a.Err = Err + (i1 - g0); a.err_ld = ELD;
@@ -496,18 +513,21 @@ extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_
             }
             LLMC_LAUNCH_CHECK();
             const int64_t i2 = i1 + count;
-            if (i2 < gend) {   // near columns of the group
+            if (i2 < near_end) {   // near columns of the group
+                // the GEMM wants 16-B aligned operands: a ragged n_quant (OWQ) starts up to 3 columns early, on
+                // columns the loop has already visited — W is dead there (their values live in Wout)
+                const int64_t c0 = i2 & ~(int64_t)3;
                 SgemmArgs g{};
                 g.A = Err + (i1 - g0); g.lda = ELD;
-                g.B = Hinv + i1 * K + i2; g.ldb = K;
-                g.C = W + i2; g.ldc = K;
-                g.M = g.M_last = (int)R; g.N = g.N_last = (int)(gend - i2); g.Kd = g.Kd_last = count;
+                g.B = Hinv + i1 * K + c0; g.ldb = K;
+                g.C = W + c0; g.ldc = K;
+                g.M = g.M_last = (int)R; g.N = g.N_last = (int)(near_end - c0); g.Kd = g.Kd_last = count;
                 g.epilogue = SG_SUB; g.batch = 1;
                 int rc = sgemm_launch(g, false, false, st);
                 if (rc) return rc;
             }
         }
-        if (gend < K) {        // far columns: GRP phases of 128
+        if (near_end < K) {    // far columns: GRP phases of 128
             const int64_t gend2 = gend + (int64_t)BS * GRP < K ? gend + (int64_t)BS * GRP : K;
             if (side && pending_side) {   // columns gend.. were last written by the previous group's side update,
                 int rc = join_from_side(side, st);   // which also still reads the other err buffer

@@ -338,6 +338,75 @@ def suite_gptq():
     save('gptq', **out)
 
 
+def suite_gptq_owq():
+    """GPTQ with OWQ (gptq.py:44-56, 66-83, 199-244): the n_out columns with the largest Hessian diagonal go last, stay
+    in floating point and only receive the error feedback; groups are clipped at columns - n_out."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29594', rank=0, world_size=1)
+    out = {}
+    cfgs = [('asym_g128_owq6', 4, False, 'per_group', 128, 'bf16', 24, 256, 6),
+            ('sym_g64_owq16', 4, True, 'per_group', 64, 'f16', 32, 256, 16),
+            ('asym_pc_owq8', 4, False, 'per_channel', None, 'f16', 16, 256, 8)]
+    gen = torch.Generator().manual_seed(31337)
+    for (name, bit, sym, gran, gs, dt, R, K, n_out) in cfgs:
+        kw = dict(group_size=gs) if gs else {}
+        wq = IntegerQuantizer(bit, sym, gran, **kw)
+        g = _gptq_instance(wq, False, False, dtype=DT[dt])
+        g.owq, g.need_perm, g.n_out_dict = True, True, {'fc': n_out}
+        layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+        layer.weight.data = rand_weight(gen, R, K, dt)
+        _, s0, z0, qmax, qmin = wq.get_tensor_qparams(layer.weight.data)
+        layer.register_buffer('buf_scales', s0.detach())
+        layer.register_buffer('buf_zeros', z0.detach())
+        layer.register_buffer('buf_qmax', torch.tensor(qmax))
+        layer.register_buffer('buf_qmin', torch.tensor(qmin))
+        g.layers_cache['fc'] = {}
+        g.layer_init(layer, 'fc')
+        xs = []
+        for b in range(2):
+            x = (torch.randn(1, 96, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen)))
+            x[..., 5] *= 30
+            x[..., 77] *= 12
+            x = x.to(DT[dt])
+            xs.append(x)
+            g.add_batch(layer, 'fc', x, None)
+        H = g.layers_cache['fc']['H'].clone()
+        rtn_s, rtn_z = layer.buf_scales.clone(), layer.buf_zeros.clone()
+        g.initialize_qparams_and_prepare_weights(layer, 'fc')
+        W0 = layer.weight.data.clone()
+        Wp, U = g.process_hessian_and_weights(layer, 'fc')
+        Wp_in = Wp.clone()
+        Losses, tmp, Wrun = torch.zeros_like(Wp), torch.zeros_like(Wp), Wp.clone()
+        g.weight_transform(Wrun, U, Losses, tmp)
+        p = name + '/'
+        out[p + 'W0'] = f32(W0)
+        out[p + 'Hdiag'] = f32(torch.diag(H))
+        out[p + 'perm'] = g.perm.numpy().astype(np.int64)
+        out[p + 'Wp'], out[p + 'U'] = f32(Wp_in), f32(U)
+        out[p + 'tmp'], out[p + 'losses'], out[p + 'W_after'] = f32(tmp), f32(Losses), f32(Wrun)
+        out[p + 'rtn_scales'] = f32(rtn_s).reshape(-1)
+        out[p + 'rtn_zeros'] = f32(rtn_z).reshape(-1) if rtn_z.dim() > 0 else np.zeros(0, np.float32)
+        # finish the layer like update_layer_with_transformed_weights (gptq.py:186-196)
+        t2 = tmp.clone()
+        t2[:, g.n_nonout:] = Wrun[:, g.n_nonout:]
+        t2 = t2[:, g.invperm]
+        layer.weight.data = t2.reshape(layer.weight.shape)
+        if gran == 'per_group':
+            g.update_model_qparams(layer)
+        out[p + 'final_w'] = f32(layer.weight.data)
+        out[p + 'buf_scales'] = f32(layer.buf_scales).reshape(-1)
+        out[p + 'buf_scales_dtype'] = np.array(str(layer.buf_scales.dtype))
+        bz = layer.buf_zeros
+        out[p + 'buf_zeros'] = f32(bz).reshape(-1) if bz.dim() > 0 else np.zeros(0, np.float32)
+        fq = g.w_qdq(layer, wq)
+        out[p + 'w_qdq'], out[p + 'w_qdq_dtype'] = f32(fq), np.array(str(fq.dtype))
+        out[p + 'meta'] = np.array([bit, int(sym), gs or 0, R, K, n_out, float(qmin), float(qmax)], dtype=np.float64)
+        out[p + 'dt'], out[p + 'gran'] = np.array(dt), np.array(gran)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('gptq_owq', **out)
+
+
 def suite_awq():
     """Awq.search_scale_subset (20-point grid, one batch) with inspect = the stacked Linear layers."""
     import torch.distributed as dist
@@ -660,7 +729,7 @@ def suite_mse():
     save('mse', **out)
 
 SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt}
+          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

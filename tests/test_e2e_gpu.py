@@ -191,3 +191,34 @@ def test_awq_matches_reference_classes():
         got = _linears(model)[n].weight.data.float().cpu().numpy()
         ref = g['awq/w/' + n]
         assert np.mean(np.abs(got - ref) <= 2.0 ** -5 * np.abs(ref).max()) > 0.97, n
+
+
+def test_gptq_owq_block_loop_keeps_outlier_columns_in_floating_point():
+    """OWQ through the class (quant.special.owq / n_outs, gptq.py:44-56,89-93): buf_n_nonout / buf_perm are set, the
+    n_out columns with the largest Hessian diagonal are NOT on the 4-bit grid after deploy('fake_quant'), the rest are."""
+    import llmc_amd.compression.quantization as Q
+    model, inp, config = make(None)
+    qc = Cfg(weight=Cfg(bit=4, symmetric=False, granularity='per_group', group_size=128),
+             special=Cfg(actorder=True, static_groups=True, percdamp=0.01, blocksize=128, true_sequential=False,
+                         owq=True, n_outs=[6, 6, 8]),
+             quant_out=False)
+    algo = Q.GPTQ(model, qc, copy.deepcopy(inp), None, config)
+    assert algo.owq and not algo.actorder and not algo.static_groups and algo.need_perm      # forced by OWQ
+    algo.run_block_loop()
+    blk = model.get_blocks()[0]
+    for name, n_out in (('gate_proj', 6), ('up_proj', 6), ('down_proj', 8)):
+        m = getattr(blk, name)
+        K = m.weight.shape[1]
+        assert int(m.buf_n_nonout) == K - n_out and m.buf_perm.shape == (K,)
+        assert m.weight.dtype == torch.float32
+        assert sorted(m.buf_perm.tolist()) == list(range(K))
+    algo.deploy('fake_quant')
+    fq = model.get_blocks()[0].gate_proj
+    w = fq.weight.float()
+    perm = fq.buf_perm
+    out_cols = perm[-6:]
+    # quantized columns: at most 16 distinct values per (row, group of the PERMUTED order); outlier columns are free
+    wp = w[:, perm][:, :256 - 6]
+    g0 = wp[:, :128]
+    assert max(len(torch.unique(g0[r])) for r in range(8)) <= 16
+    assert len(torch.unique(w[:, out_cols])) > 16 * 6

@@ -117,8 +117,20 @@ def test_autoawq_checkpoint_round_trip(tmp_path):
         fq = q.fake_quant_weight_dynamic(lin.weight.data.cuda()).float().cpu().numpy()     # [R, K]
         got = deq.reshape(K, R).T
         # gemm_pack re-derives the codes as round((w + z*s)/s) in fp16 WITHOUT a clamp (module_utils.py:1018-1030, as
-        # AutoAWQ's own packer does): a group maximum can land on 16 and spill into the neighbouring nibble. Those rare
-        # words are reproduced bit-exactly from the reference (tests/golden/pack.npz); everywhere else the decoded
-        # weight is the deployed fake quantisation
+        # AutoAWQ's own packer does): fp16 rounding of w + z*s moves ~0.3 % of the codes by one step against
+        # clamp(round(w/s) + z), and a group maximum can land on 16 and spill into the neighbouring nibble. So: the
+        # stored codes equal an independent fp16 restatement of that formula wherever it stays inside [0, 15] ...
+        _, s16, z16 = q.real_quant_weight_dynamic(lin.weight.data.cuda())
+        s16, z16 = s16.to(torch.float16).cpu(), z16.cpu()
+        w16 = lin.weight.data.cpu().to(torch.float16)
+        sz = (s16 * z16.to(torch.float16))                                           # scale_zeros, fp16
+        want = torch.round((w16.reshape(R, K // 128, 128) + sz[:, :, None]) / s16[:, :, None]).reshape(R, K).int()
+        inside = (want >= 0) & (want <= 15)
+        got_codes = torch.from_numpy(codes.T.copy())                                   # [R, K]
+        spill = (~inside).T.reshape(K, R // 8, 8).any(-1).repeat_interleave(8, 1).T   # words (8 rows of R) hit by an overflow
+        assert torch.equal(got_codes[~spill], want[~spill]) and float(spill.float().mean()) < 0.02
+        np.testing.assert_array_equal(zeros, z16.numpy().astype(np.int32).T)
+        np.testing.assert_array_equal(sc.numpy(), s16.numpy().T)
+        # ... and the decoded weight is the deployed fake quantisation up to those one-step differences
         ok = np.abs(got - fq) <= 2 ** -10 * np.abs(fq).max() + 1e-7
-        assert ok.mean() > 0.999, ok.mean()
+        assert ok.mean() > 0.99, ok.mean()

@@ -400,3 +400,72 @@ def test_chol_inv_upper_large_property(K):
     E = U @ H @ U.T
     E.diagonal().sub_(1.0)
     assert E.abs().max().item() < 1e-3
+
+
+def test_owq_column_loop_and_layer_finish_match_reference_golden():
+    """OWQ (gptq.py:44-56, 66-83): outlier columns last, never quantized, still fed the error; groups clipped at
+    columns - n_out. Given the reference's own Hinv the loop is bit-exact; perm, final weights, merged qparams and the
+    deploy-time fake quantization (fp outlier columns restored) follow."""
+    import types
+
+    from llmc_amd.compression.quantization import IntegerQuantizer
+    from llmc_amd.compression.quantization.gptq import GPTQ
+    from llmc_amd.compression.quantization.gptq_ops import gptq_quantize
+    TDm = {'f16': torch.float16, 'bf16': torch.bfloat16, 'torch.float16': torch.float16, 'torch.bfloat16': torch.bfloat16}
+    g = load_golden('gptq_owq')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        bit, sym, gs, R, K, n_out, qmin, qmax = g[p + 'meta']
+        bit, sym, gs, R, K, n_out = int(bit), bool(sym), int(gs), int(R), int(K), int(n_out)
+        nn_ = K - n_out
+        # hessian_sorting, OWQ form (actorder is forced off): non-outlier columns in original order, then the n_out
+        # largest Hessian diagonals in descending order
+        perm = GPTQ.owq_permutation(cu(g[p + 'Hdiag']), n_out)
+        np.testing.assert_array_equal(perm.cpu().numpy(), g[p + 'perm'], err_msg=name)
+        ng = 1 if gs == 0 else K // gs
+        if gs:
+            init_s = cu(g[p + 'rtn_scales']).reshape(R, ng)
+            init_z = cu(g[p + 'rtn_zeros']).reshape(R, ng) if g[p + 'rtn_zeros'].size else None
+            Wd = cu(g[p + 'Wp'])
+            tmp, losses, s, z = gptq_quantize(Wd, cu(g[p + 'U']), sym, qmin, qmax, gs, n_quant=nn_,
+                                              init_scales=init_s, init_zeros=init_z)
+        else:
+            # per_channel OWQ: qparams of the permuted non-outlier columns (gptq.py:157-164), fp32 weights
+            q32 = IntegerQuantizer(bit, sym, 'per_channel')
+            _, s_pc, z_pc, _, _ = q32.get_tensor_qparams(cu(g[p + 'Wp'])[:, :nn_].contiguous())
+            Wd = cu(g[p + 'Wp'])
+            tmp, losses, s, z = gptq_quantize(Wd, cu(g[p + 'U']), sym, qmin, qmax, 0, scales=s_pc,
+                                              zeros=None if sym else z_pc, n_quant=nn_)
+        np.testing.assert_array_equal(bits(tmp.cpu().numpy()), bits(g[p + 'tmp']), err_msg=name)
+        np.testing.assert_array_equal(bits(losses.cpu().numpy()), bits(g[p + 'losses']), err_msg=name)
+        np.testing.assert_array_equal(bits(Wd.cpu().numpy()[:, nn_:]), bits(g[p + 'W_after'][:, nn_:]), err_msg=name)
+        # finish like update_layer_with_transformed_weights (gptq.py:186-196)
+        final = tmp.clone()
+        final[:, nn_:] = Wd[:, nn_:]
+        final = final[:, torch.argsort(perm)]
+        np.testing.assert_array_equal(bits(final.cpu().numpy()), bits(g[p + 'final_w']), err_msg=name)
+        if gs:
+            np.testing.assert_array_equal(bits(s.reshape(-1).cpu().numpy()), bits(g[p + 'buf_scales']), err_msg=name)
+            if not sym:
+                np.testing.assert_array_equal(bits(z.reshape(-1).cpu().numpy()), bits(g[p + 'buf_zeros']), err_msg=name)
+        # w_qdq with OWQ: fake-quant in permuted order, fp outlier columns restored, un-permuted, model dtype
+        layer = torch.nn.Linear(K, R, bias=False)
+        layer.weight.data = final.clone()
+        sdt = torch.float32
+        layer.register_buffer('buf_scales', cu(g[p + 'buf_scales']).to(sdt).reshape(-1, 1))
+        if g[p + 'buf_zeros'].size:
+            layer.register_buffer('buf_zeros', cu(g[p + 'buf_zeros']).to(sdt).reshape(-1, 1))
+        else:
+            layer.register_buffer('buf_zeros', torch.tensor(0.0))
+        layer.register_buffer('buf_qmax', torch.tensor(qmax))
+        layer.register_buffer('buf_qmin', torch.tensor(qmin))
+        layer.register_buffer('buf_perm', perm)
+        layer.register_buffer('buf_invperm', torch.argsort(perm))
+        layer.register_buffer('buf_n_nonout', torch.tensor(nn_))
+        layer = layer.cuda()
+        gran = str(g[p + 'gran'])
+        wq = IntegerQuantizer(bit, sym, gran, **({'group_size': gs} if gs else {}))
+        this = types.SimpleNamespace(need_perm=True, owq=True, model_dtype=TDm[str(g[p + 'dt'])])
+        fq = GPTQ.w_qdq(this, layer, wq)
+        assert fq.dtype == TDm[str(g[p + 'w_qdq_dtype'])]
+        np.testing.assert_array_equal(bits(fq.float().cpu().numpy()), bits(g[p + 'w_qdq']), err_msg=name)
