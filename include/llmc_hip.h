@@ -258,6 +258,29 @@ int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64
 int llmc_test_gemm3(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
                     int Kd, int TA, int epilogue, int a_upper, int b_upper, int c_upper_only, llmc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FP8 block-wise (DeepSeek-V3 style): llmc/compression/quantization/kernel.py (Triton) and FloatQuantizer `per_block`
+ * ------------------------------------------------------------------------------------------------ */
+/* weight_cast_to_fp8 (kernel.py:58-86; quant.py:33-43) and FloatQuantizer per_block fake / real quant
+ * (quant.py:132-143, 612-658, 1043-1072, 1195-1221). W [M, N] dt; one fp32 scale per block x block tile, row-major
+ * [ceil(M/block), ceil(N/block)]: scale = max(absmax, clamp_min) / 448; q = e4m3fn(W / scale) (fp32 division, RNE).
+ * clamp_min = 1e-5: FloatQuantizer (`.clamp(min=1e-5)`, zero scales replaced by 1); clamp_min = 0: the Triton kernel
+ * (an all-zero block yields scale 0 and NaN codes, like 0 / 0 there). fake bit 0: out is dt = q * scale, else e4m3
+ * bytes; fake bit 1: `scales` is an INPUT (the *_static forms, quant.py:1074-1160). */
+int llmc_fp8_block_quant(const void* W, int dt, int64_t M, int64_t N, int block, float clamp_min, int fake, void* out,
+                         float* scales, llmc_stream_t stream);
+/* weight_cast_to_bf16 (kernel.py:89-143; quant.py:18-30): out[m, n] = float(W8[m, n]) * scales[m/block, n/block] in out_dt. */
+int llmc_fp8_block_dequant(const void* W8, const float* scales, int64_t M, int64_t N, int block, int out_dt, void* out,
+                           llmc_stream_t stream);
+/* act_quant (kernel.py:7-55): X contiguous, n_elem elements, every `block` consecutive ones share scale = absmax / 448
+ * (fp32, no clamp); out8 e4m3 bytes, scales [n_elem / block]. */
+int llmc_fp8_act_quant(const void* X, int dt, int64_t n_elem, int block, void* out8, float* scales, llmc_stream_t stream);
+/* fp8_gemm + block_wise_fp8_forward_func (kernel.py:146-242; module_utils.py:40-45): A8 [M, K] e4m3 with a_s [M, K/128],
+ * B8 [N, K] e4m3 (a weight) with b_s [N/128, K/128]; C [M, N] out_dt = sum over 128-deep K blocks of
+ * (A_kb . B_kb^T) * a_s * b_s, fp32 accumulation on the fp8 MFMA; bias [N] (out_dt) is added after the rounding. */
+int llmc_fp8_block_gemm(const void* A8, const float* a_s, const void* B8, const float* b_s, int64_t M, int64_t N,
+                        int64_t K, int out_dt, const void* bias, void* C, llmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,10 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp]),
     'llmc_fp8_quant_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_fp8_quant': (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'llmc_fp8_block_quant': (_i32, [_vp, _i32, _i64, _i64, _i32, _f32, _i32, _vp, _vp, _vp]),
+    'llmc_fp8_block_dequant': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    'llmc_fp8_act_quant': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    'llmc_fp8_block_gemm': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     'llmc_pack_awq_gemm': (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     'llmc_test_sgemm': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i32, _vp]),

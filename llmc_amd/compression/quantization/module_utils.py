@@ -266,6 +266,44 @@ class MlcllmRealQuantLinear(AutoawqRealQuantLinear):
     pass
 
 
+class LlmcFp8Linear(nn.Module):
+    """module_utils.py:130-191: a Linear whose checkpoint weight is block-scaled FP8 (DeepSeek-V3): `weight`
+    float8_e4m3fn [R, K] + `weight_scale_inv` fp32 [ceil(R/b), ceil(K/b)]. forward quantizes the activation per
+    1 x b block and runs the block-scaled fp8 GEMM (kernel.block_wise_fp8_forward_func) — on gfx950 the HIP kernels
+    replace the reference's Hopper-only Triton path, so its bf16 de-quantize-and-F.linear fallback is not needed."""
+
+    def __init__(self, in_features, out_features, bias, block_size):
+        super().__init__()
+        self.block_size, self.in_features, self.out_features = block_size, in_features, out_features
+        if bias is not None:
+            self.bias = nn.Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=torch.float8_e4m3fn), requires_grad=False)
+        so, si = -(-out_features // block_size), -(-in_features // block_size)
+        self.weight_scale_inv = nn.Parameter(torch.empty(so, si, dtype=torch.float32), requires_grad=False)
+
+    def forward(self, x):
+        from .kernel import block_wise_fp8_forward_func, weight_cast_to_bf16
+        if self.weight.data.dtype == torch.float8_e4m3fn:
+            if self.block_size == 128 and x.shape[-1] % 128 == 0:
+                return block_wise_fp8_forward_func(x, self.weight.data, self.weight_scale_inv.data, self.block_size,
+                                                   None if self.bias is None else self.bias.data)
+            w = weight_cast_to_bf16(self.weight.data, self.weight_scale_inv.data, self.block_size)
+            return hip_linear(x, w, self.bias)
+        return hip_linear(x, self.weight, self.bias)
+
+    @classmethod
+    @torch.no_grad()
+    def new(cls, module, block_size):
+        return cls(module.in_features, module.out_features, module.bias, block_size)
+
+    def __repr__(self):
+        return (f'LlmcFp8Linear(in_features={self.in_features}, out_features={self.out_features}, '
+                f'bias={self.bias is not None}, weight_shape={self.weight.shape}, weight_dtype={self.weight.dtype}, '
+                f'block_size={self.block_size})')
+
+
 _TRANSFORMERS_LINEAR_TYPES_ = [nn.Linear]
 _TRANSFORMERS_LN_TYPES_ = [nn.LayerNorm]
 try:  # RMSNorm-style layers of HF models count as LN types for apply_scale
@@ -277,7 +315,7 @@ if hasattr(nn, 'RMSNorm') and nn.RMSNorm not in _TRANSFORMERS_LN_TYPES_:
     _TRANSFORMERS_LN_TYPES_.append(nn.RMSNorm)
 
 _LLMC_LN_TYPES_ = []
-_LLMC_LINEAR_TYPES_ = [OriginFloatLinear, FakeQuantLinear, EffcientFakeQuantLinear, VllmRealQuantLinear,
+_LLMC_LINEAR_TYPES_ = [LlmcFp8Linear, OriginFloatLinear, FakeQuantLinear, EffcientFakeQuantLinear, VllmRealQuantLinear,
                        SglRealQuantLinear, AutoawqRealQuantLinear, MlcllmRealQuantLinear, LightllmRealQuantLinear]
 _REALQUANT_LINEAR_MAP_ = {
     'vllm_quant': VllmRealQuantLinear,

@@ -42,7 +42,7 @@ class BaseQuantizer(object):
         elif self.granularity == 'per_head':
             self.head_num = self.kwargs['head_num']
         elif self.granularity == 'per_block':
-            raise NotImplementedError('per_block (DeepSeek FP8 block-wise) is outside the hot path')
+            self.block_size = self.kwargs['block_size']
 
         if self.kwargs.get('ste', False) or self.kwargs.get('ste_all', False):
             raise NotImplementedError('STE rounding (training-time) is outside the hot path')
@@ -402,7 +402,7 @@ class FloatQuantizer(BaseQuantizer):
         self.quant_type = 'float-quant'
         if self.bit != 'e4m3':
             raise NotImplementedError(f'FloatQuantizer bit={self.bit}: only e4m3 is on the accelerated path')
-        if self.granularity not in ('per_tensor', 'per_channel', 'per_token'):
+        if self.granularity not in ('per_tensor', 'per_channel', 'per_token', 'per_block'):
             raise NotImplementedError(f'FloatQuantizer granularity={self.granularity}')
         self.e_bits, self.m_bits = 4, 3
         self.use_qtorch = self.kwargs.get('use_qtorch', True)
@@ -429,12 +429,42 @@ class FloatQuantizer(BaseQuantizer):
                                     _ffi.dt(sdtype), int(static), _ffi.ptr(ws), _ffi.stream()), 'llmc_fp8_quant')
         return out, s.reshape(self._qparam_shape(tensor))
 
+    # ---- per_block (quant.py:132-143, 612-658): b x b tiles of a 2-D weight, fp32 scales [M/b, 1, N/b, 1] ----------
+    def _run_block(self, weight, fake, scales=None):
+        _ffi.require_gpu(weight, scales)
+        if weight.dim() != 2:
+            raise ValueError('per_block quantization takes a 2-D weight')
+        L = _ffi.lib()
+        w = weight.contiguous()
+        M, N = w.shape
+        b = int(self.block_size)
+        mb, nb = -(-M // b), -(-N // b)
+        static = scales is not None
+        s = (scales.reshape(mb, nb).to(device=w.device, dtype=torch.float32).contiguous() if static
+             else torch.empty((mb, nb), dtype=torch.float32, device=w.device))
+        out = torch.empty_like(w) if fake else torch.empty((M, N), dtype=torch.uint8, device=w.device)
+        _ffi.check(L.llmc_fp8_block_quant(_ffi.ptr(w), _ffi.dt(w), M, N, b, 1e-5, int(bool(fake)) | (2 if static else 0),
+                                          _ffi.ptr(out), _ffi.ptr(s), _ffi.stream()), 'llmc_fp8_block_quant')
+        return out, s
+
     def get_tensor_qparams(self, tensor, args={}):
+        if self.granularity == 'per_block':
+            _, s = self._run_block(tensor, True)
+            b = int(self.block_size)
+            M, N = tensor.shape
+            mb, nb = s.shape
+            t = tensor
+            if M % b or N % b:                      # the reference pads with zeros before viewing [M/b, b, N/b, b]
+                t = torch.zeros((mb * b, nb * b), dtype=tensor.dtype, device=tensor.device)
+                t[:M, :N] = tensor
+            return t.view(mb, b, nb, b), s.view(mb, 1, nb, 1), torch.tensor(0.0), self.qmax, self.qmin
         tensor = self.reshape_tensor(tensor)
         _, scales = self._run(tensor, True)
         return tensor, scales, torch.tensor(0.0), self.qmax, self.qmin
 
     def fake_quant_weight_dynamic(self, weight, args={}):
+        if self.granularity == 'per_block':
+            return self._run_block(weight, True)[0]
         out, _ = self._run(self.reshape_tensor(weight), True)
         return out.reshape(weight.shape)
 
@@ -447,6 +477,8 @@ class FloatQuantizer(BaseQuantizer):
         return out.reshape(act.shape)
 
     def fake_quant_weight_static(self, weight, args):
+        if self.granularity == 'per_block':
+            return self._run_block(weight, True, scales=args['scales'])[0]
         out, _ = self._run(self.reshape_tensor(weight), True, scales=args['scales'])
         return out.reshape(weight.shape)
 
@@ -456,16 +488,35 @@ class FloatQuantizer(BaseQuantizer):
         return weight, scales.reshape(qshape), None
 
     def real_quant_weight_dynamic(self, weight, args={}):
+        if self.granularity == 'per_block':         # scales.view(scales.shape[0], scales.shape[2]) (quant.py:1215-1216)
+            bits, s = self._run_block(weight, False)
+            return bits.view(torch.float8_e4m3fn), s, None
         bits, scales = self._run(self.reshape_tensor(weight), False)
         return self._finish(bits, scales, weight.shape)
 
     def real_quant_weight_static(self, weight, args):
+        if self.granularity == 'per_block':
+            bits, s = self._run_block(weight, False, scales=args['scales'])
+            return bits.view(torch.float8_e4m3fn), s, None
         bits, scales = self._run(self.reshape_tensor(weight), False, scales=args['scales'])
         return self._finish(bits, scales, weight.shape)
 
     def __repr__(self):
         return (f'FloatQuantizer(bit={self.bit},e_bits={self.e_bits}, m_bits={self.m_bits},'
                 f'granularity={self.granularity},kwargs={self.kwargs}, qmin={self.qmin}, qmax={self.qmax})')
+
+
+def weight_cast_to_bf16(weight, scale, block_size):
+    """quant.py:18-30 (the non-Triton spelling of kernel.py's function): block-scaled e4m3 weight -> bf16."""
+    from .kernel import weight_cast_to_bf16 as _cast
+    return _cast(weight.contiguous(), scale.contiguous(), block_size, dtype=torch.bfloat16)
+
+
+def weight_cast_to_fp8(weight, block_size):
+    """quant.py:33-43: FloatQuantizer(e4m3, per_block).real_quant_weight_dynamic -> (fp8 weight, fp32 block scales)."""
+    q = FloatQuantizer(bit='e4m3', symmetric=True, granularity='per_block', block_size=block_size, use_qtorch=True)
+    w, s, _ = q.real_quant_weight_dynamic(weight)
+    return w, s
 
 
 def pack_awq_gemm(weight, scales, zeros, group_size):

@@ -80,6 +80,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float v) {
     return u;
 }
 
+// Make an fp32 value opaque to the optimiser. hipcc folds `(f16)(a * b)` into v_fma_mixlo_f16 a, b, +0: the added +0
+// turns a product of -0.0 into +0.0 ((-0) + (+0) = +0), which the reference's `(q - 0) * s` keeps negative.
+__device__ __forceinline__ float opaque_f32(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // round an fp32 value to storage dtype `dt` and come back to fp32 (ATen "opmath" semantics)
 __device__ __forceinline__ float rnd(float v, int dt) {
     if (dt == LLMC_F16) return f16_bits_to_f32(f32_to_f16_bits(v));

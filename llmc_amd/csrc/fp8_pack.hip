@@ -34,7 +34,8 @@ __device__ __forceinline__ float e4m3fn_to_f32(uint8_t v) {
     if ((v & 0x7f) == 0x7f) r = __uint_as_float(0x7fc00000u);
     else if (e == 0) r = (float)m * 0.001953125f;
     else r = __uint_as_float(((e - 7 + 127) << 23) | (m << 20));
-    return (v & 0x80) ? -r : r;
+    // sign by bit: a negative zero must stay negative ((q - 0) * s = -0.0 in the reference)
+    return __uint_as_float(__float_as_uint(r) | ((uint32_t)(v & 0x80) << 24));
 }
 
 // amax[row] = clamp(absmax, 1e-5) in dt (from llmc_minmax_qparams with qmax = 1). scale = amax / 448 in the
@@ -44,7 +45,7 @@ template <typename T>
 __device__ __forceinline__ void fp8_one(float w, float s, int tdt, int fake, int DT, T* of, uint8_t* ob) {
     const float t = rnd(rnd(w / s, tdt) + 0.0f, tdt);          // tensor / scales + zeros
     const uint8_t q = f32_to_e4m3fn(t);
-    if (fake) *of = from_f32<T>(e4m3fn_to_f32(q) * s);          // fp32 product, one rounding to dt
+    if (fake) *of = from_f32<T>(opaque_f32(e4m3fn_to_f32(q) * s));   // fp32 product, one rounding to dt
     else *ob = q;
 }
 

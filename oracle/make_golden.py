@@ -633,6 +633,47 @@ def suite_fp8():
     save('fp8', **out)
 
 
+def suite_fp8_block():
+    """FloatQuantizer e4m3 `per_block` (128 x 128 tiles, DeepSeek-V3 layout) and the reference's non-Triton
+    weight_cast_to_fp8 / weight_cast_to_bf16 (quant.py:18-43). float_quantize is bound to torch's e4m3fn cast as in
+    suite_fp8 (qtorch is not vendored). The Triton kernels (kernel.py) cannot run here: act_quant and fp8_gemm are
+    checked against oracle/quant_ref.py's restatement only (parity unpinned for those two)."""
+    import llmc.compression.quantization.quant as qmod
+
+    def fq(x, e, m, rounding='nearest'):
+        assert (e, m) == (4, 3)
+        return x.to(torch.float8_e4m3fn).float()
+    qmod.float_quantize = fq
+    out = {}
+    gen = torch.Generator().manual_seed(77)
+    ci = 0
+    # N is kept a multiple of the block: the reference's restore_tensor (quant.py:647-651) scrambles a padded N
+    for dt, (M, N), bsz in (('bf16', (200, 384), 128), ('f16', (128, 256), 128), ('bf16', (100, 192), 64)):
+        q = qmod.FloatQuantizer('e4m3', True, 'per_block', block_size=bsz, use_qtorch=True)
+        w = (torch.randn(M, N, generator=gen) * 0.05).to(DT[dt])
+        w[:, 7] *= 25
+        w[3, 5] = 0.0
+        if bsz == 64:
+            w[:64, :64] = 0.0                       # an all-zero block: scale clamps to 1e-5 / 448
+        rw, rs, _ = q.real_quant_weight_dynamic(w.clone())
+        fk = q.fake_quant_weight_dynamic(w.clone())
+        w8, s8 = qmod.weight_cast_to_fp8(w.clone(), bsz)
+        back = qmod.weight_cast_to_bf16(w8, s8, bsz)
+        p = f'c{ci}_'
+        out[p + 'w'] = f32(w)
+        out[p + 'bits'] = rw.view(torch.uint8).numpy()
+        out[p + 'scales'] = f32(rs)
+        out[p + 'fake'] = f32(fk)
+        out[p + 'cast_bits'] = w8.view(torch.uint8).numpy()
+        out[p + 'cast_scales'] = f32(s8)
+        out[p + 'cast_back'] = f32(back)
+        out[p + 'dt'] = np.array(dt)
+        out[p + 'block'] = np.array(bsz)
+        ci += 1
+    out['n'] = np.array(ci)
+    save('fp8_block', **out)
+
+
 def suite_e2e():
     """The reference's OWN algorithm classes (RTN / GPTQ / Awq, constructed and driven exactly as llmc/__main__.py
     does: ctor -> run_block_loop() -> deploy()) on the toy model adapter of tests/toy_model.py, on CPU.
@@ -729,7 +770,7 @@ def suite_mse():
     save('mse', **out)
 
 SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq}
+          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

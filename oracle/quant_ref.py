@@ -254,3 +254,36 @@ def mse_range(x, sym, qmin, qmax, round_zp=True, maxshrink=0.8, grid=100, norm=2
         cur_min = np.where(better, xmin, cur_min)
         cur_max = np.where(better, xmax, cur_max)
     return cur_min, cur_max
+
+
+# ---- FP8 block-wise (kernel.py:7-55, 146-242): restated from the Triton source, which cannot run here (no CUDA /
+# Triton backend): PARITY UNPINNED for these two functions — they are checked against this restatement only.
+def act_quant_ref(x, block=128):
+    """kernel.py:7-55. x float array [..., K]; returns (e4m3 bytes as uint8, fp32 scales [..., K / block])."""
+    import torch
+    xf = np.asarray(x, dtype=np.float32)
+    shp = xf.shape
+    xb = xf.reshape(-1, block)
+    s = (np.abs(xb).max(axis=1) / np.float32(448.0)).astype(np.float32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        y = (xb / s[:, None]).astype(np.float32)
+    bits = torch.from_numpy(y).to(torch.float8_e4m3fn).view(torch.uint8).numpy().reshape(shp)
+    return bits, s.reshape(*shp[:-1], shp[-1] // block)
+
+
+def fp8_block_gemm_ref(a_bits, a_s, b_bits, b_s, block=128):
+    """kernel.py:146-242: sum over K blocks of (A_kb . B_kb^T) * a_s[m, kb] * b_s[n / block, kb] in fp32 (fp64
+    accumulation inside a block: the products are exact, only the summation order is the kernel's own)."""
+    import torch
+    A = torch.from_numpy(np.ascontiguousarray(a_bits)).view(torch.float8_e4m3fn).float().numpy()
+    B = torch.from_numpy(np.ascontiguousarray(b_bits)).view(torch.float8_e4m3fn).float().numpy()
+    M, K = A.shape
+    N = B.shape[0]
+    out = np.zeros((M, N), dtype=np.float32)
+    for kb in range((K + block - 1) // block):
+        sl = slice(kb * block, min(K, (kb + 1) * block))
+        part = (A[:, sl].astype(np.float64) @ B[:, sl].astype(np.float64).T).astype(np.float32)
+        t = (part * a_s[:, kb][:, None]).astype(np.float32)
+        t = (t * np.repeat(b_s[:, kb], block)[:N][None, :]).astype(np.float32)
+        out = (out + t).astype(np.float32)
+    return out
