@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
                     help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
                          'vllm: sym g128 static groups + INT4 pack (configs/quantization/backend/vllm/gptq_w4a16.yml)')
+    ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq'],
+                    help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
+                         'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch')
     ap.add_argument('--mode', default='independent', choices=['independent', 'cooperative'])
     ap.add_argument('--overlap', type=int, default=4,
                     help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); '
@@ -293,11 +296,86 @@ class DryOps:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# AWQ workload (BASELINE.json configs[2]): per block, the four subsets' 20-point scale searches (awq.py:179-253) with
+# inspect = the subset's Linear layers, N = 128 x 512 tokens in one batch, W4 symmetric g128, trans v2
+# ---------------------------------------------------------------------------------------------------------------
+def run_awq(args):
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback in llmc_amd)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    from llmc_amd.compression.quantization import IntegerQuantizer, awq_ops
+    from llmc_amd.compression.quantization.awq_pipeline import search_scale_stacked
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
+    n_seq, seq = 128, 512                                  # configs/quantization/methods/Awq/awq_w_only.yml:12-14
+    N = n_seq * seq
+    wq = IntegerQuantizer(4, True, 'per_group', group_size=128)
+    groups = block_groups(args.model)
+    acts = {name: synth_acts(n_seq, seq, K, rank * 64 + gi, dev, dtype).reshape(N, K) for gi, (name, K, _) in enumerate(groups)}
+    weights = {name: [synth_weight(R, K, rank * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
+               for gi, (name, K, layers) in enumerate(groups)}
+    gemm_ev = []
+
+    def step(record):
+        out = []
+        for name, K, layers in groups:
+            out.append(search_scale_stacked(weights[name], acts[name], wq, 'v2', timing=gemm_ev if record else None))
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    n_layers = sum(len(ls) for _, _, ls in groups)
+    fl_eval = sum(2.0 * N * sum(r for _, r in ls) * K for _, K, ls in groups)        # one evaluation of every subset
+    fl = sum(f for _, _, f in gemm_ev)
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_ev)
+    if rank == 0:
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        print(json.dumps({
+            'metric': 'layers/sec (AWQ W4A16 g128 scale search + fake-quant eval, %s Linear shapes, 128x512 calib)' % args.model,
+            'value': n_layers * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'AWQ W4A16 g128 sym, trans v2, 20-point scale search with inspect = the Linear layers, '
+                                   f'{args.model}-shaped random-init layers, 1 block (7 Linear, 4 subsets) per step per GPU',
+                       'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
+                         'frac': ach * 1e12 / PEAK_MFMA_16BIT, 'traffic': None,
+                         'kernel': 'k_linear_eval (llmc_linear_eval, the 21 products of a search)', 'launches': len(gemm_ev),
+                         'algorithmic_flops_per_launch': fl / max(1, len(gemm_ev)), 'avg_launch_ms': ms / max(1, len(gemm_ev)),
+                         'whole_search_tflops': 21 * fl_eval * args.steps / dt / 1e12},
+        }), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse_args()
     rc = maybe_spawn(args)
     if rc is not None:
         sys.exit(rc)
+    if args.workload == 'awq':
+        return run_awq(args)
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -15,7 +15,7 @@ from . import awq_ops
 
 
 @torch.no_grad()
-def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, return_losses=False):
+def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, return_losses=False, timing=None):
     """weights: list of [R_i, K] tensors (model dtype, untouched); x: [..., K] activations (model dtype).
     Returns best_scales [K] (model dtype) (and the device tensor of the 20 mean losses)."""
     _ffi.require_gpu(x, *weights)
@@ -32,7 +32,14 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
         w_max = m if w_max is None else w_max.add_(m)
     w_max = w_max.div_(len(weights))
     x_mean = awq_ops.act_mean(x2)                       # get_act_scale (awq.py:74-76)
+    def _ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+    e0 = _ev() if timing is not None else None
     org_out = awq_ops.linear_out(x2, wcat)              # get_original_out (awq.py:128-132)
+    if timing is not None:
+        timing.append((e0, _ev(), 2.0 * N * R * K))
     losses = torch.zeros(n_grid, dtype=torch.float32, device=x.device)
     scales_all = []
     for n in range(n_grid):
@@ -40,7 +47,10 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
         s = awq_ops.awq_scales(x_mean, w_max, ratio, trans_version)
         wq = awq_ops.scale_fakequant(wcat, s, wquantizer)
         xs = awq_ops.div_cols(x2, s)
+        e0 = _ev() if timing is not None else None
         awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1])
+        if timing is not None:
+            timing.append((e0, _ev(), 2.0 * N * R * K))
         scales_all.append(s)
     losses /= float(N * R)                               # .pow(2).mean() (awq.py:136)
     best = int(torch.argmin(losses).item())              # strict '<' keeps the first minimum (awq.py:245)

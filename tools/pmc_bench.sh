@@ -1,34 +1,43 @@
 #!/bin/bash
-# HBM traffic of the dominant kernel (k_syrk) inside bench.py: FETCH_SIZE and WRITE_SIZE in separate passes
-# (TCC has 4 slots; FETCH_SIZE takes 3, WRITE_SIZE 2 — /opt/skills/guides/MI355X_MICROARCH.md).
+# HBM-side traffic of the dominant kernel (k_syrk4) inside bench.py: FETCH_SIZE and WRITE_SIZE in separate passes
+# (TCC has 4 slots; FETCH_SIZE takes 3, WRITE_SIZE 2 — /opt/skills/guides/MI355X_MICROARCH.md), per input width.
+# Writes gpurun_out/<round>/pmc_traffic.json; copy it to profiles/rNN_pmc_traffic.json (bench.py reports it).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_bench
+OUT=${1:-gpurun_out/pmc_bench}
 mkdir -p $OUT
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- $CMD > $OUT/f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- $CMD > $OUT/w.log 2>&1
-python - <<'PY'
-import csv, glob, json
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/f -o f -- $CMD > $OUT/f.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum --output-format csv -d $OUT/w -o w -- $CMD > $OUT/w.log 2>&1
+python - "$OUT" <<'PY'
+import csv, glob, json, sys
 from collections import defaultdict
+out_dir = sys.argv[1]
 agg = defaultdict(lambda: defaultdict(list))
-for f in glob.glob('gpurun_out/pmc_bench/**/*_counter_collection.csv', recursive=True):
+for f in glob.glob(out_dir + '/**/*_counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
-        if 'k_syrk<' in k or 'k_syrk2<' in k:
-            agg['k_syrk'][r['Counter_Name']].append(float(r['Counter_Value']))
-out = {}
-for k, cs in agg.items():
-    fetch = cs.get('FETCH_SIZE', [])
-    write = cs.get('WRITE_SIZE', [])
-    out[k] = {
-        'launches': len(fetch),
-        'FETCH_SIZE_KB_avg': sum(fetch) / max(1, len(fetch)),
-        'WRITE_SIZE_KB_avg': sum(write) / max(1, len(write)),
-        # gfx950: FETCH_SIZE reports half of the bytes of a wide coalesced streaming read -> x2 (guide, HBM section)
-        'hbm_bytes_per_launch': (2.0 * sum(fetch) / max(1, len(fetch)) + sum(write) / max(1, len(write))) * 1024.0,
-        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 1; '
-                'FETCH_SIZE doubled per the gfx950 correction; average over the 8 k_syrk launches (6x K=4096, 2x K=14336)',
-    }
-json.dump(out, open('gpurun_out/pmc_bench/traffic.json', 'w'), indent=1)
-print(json.dumps(out, indent=1))
+        if 'k_syrk4<' in r['Kernel_Name']:
+            agg[int(r['Dispatch_Id'])][r['Counter_Name']].append(float(r['Counter_Value']))
+# dispatches of one pass in launch order: per step 3 x (K = 4096) then 1 x (K = 14336); keep the LAST step's four
+def per_launch(counter):
+    ids = sorted(i for i, c in agg.items() if counter in c)
+    vals = [sum(agg[i][counter]) for i in ids]
+    return vals[-4:]
+fetch, write = per_launch('FETCH_SIZE'), per_launch('WRITE_SIZE')
+hit, miss = per_launch('TCC_HIT_sum'), per_launch('TCC_MISS_sum')
+T = 128 * 2048
+def alg(K):
+    return 2.0 * T * K          # X read once (16-bit); partial tiles are accounted in WRITE_SIZE
+rows = []
+for i, K in enumerate([4096, 4096, 4096, 14336]):
+    if i < len(fetch) and i < len(write):
+        b = (2.0 * fetch[i] + write[i]) * 1024.0     # gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (guide, HBM section)
+        rows.append({'K': K, 'FETCH_SIZE_KB': fetch[i], 'WRITE_SIZE_KB': write[i], 'bytes': b, 'algorithmic_X_bytes': alg(K),
+                     'ratio_vs_X': b / alg(K), 'l2_hit': hit[i] / (hit[i] + miss[i]) if i < len(hit) and i < len(miss) else None})
+avg = sum(r['bytes'] for r in rows) / max(1, len(rows))
+res = {'k_syrk': {'launches': len(rows), 'per_launch': rows, 'hbm_bytes_per_launch': avg,
+                  'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 1; '
+                          'FETCH_SIZE doubled per the gfx950 correction; fabric-side requests (Infinity-Cache hits included); '
+                          'average over the four k_syrk4 launches of a step (3x K=4096, 1x K=14336), per-width values in per_launch'}}
+json.dump(res, open(out_dir + '/pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(res, indent=1))
 PY
