@@ -50,10 +50,23 @@ static inline float qdq_f32(float x, float s, float z, float qmin, float qmax) {
  * group_size 0 = per_channel (static qparams, one group); static_groups: scales/zeros are inputs
  * [R, ng] in original column order, col_group[i] selects the group of processed column i.
  * dynamic: scales/zeros [R, ng] outputs in processing order. zeros may be NULL when sym && static.
+ * n_quant < K is OWQ (gptq.py:44-56, 199-221): the loop visits the first n_quant columns only, groups are clipped
+ * at n_quant, the trailing columns still receive every block's error feedback.
  */
+int gptq_weight_transform_cols(float* W, const float* Hinv, int64_t R, int64_t K, int64_t n_quant, int sym, float qmin,
+                               float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
+                               float* scales, float* zeros, float* Wout, float* losses, int blocksize);
+
 int gptq_weight_transform(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin, float qmax,
                           int64_t group_size, int static_groups, const int32_t* col_group, float* scales,
                           float* zeros, float* Wout, float* losses, int blocksize) {
+    return gptq_weight_transform_cols(W, Hinv, R, K, K, sym, qmin, qmax, group_size, static_groups, col_group, scales,
+                                      zeros, Wout, losses, blocksize);
+}
+
+int gptq_weight_transform_cols(float* W, const float* Hinv, int64_t R, int64_t K, int64_t n_quant, int sym, float qmin,
+                               float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
+                               float* scales, float* zeros, float* Wout, float* losses, int blocksize) {
     const int per_channel = group_size <= 0;
     const int static_mode = static_groups || per_channel;
     const int64_t ng = per_channel ? 1 : (K + group_size - 1) / group_size;
@@ -64,8 +77,8 @@ int gptq_weight_transform(float* W, const float* Hinv, int64_t R, int64_t K, int
         float* err = (float*)malloc(sizeof(float) * blocksize);
         float* w1 = (float*)malloc(sizeof(float) * blocksize);
         float s = 1.0f, z = 0.0f;
-        for (int64_t i1 = 0; i1 < K; i1 += blocksize) {
-            const int64_t i2 = i1 + blocksize < K ? i1 + blocksize : K;
+        for (int64_t i1 = 0; i1 < n_quant; i1 += blocksize) {
+            const int64_t i2 = i1 + blocksize < n_quant ? i1 + blocksize : n_quant;
             const int count = (int)(i2 - i1);
             memcpy(w1, w + i1, sizeof(float) * count);      /* W1 = W[:, i1:i2].clone() */
             for (int i = 0; i < count; ++i) {
@@ -76,7 +89,7 @@ int gptq_weight_transform(float* W, const float* Hinv, int64_t R, int64_t K, int
                         /* search_column_qparams on W[:, col : min(col+g, K)]: NOTE the reference reads W,
                            not W1 (gptq.py:216); inside the current block W is stale w.r.t. the in-block
                            updates only when a group starts mid-block (group_size < blocksize). */
-                        int64_t e = col + group_size < K ? col + group_size : K;
+                        int64_t e = col + group_size < n_quant ? col + group_size : n_quant;
                         float mn = INFINITY, mx = -INFINITY;
                         for (int64_t c = col; c < e; ++c) {
                             float v = w[c];

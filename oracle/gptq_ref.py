@@ -95,10 +95,22 @@ def _clib():
     return _lib
 
 
+def owq_permutation(h_diag, n_out):
+    """hessian_sorting with OWQ (gptq.py:66-83, actorder forced off): non-outlier columns in original order, then
+    the n_out largest Hessian diagonals, largest first (stable ties like torch.argsort's default are not relied on)."""
+    desc = np.argsort(-np.asarray(h_diag, dtype=np.float32), kind='stable')
+    keep = np.ones(len(h_diag), dtype=bool)
+    keep[desc[:n_out]] = False
+    return np.concatenate([np.arange(len(h_diag))[keep], desc[:n_out]]).astype(np.int64)
+
+
 def weight_transform(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, col_group=None,
-                     scales=None, zeros=None, blocksize=128, want_losses=True):
+                     scales=None, zeros=None, blocksize=128, want_losses=True, n_quant=None, init_scales=None,
+                     init_zeros=None):
     """gptq.py:199-244. W [R,K] fp32 (copied), Hinv [K,K] fp32 upper.
-    Returns dict(tmp, W (running), losses, scales [R,ng], zeros [R,ng])."""
+    Returns dict(tmp, W (running), losses, scales [R,ng], zeros [R,ng]).
+    n_quant < K: OWQ (only the first n_quant columns are visited; dynamic qparams of never-visited groups keep
+    init_scales / init_zeros, the layer's RTN qparams the reference's `self.groups` starts from)."""
     import ctypes
     L = _clib()
     W = np.array(W, dtype=np.float32, copy=True, order='C')
@@ -111,8 +123,10 @@ def weight_transform(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, 
         scales = np.ascontiguousarray(np.asarray(scales, dtype=np.float32).reshape(R, ng))
         zeros = None if zeros is None else np.ascontiguousarray(np.asarray(zeros, dtype=np.float32).reshape(R, ng))
     else:
-        scales = np.zeros((R, ng), dtype=np.float32)
-        zeros = np.zeros((R, ng), dtype=np.float32)
+        scales = (np.array(init_scales, dtype=np.float32).reshape(R, ng).copy() if init_scales is not None
+                  else np.zeros((R, ng), dtype=np.float32))
+        zeros = (np.array(init_zeros, dtype=np.float32).reshape(R, ng).copy() if init_zeros is not None
+                 else np.zeros((R, ng), dtype=np.float32))
     cg = None if col_group is None else np.ascontiguousarray(col_group, dtype=np.int32)
     tmp = np.zeros_like(W)
     losses = np.zeros_like(W) if want_losses else None
@@ -120,10 +134,11 @@ def weight_transform(W, Hinv, sym, qmin, qmax, group_size, static_groups=False, 
     def p(a):
         return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
-    rc = L.gptq_weight_transform(p(W), p(Hinv), ctypes.c_int64(R), ctypes.c_int64(K), int(bool(sym)),
-                                 ctypes.c_float(qmin), ctypes.c_float(qmax), ctypes.c_int64(group_size or 0),
-                                 int(bool(static_groups)), p(cg), p(scales), p(zeros), p(tmp), p(losses),
-                                 int(blocksize))
+    rc = L.gptq_weight_transform_cols(p(W), p(Hinv), ctypes.c_int64(R), ctypes.c_int64(K),
+                                      ctypes.c_int64(K if n_quant is None else int(n_quant)), int(bool(sym)),
+                                      ctypes.c_float(qmin), ctypes.c_float(qmax), ctypes.c_int64(group_size or 0),
+                                      int(bool(static_groups)), p(cg), p(scales), p(zeros), p(tmp), p(losses),
+                                      int(blocksize))
     assert rc == 0
     return dict(tmp=tmp, W=W, losses=losses, scales=scales, zeros=zeros)
 

@@ -287,3 +287,48 @@ def fp8_block_gemm_ref(a_bits, a_s, b_bits, b_s, block=128):
         t = (t * np.repeat(b_s[:, kb], block)[:N][None, :]).astype(np.float32)
         out = (out + t).astype(np.float32)
     return out
+
+
+# ---- per_tensor asymmetric (quant.py:132-136, 555-556): 0-dim min/max of the tensor dtype against the 0-dim fp32
+# (qmax - qmin) promote scales / zeros to fp32; in the ops against the dimensioned tensor the 0-dim qparams keep their
+# fp32 VALUE but do not promote the result, which is rounded to the tensor dtype after every op.
+def per_tensor_asym_qparams(w, dt, qmin, qmax):
+    mn, mx = np.float32(w.min()), np.float32(w.max())
+    d = np.maximum(rnd(mx - mn, dt), rnd(np.float32(1e-5), dt))
+    s = np.float32(d) / np.float32(qmax - qmin)
+    z = np.float32(qmin) - np.rint(np.float32(mn) / s)
+    z = np.minimum(np.maximum(z, np.float32(qmin)), np.float32(qmax))
+    return np.float32(s), np.float32(z)
+
+
+def per_tensor_asym_fake_and_codes(w, dt, qmin, qmax):
+    s, z = per_tensor_asym_qparams(w, dt, qmin, qmax)
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        t = rnd(w / s, dt)
+        t = rnd(np.rint(t), dt)
+        t = rnd(t + z, dt)
+        codes = np.minimum(np.maximum(t, np.float32(qmin)), np.float32(qmax))
+        fake = rnd(rnd(codes - z, dt) * s, dt)
+    return fake.astype(np.float32), codes.astype(np.int32), s, z
+
+
+# ---- FP8 e4m3 per_block (quant.py:132-143, 612-658, 1043-1072): b x b tiles, fp32 scale = max(absmax, 1e-5) / 448,
+# q = e4m3(x / scale) in fp32 (the dimensioned fp32 scale promotes the 16-bit tensor), fake = q * scale rounded once.
+def fp8_per_block(w, dt, block):
+    w = np.asarray(w, dtype=np.float32)
+    M, N = w.shape
+    mb, nb = -(-M // block), -(-N // block)
+    bits = np.zeros((M, N), dtype=np.uint8)
+    fake = np.zeros((M, N), dtype=np.float32)
+    scales = np.zeros((mb, nb), dtype=np.float32)
+    for i in range(mb):
+        for j in range(nb):
+            sl = (slice(i * block, min(M, (i + 1) * block)), slice(j * block, min(N, (j + 1) * block)))
+            blk = w[sl]
+            s = np.float32(max(np.abs(blk).max(), np.float32(1e-5))) / np.float32(448.0)
+            scales[i, j] = s
+            y = (blk / s + np.float32(0.0)).astype(np.float32)
+            b = f32_to_e4m3fn_bits(y)
+            bits[sl] = b
+            fake[sl] = rnd((e4m3fn_bits_to_f32(b) * s).astype(np.float32), dt)
+    return bits, scales, fake

@@ -255,3 +255,57 @@ def test_auto_clip_matches_reference():
         assert (mn.reshape(ref_mn.shape) == ref_mn).mean() >= 0.97, name
         # clipped values are always one of the 10 candidate levels of the group's original max
         assert (ref_mx > 0).all()
+
+
+def test_per_tensor_asymmetric_bit_exact():
+    """quant_pt.npz: fp32 0-dim qparams, op results in the tensor dtype."""
+    g = load_golden('quant_pt')
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        bit, qmin, qmax = g[p + 'meta']
+        dt = str(g[p + 'dt'])
+        fake, codes, s, z = Q.per_tensor_asym_fake_and_codes(g[p + 'w'], dt, qmin, qmax)
+        np.testing.assert_array_equal(np.array([s]).view(np.uint32), g[p + 'scales'].view(np.uint32), err_msg=str(ci))
+        np.testing.assert_array_equal(np.array([z]), g[p + 'zeros'], err_msg=str(ci))
+        np.testing.assert_array_equal(fake.view(np.uint32), g[p + 'fake'].view(np.uint32), err_msg=str(ci))
+        np.testing.assert_array_equal(codes, g[p + 'codes'], err_msg=str(ci))
+
+
+def test_fp8_per_block_bit_exact():
+    g = load_golden('fp8_block')
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        bits, scales, fake = Q.fp8_per_block(g[p + 'w'], str(g[p + 'dt']), int(g[p + 'block']))
+        np.testing.assert_array_equal(scales.view(np.uint32), g[p + 'scales'].view(np.uint32), err_msg=str(ci))
+        np.testing.assert_array_equal(bits, g[p + 'bits'], err_msg=str(ci))
+        np.testing.assert_array_equal(fake.view(np.uint32), g[p + 'fake'].view(np.uint32), err_msg=str(ci))
+        np.testing.assert_array_equal(bits, g[p + 'cast_bits'])
+        back = Q.rnd((Q.e4m3fn_bits_to_f32(bits) * np.repeat(np.repeat(scales, int(g[p + 'block']), 0), int(g[p + 'block']), 1)
+                      [:bits.shape[0], :bits.shape[1]]).astype(np.float32), 'bf16')
+        np.testing.assert_array_equal(back.view(np.uint32), g[p + 'cast_back'].view(np.uint32), err_msg=str(ci))
+
+
+def test_gptq_owq_loop_bit_exact():
+    """gptq_owq.npz: OWQ permutation and the column loop restricted to the non-outlier columns, given the reference's Hinv."""
+    from oracle import gptq_ref as G
+    g = load_golden('gptq_owq')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        bit, sym, gs, R, K, n_out, qmin, qmax = g[p + 'meta']
+        sym, gs, R, K, n_out = bool(sym), int(gs), int(R), int(K), int(n_out)
+        np.testing.assert_array_equal(G.owq_permutation(g[p + 'Hdiag'], n_out), g[p + 'perm'], err_msg=name)
+        nn_ = K - n_out
+        if gs:
+            ng = K // gs
+            r = G.weight_transform(g[p + 'Wp'], g[p + 'U'], sym, qmin, qmax, gs, n_quant=nn_,
+                                   init_scales=g[p + 'rtn_scales'].reshape(R, ng),
+                                   init_zeros=g[p + 'rtn_zeros'].reshape(R, ng) if g[p + 'rtn_zeros'].size else None)
+        else:
+            s, z = Q.minmax_qparams(g[p + 'Wp'][:, :nn_], 'f32', sym, qmin, qmax)
+            r = G.weight_transform(g[p + 'Wp'], g[p + 'U'], sym, qmin, qmax, 0, scales=s, zeros=None if sym else z,
+                                   n_quant=nn_)
+        np.testing.assert_array_equal(r['tmp'].view(np.uint32), g[p + 'tmp'].view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(r['losses'].view(np.uint32), g[p + 'losses'].view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(r['W'][:, nn_:].view(np.uint32), g[p + 'W_after'][:, nn_:].view(np.uint32), err_msg=name)
+        if gs:
+            np.testing.assert_array_equal(r['scales'].reshape(-1).view(np.uint32), g[p + 'buf_scales'].view(np.uint32), err_msg=name)
