@@ -93,6 +93,13 @@ class GPTQ(BaseBlockwiseQuantization):
     @torch.no_grad()
     def add_batch(self, layer, name, inp, out):
         """gptq.py:254-295 (running-mean Hessian of the layer's input), fed once per distinct input tensor."""
+        active = getattr(self, '_active_layers', None)
+        if active is not None and name not in active:
+            # true_sequential: the first pass over the block hooks every layer, but the Hessians of the later subsets
+            # are re-initialised and re-accumulated after the earlier subsets have been quantized
+            # (base_blockwise_quantization.py:506-526, gptq.py:311-315) — accumulating them now is wasted work
+            # (for a Llama block: 3 of the 4 distinct Hessians, the widest one included)
+            return
         c = self.layers_cache[name]
         c['calls'] += 1
         call = c['calls']
@@ -144,6 +151,7 @@ class GPTQ(BaseBlockwiseQuantization):
     @torch.no_grad()
     def subset_init(self, subset):
         self.named_layers = subset['layers']
+        self._active_layers = set(subset['layers']) if getattr(self, 'true_sequential', False) else None
         by_k = {}
         for n, l in self.named_layers.items():
             by_k.setdefault(self._in_features(l), []).append(n)
@@ -153,6 +161,11 @@ class GPTQ(BaseBlockwiseQuantization):
     @torch.no_grad()
     def block_init(self, block):
         self.named_layers = self.model.get_block_linears(block)
+        self._active_layers = None
+        if getattr(self, 'true_sequential', False):
+            subsets = self.model.get_subsets_in_block(block)
+            if subsets:
+                self._active_layers = set(subsets[0]['layers'])
         for names in self._group_layers(self.named_layers, block):
             l0 = self.named_layers[names[0]]
             self._new_group(names, self._in_features(l0), l0.weight.device)

@@ -132,3 +132,46 @@ def test_gptq_hessian_sharing_needs_the_same_input_tensor(monkeypatch):
         h = torch.randn(1, 5, 8)
         g2.add_batch(qkv['q'], 'q', h, None)
         g2.add_batch(qkv['k'], 'k', h.clone(), None)
+
+
+def test_true_sequential_first_pass_feeds_only_the_first_subset(monkeypatch):
+    """under true_sequential the Hessians of subsets 2.. are re-accumulated after the earlier subsets are
+    quantized (base_blockwise_quantization.py:506-526); the first pass must not compute them."""
+    import llmc_amd.compression.quantization.gptq as gq
+
+    class FakeAcc:
+        def __init__(self, K, dev):
+            self.K, self.nsamples, self.fed = K, 0, []
+            self.H = torch.zeros(K, K)
+
+        def add(self, inp):
+            self.fed.append(inp)
+            self.nsamples += inp.shape[0]
+    monkeypatch.setattr(gq, 'HessianAccumulator', FakeAcc)
+    lin = lambda k: torch.nn.Linear(k, 4, bias=False)  # noqa: E731
+    layers = {'q': lin(8), 'k': lin(8), 'o': lin(8), 'down': lin(16)}
+    subsets = [{'layers': {'q': layers['q'], 'k': layers['k']}}, {'layers': {'o': layers['o']}}, {'layers': {'down': layers['down']}}]
+
+    class M:
+        def get_block_linears(self, b):
+            return layers
+
+        def get_subsets_in_block(self, b):
+            return subsets
+    for seq in (True, False):
+        g = gq.GPTQ.__new__(gq.GPTQ)
+        g.layers_cache, g._groups, g._group_of, g.model, g.true_sequential = {}, {}, {}, M(), seq
+        g.block_init(None)
+        h = torch.randn(1, 3, 8)
+        for n in ('q', 'k', 'o'):
+            g.add_batch(layers[n], n, h if n != 'o' else torch.randn(1, 3, 8), None)
+        g.add_batch(layers['down'], 'down', torch.randn(1, 3, 16), None)
+        fed = {n: len(g.layers_cache[n]['acc'].fed) for n in layers}
+        if seq:
+            assert fed == {'q': 1, 'k': 1, 'o': 0, 'down': 0}
+            g.subset_init(subsets[1])                       # rehook_next_subset
+            g.add_batch(layers['q'], 'q', h, None)          # a stray hook of an earlier subset is ignored
+            g.add_batch(layers['o'], 'o', torch.randn(1, 3, 8), None)
+            assert len(g.layers_cache['o']['acc'].fed) == 1
+        else:
+            assert fed == {'q': 1, 'k': 1, 'o': 1, 'down': 1}
