@@ -249,10 +249,23 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             samples = [act_tensors[0][i] for i in range(act_tensors[0].shape[0])]
         else:
             samples = list(act_tensors)
-        # static_minmax: mean over samples of per-sample min / max, then get_qparams on the means
-        mx = torch.stack([s.max().float() for s in samples]).mean()
-        mn = torch.stack([s.min().float() for s in samples]).mean()
         aq = self.aquantizer
+        algo = getattr(aq, 'calib_algo', 'static_minmax')
+        if algo == 'static_moving_minmax':
+            # quant.py:524-543: exponential moving average of the per-sample ranges (alpha = 0.01, the default of
+            # get_batch_tensors_qparams), in the sample dtype like the reference
+            alpha = 0.01
+            mn = mx = None
+            for smp in samples:
+                a, b = smp.min(), smp.max()
+                mn, mx = (a, b) if mn is None else (mn + alpha * (a - mn), mx + alpha * (b - mx))
+        elif algo in ('static_minmax', 'minmax'):
+            # quant.py:253-263: mean over samples of per-sample min / max (fp32), then get_qparams on the means
+            mx = torch.stack([s.max().float() for s in samples]).mean()
+            mn = torch.stack([s.min().float() for s in samples]).mean()
+        else:
+            raise NotImplementedError(f'static activation calibration {algo}: static_minmax and static_moving_minmax '
+                                      'are on the accelerated path (static_hist is not)')
         qmax, qmin = aq.qmax.to(mx.device), aq.qmin.to(mx.device)
         abs_max = torch.max(mx.abs(), mn.abs()).clamp(min=1e-5)
         if aq.sym:

@@ -29,7 +29,7 @@ class BaseQuantizer(object):
         self.kwargs = kwargs
 
         self.calib_algo = self.kwargs.get('calib_algo', 'minmax')
-        if self.calib_algo not in ('minmax', 'static_minmax', 'mse'):
+        if self.calib_algo not in ('minmax', 'static_minmax', 'static_moving_minmax', 'mse'):
             raise NotImplementedError(
                 f'calib_algo={self.calib_algo}: only minmax and mse ranges are on the accelerated path')
         # mse config (quant.py:78-81)
