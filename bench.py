@@ -361,7 +361,7 @@ def run_awq(args):
                        'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                          'frac': ach * 1e12 / PEAK_MFMA_16BIT, 'traffic': None,
-                         'kernel': 'k_linear_eval (llmc_linear_eval, the 21 products of a search)', 'launches': len(gemm_ev),
+                         'kernel': 'k_linear_eval4 (llmc_linear_eval_kt, the 21 products of a search; k_linear_eval when K % 128 != 0)', 'launches': len(gemm_ev),
                          'algorithmic_flops_per_launch': fl / max(1, len(gemm_ev)), 'avg_launch_ms': ms / max(1, len(gemm_ev)),
                          'whole_search_tflops': 21 * fl_eval * args.steps / dt / 1e12},
         }), flush=True)

@@ -220,6 +220,10 @@ int llmc_awq_scale_fakequant(const void* W, const void* s, int dt, int64_t R, in
 /* scaling_input (base_blockwise_quantization.py:877-889): out = X / s[None,:] in dt. */
 int llmc_div_cols(const void* X, const void* s, int dt, int64_t N, int64_t K, void* out,
                   llmc_stream_t stream);
+/* The same quotient written in the k-tiled layout llmc_linear_eval_kt reads (see below): out[K/32][N][32], f16/bf16,
+ * K % 32 == 0, out of place. Same bits as llmc_div_cols followed by llmc_ktile_pack. */
+int llmc_div_cols_kt(const void* X, const void* s, int dt, int64_t N, int64_t K, void* out,
+                     llmc_stream_t stream);
 /* apply_scale helpers (base_blockwise_quantization.py:597-611,750-778): W *= s[None,:] ; v /= s. */
 int llmc_mul_cols(void* W, const void* s, int dt, int64_t R, int64_t K, llmc_stream_t stream);
 
@@ -232,6 +236,14 @@ int llmc_mul_cols(void* W, const void* s, int dt, int64_t R, int64_t K, llmc_str
 size_t llmc_linear_eval_ws_bytes(int64_t N, int64_t K, int64_t R);
 int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N, int64_t K, int64_t R, int mode,
                      void* Yout, const void* Y0, float* loss_sum, void* ws, llmc_stream_t stream);
+/* The same product from K-TILED operands, layout T[K/32][rows][32] (the 32-k slice of every row contiguous): the
+ * layout the one-wave-per-SIMD GEMM streams at whole cache lines. llmc_ktile_pack converts a row-major [rows, K]
+ * 16-bit matrix; llmc_linear_eval_kt is llmc_linear_eval (same modes, outputs, Y0 and workspace, same bits) with
+ * both operands k-tiled; K % 128 == 0. Used by the AWQ grid step, where x / s and fakequant(W * s) are produced
+ * per evaluation anyway (awq.py:229-236). */
+int llmc_ktile_pack(const void* src, int dt, int64_t rows, int64_t K, void* dst, llmc_stream_t stream);
+int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64_t N, int64_t K, int64_t R, int mode,
+                        void* Yout, const void* Y0, float* loss_sum, void* ws, llmc_stream_t stream);
 
 /* AutoClipper.auto_clip_layer (auto_clip.py:84-191), clip_version v1, w_only:
  *   W [R, K] dt; X [n_tok, K] dt (already token-subsampled); groups of g along K.

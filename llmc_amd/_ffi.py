@@ -50,10 +50,13 @@ SIGNATURES = {
     'llmc_awq_scales': (_i32, [_vp, _vp, _i32, _i64, _f64, _i32, _vp, _vp]),
     'llmc_awq_scale_fakequant': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _f32, _f32, _vp, _vp]),
     'llmc_div_cols': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    'llmc_div_cols_kt': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     'llmc_mul_cols': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp]),
     'llmc_clamp_groups': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     'llmc_linear_eval_ws_bytes': (_sz, [_i64, _i64, _i64]),
     'llmc_linear_eval': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'llmc_ktile_pack': (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+    'llmc_linear_eval_kt': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'llmc_awq_clip_search_ws_bytes': (_sz, [_i64, _i64, _i64, _i64]),
     'llmc_awq_clip_search': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _f32,
                                     _vp, _vp, _vp, _vp]),

@@ -55,15 +55,17 @@ def scale_fakequant(w, scales, wquantizer):
     return out
 
 
-def div_cols(x, scales):
-    """scaling_input (base_blockwise_quantization.py:877-889): x / scales.view(1, -1)."""
+def div_cols(x, scales, tiled=False):
+    """scaling_input (base_blockwise_quantization.py:877-889): x / scales.view(1, -1).
+    tiled: the quotient is written as a ktile_pack image (2-D, for linear_loss_sum(..., tiled=True))."""
     _ffi.require_gpu(x, scales)
     L = _ffi.lib()
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     out = torch.empty_like(x2)
-    _ffi.check(L.llmc_div_cols(_ffi.ptr(x2), _ffi.ptr(scales.contiguous()), _ffi.dt(x2), x2.shape[0], x2.shape[1],
-                               _ffi.ptr(out), _ffi.stream()), 'llmc_div_cols')
-    return out.reshape(x.shape)
+    fn, name = (L.llmc_div_cols_kt, 'llmc_div_cols_kt') if tiled else (L.llmc_div_cols, 'llmc_div_cols')
+    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(scales.contiguous()), _ffi.dt(x2), x2.shape[0], x2.shape[1], _ffi.ptr(out),
+                  _ffi.stream()), name)
+    return out if tiled else out.reshape(x.shape)
 
 
 def mul_cols_(w, scales):
@@ -98,8 +100,9 @@ def linear_supported(x, w):
     return max(N * K, R * K, N * R) * 2 < (1 << 32)
 
 
-def linear_out(x, wq, bias=None):
-    """F.linear(x, wq, bias) on the HIP GEMM: [N, K] x [R, K]^T (+ b) -> [N, R], rounded once to the model dtype."""
+def linear_out(x, wq, bias=None, tiled=False):
+    """F.linear(x, wq, bias) on the HIP GEMM: [N, K] x [R, K]^T (+ b) -> [N, R], rounded once to the model dtype.
+    tiled: x and wq are ktile_pack images (x 2-D)."""
     _ffi.require_gpu(x, wq, bias)
     L = _ffi.lib()
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
@@ -109,14 +112,31 @@ def linear_out(x, wq, bias=None):
     y = torch.empty((N, R), dtype=x.dtype, device=x.device)
     if bias is not None:
         bias = bias.to(x.dtype).contiguous()
-    _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 0, _ffi.ptr(y), _ffi.ptr(bias), 0, 0,
-                                  _ffi.stream()), 'llmc_linear_eval')
+    fn, name = (L.llmc_linear_eval_kt, 'llmc_linear_eval_kt') if tiled else (L.llmc_linear_eval, 'llmc_linear_eval')
+    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 0, _ffi.ptr(y), _ffi.ptr(bias), 0, 0, _ffi.stream()),
+               name)
     return y.reshape(*x.shape[:-1], R)
 
 
-def linear_loss_sum(x, wq, y0, loss_acc=None):
+def ktile_supported(x, w):
+    """linear_supported and K % 128 == 0: the k-tiled GEMM (llmc_linear_eval_kt) takes the pair."""
+    return linear_supported(x, w) and w.shape[1] % 128 == 0
+
+
+def ktile_pack(m):
+    """Row-major [rows, K] 16-bit matrix -> the k-tiled layout T[K/32][rows][32] llmc_linear_eval_kt streams (same bytes,
+    a new buffer of the same shape: only linear_loss_sum(..., tiled=True) / linear_out(..., tiled=True) may read it)."""
+    _ffi.require_gpu(m)
+    m = m.reshape(-1, m.shape[-1]).contiguous()
+    out = torch.empty_like(m)
+    _ffi.check(_ffi.lib().llmc_ktile_pack(_ffi.ptr(m), _ffi.dt(m), m.shape[0], m.shape[1], _ffi.ptr(out), _ffi.stream()),
+               'llmc_ktile_pack')
+    return out
+
+
+def linear_loss_sum(x, wq, y0, loss_acc=None, tiled=False):
     """sum((y0 - F.linear(x, wq))^2) with the difference formed in the model dtype; returns / accumulates into
-    a 1-element fp32 device tensor (no host sync)."""
+    a 1-element fp32 device tensor (no host sync). tiled: x and wq are ktile_pack images."""
     _ffi.require_gpu(x, wq, y0)
     L = _ffi.lib()
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
@@ -127,8 +147,9 @@ def linear_loss_sum(x, wq, y0, loss_acc=None):
     if loss_acc is None:
         loss_acc = torch.zeros(1, dtype=torch.float32, device=x.device)
     ws = _ffi.workspace(L.llmc_linear_eval_ws_bytes(N, K, R), x.device)
-    _ffi.check(L.llmc_linear_eval(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 1, 0, _ffi.ptr(y0),
-                                  _ffi.ptr(loss_acc), _ffi.ptr(ws), _ffi.stream()), 'llmc_linear_eval')
+    fn, name = (L.llmc_linear_eval_kt, 'llmc_linear_eval_kt') if tiled else (L.llmc_linear_eval, 'llmc_linear_eval')
+    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 1, 0, _ffi.ptr(y0), _ffi.ptr(loss_acc), _ffi.ptr(ws),
+                  _ffi.stream()), name)
     return loss_acc
 
 

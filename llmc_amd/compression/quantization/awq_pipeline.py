@@ -7,6 +7,8 @@ host and restored (the reference reloads the module's state dict from a CPU copy
 activation mean is computed once instead of once per grid step, and the 20 losses stay on the device until
 the final argmin (one sync instead of 20 `.item()` calls).
 """
+import os
+
 import torch
 
 from llmc_amd import _ffi
@@ -36,8 +38,12 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
+    # K % 128 == 0: the 21 products run on the k-tiled GEMM (llmc_linear_eval_kt), operands re-laid by llmc_ktile_pack
+    kt = awq_ops.ktile_supported(x2, wcat) and os.environ.get('LLMC_AWQ_KT', '1') != '0'   # 0: diagnostic, row-major GEMM
+    xa, wa = (awq_ops.ktile_pack(x2), awq_ops.ktile_pack(wcat)) if kt else (x2, wcat)
     e0 = _ev() if timing is not None else None
-    org_out = awq_ops.linear_out(x2, wcat)              # get_original_out (awq.py:128-132)
+    org_out = awq_ops.linear_out(xa, wa, tiled=kt)     # get_original_out (awq.py:128-132)
+    del xa, wa
     if timing is not None:
         timing.append((e0, _ev(), 2.0 * N * R * K))
     losses = torch.zeros(n_grid, dtype=torch.float32, device=x.device)
@@ -46,9 +52,11 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
         ratio = n * 1 / n_grid
         s = awq_ops.awq_scales(x_mean, w_max, ratio, trans_version)
         wq = awq_ops.scale_fakequant(wcat, s, wquantizer)
-        xs = awq_ops.div_cols(x2, s)
+        xs = awq_ops.div_cols(x2, s, tiled=kt)
+        if kt:
+            wq = awq_ops.ktile_pack(wq)
         e0 = _ev() if timing is not None else None
-        awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1])
+        awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1], tiled=kt)
         if timing is not None:
             timing.append((e0, _ev(), 2.0 * N * R * K))
         scales_all.append(s)

@@ -147,6 +147,32 @@ __global__ __launch_bounds__(AB) void k_cols_op(const T* __restrict__ X, const T
         *reinterpret_cast<uint4*>(out + r * K + c) = ro;
     }
 }
+// x / s[col] written K-TILED (T[K/32][rows][32], linear_eval.hip): block = 64 rows x two 32-k slices, thread = one 16-B
+// chunk of each; whole 128-B lines in, KiB runs out. 16-bit T only.
+template <typename T>
+__global__ __launch_bounds__(256) void k_div_cols_kt(const T* __restrict__ X, const T* __restrict__ s, int64_t N,
+                                                     int64_t K, T* __restrict__ out) {
+    constexpr int DT = dt_of<T>::value;
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    const int64_t row = (int64_t)blockIdx.x * 64 + r;
+    if (row >= N) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t kt = (int64_t)blockIdx.y * 2 + j;
+        if (kt * 32 >= K) break;
+        const int64_t col = kt * 32 + c * 8;
+        uint4 rx = *reinterpret_cast<const uint4*>(X + row * K + col);
+        uint4 rs = *reinterpret_cast<const uint4*>(s + col);
+        T xv[8], sv[8], ov[8];
+        __builtin_memcpy(xv, &rx, 16);
+        __builtin_memcpy(sv, &rs, 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ov[k] = from_f32<T>(rndc<DT>(to_f32<T>(xv[k]) / to_f32<T>(sv[k])));
+        uint4 ro;
+        __builtin_memcpy(&ro, ov, 16);
+        *reinterpret_cast<uint4*>(out + (kt * N + row) * 32 + c * 8) = ro;
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(AB) void k_clamp_groups(T* __restrict__ W, int64_t R, int64_t K, int64_t g,
                                                      const T* __restrict__ mn, const T* __restrict__ mx) {
@@ -250,6 +276,20 @@ extern "C" int llmc_div_cols(const void* X, const void* s, int dt, int64_t N, in
     const int V = 16 / dtype_size(dt);
     DISPATCH_DT(dt, hipLaunchKernelGGL((k_cols_op<T, 0>), dim3(grid1d(N * (K / V))), dim3(AB), 0, st, (const T*)X,
                                        (const T*)s, N, K, (T*)out));
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+extern "C" int llmc_div_cols_kt(const void* X, const void* s, int dt, int64_t N, int64_t K, void* out,
+                                llmc_stream_t stream) {
+    LLMC_REQUIRE((dt == LLMC_F16 || dt == LLMC_BF16) && X && s && out && X != out && N > 0 && K > 0,
+                 "div_cols_kt: bad argument (16-bit dtypes, out of place)");
+    LLMC_REQUIRE(K % 32 == 0 && K / 64 < 65535 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+                     ((uintptr_t)s & 15) == 0, "div_cols_kt: needs K % 32 == 0 and 16-B aligned buffers");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)ceil_div64(K, 64));
+    if (dt == LLMC_F16) hipLaunchKernelGGL((k_div_cols_kt<f16_t>), grid, dim3(256), 0, st, (const f16_t*)X, (const f16_t*)s, N, K, (f16_t*)out);
+    else hipLaunchKernelGGL((k_div_cols_kt<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)s, N, K, (bf16_t*)out);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }

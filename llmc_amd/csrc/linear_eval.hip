@@ -8,6 +8,8 @@
 // and on the read, which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
 // Tile 256 x 256, K-step 64, 8 waves (2 x 4), persistent grid with XCD-contiguous tile ranges: the 32
 // workgroups of an XCD walk 2 token panels x 16 weight panels at the same K position (L2-resident).
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "mfma_common.h"
 
@@ -29,7 +31,39 @@ struct LinArgs {
     const char* Y0;   // [N, R] dt (mode 1); optional bias [R] dt (mode 0)
     float* part;      // [ntiles] partial loss sums (mode 1)
     int ntm, ntn;
+    // tile order: each XCD (blockIdx & 7) works on one sbm x sbn block of tiles per round (sbm * sbn = gridDim / 8), so
+    // the CUs that share an L2 share sbm + sbn operand panels instead of ~gridDim/8 + 1; blocks are numbered tn-fastest
+    int sbm, sbn, nsn, nrounds;
+    int y0_lds;       // k_linear_eval4, mode 1: Y0 tiles are staged through LDS (R % 8 == 0, Y0 16-B aligned, < 4 GiB)
 };
+
+// (round, block) -> tile; false = padding of a ragged block
+__device__ __forceinline__ bool lin_tile(const LinArgs& a, int round, int& tm, int& tn) {
+    const int slot = blockIdx.x >> 3;
+    const int si = slot / a.sbn, sj = slot - si * a.sbn;
+    const int sid = round * 8 + (blockIdx.x & 7);
+    const int sm = sid / a.nsn, sn = sid - sm * a.nsn;
+    tm = sm * a.sbm + si;
+    tn = sn * a.sbn + sj;
+    return tm < a.ntm && tn < a.ntn;
+}
+
+static void lin_tile_order(LinArgs& a, int grid) {
+    const int spx = grid / 8;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int sbn = 1; sbn <= 8; sbn *= 2) {
+        if (spx % sbn) continue;
+        const int sbm = spx / sbn;
+        const int64_t padded = ceil_div64(a.ntm, sbm) * sbm * ceil_div64(a.ntn, sbn) * sbn;
+        const int64_t cost = padded * 64 + (sbm + sbn);   // fewest padded tiles, then fewest panels per XCD
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sbn; }
+    }
+    a.sbn = best;
+    a.sbm = spx / best;
+    a.nsn = (int)ceil_div64(a.ntn, a.sbn);
+    a.nrounds = (int)ceil_div64(ceil_div64(a.ntm, a.sbm) * a.nsn, 8);
+}
 
 template <int DT>
 __global__ __launch_bounds__(LTHREADS) void k_linear_eval(LinArgs a) {
@@ -71,13 +105,12 @@ __global__ __launch_bounds__(LTHREADS) void k_linear_eval(LinArgs a) {
         rw[3] = 0x00020000;
     }
 
-    const int G = gridDim.x;
-    const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int ntiles = a.ntm * a.ntn;
     const int nk = (int)(a.K / LBK);
 
-    for (int t = lw; t < ntiles; t += G) {
-        const int tm = t / a.ntn, tn = t - tm * a.ntn;
+    for (int round = 0; round < a.nrounds; ++round) {
+        int tm, tn;
+        if (!lin_tile(a, round, tm, tn)) continue;
+        const int t = tm * a.ntn + tn;
         const uint32_t baseX = (uint32_t)((int64_t)tm * LT * row_bytes) + voff0;
         const uint32_t baseW = (uint32_t)((int64_t)tn * LT * row_bytes) + voff0;
 
@@ -163,6 +196,279 @@ __global__ __launch_bounds__(LTHREADS) void k_linear_eval(LinArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// k_linear_eval4 — the same product from K-TILED operands, with hessian_syrk.hip's one-wave-per-SIMD structure (k_syrk4).
+// Operand layout ("kt"): T[K/32][rows][32] — the 32-k slice of every row contiguous, so the 256 x 32 panel of one stage
+// is ONE contiguous 16-KiB run and every LDS-DMA piece reads eight whole 128-B lines. (Read row-major, a 32-k stage
+// touches half a line per row and the other half one stage = 32 KiB of traffic later, after the 32-KiB vector L1 has
+// turned over: twice the L2->L1 traffic, measured 0.34 of peak against the 8-wave kernel's 0.38.) llmc_ktile_pack
+// (below) makes the layout; inside the AWQ search the producers write it directly.
+// 4 waves as 2 x 2, each 128 x 128 = 4 x 4 accumulators (256 registers in the AGPR half), 8 fragment reads per 16
+// MFMAs, LDS ring of 4 stages of 32 k, three stages of LDS-DMA in flight with a counted vmcnt, fragments
+// double-buffered in registers, one s_barrier per stage between its two MFMA bursts, ring slots compile-time (stage
+// loop unrolled by 4, so K % 128 == 0), behind every MFMA at most one fragment read (ONE ds_read_b128: both operands
+// are k-contiguous) or one LDS-DMA piece. LDS image of a panel: [256 rows][64 B]; the 16-B chunk index is XOR-ed with
+// ((row >> 2) & 3) on the DMA source address and on the read: the four rows of a ds_read_b128 lane group that share a
+// bank column sit in four chunks. The k order of the sum is k_linear_eval's (ascending, 16 per MFMA): same bits.
+// -----------------------------------------------------------------------------------------------------------------
+static constexpr int L4_THREADS = 256;
+static constexpr int L4_KS = 32;                       // k per stage
+static constexpr int L4_PANEL = LT * L4_KS * 2;        // 16 KiB
+static constexpr int L4_STAGE = 2 * L4_PANEL;
+static constexpr int L4_RING = 4;
+static constexpr int L4_LDS = L4_RING * L4_STAGE;      // 128 KiB
+
+template <int I, int N, typename F> __device__ __forceinline__ void l4_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        l4_static_for<I + 1, N>(f);
+    }
+}
+
+template <int DST>
+__device__ __forceinline__ void l4_dma(i32x4 rsrc, uint32_t voff, uint32_t& soff, uint32_t wvoff, uint32_t adv) {
+    asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\ts_add_u32 %0, %0, %5"
+                 : "+s"(soff) : "v"(voff), "s"(rsrc), "s"(wvoff), "n"(DST), "s"(adv) : "memory", "scc");
+}
+template <int N> __device__ __forceinline__ void l4_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int DT>
+__global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)(smem + L4_LDS);
+    LDS_AS char* lds = (LDS_AS char*)smem;
+    if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // DMA destinations are immediates
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int64_t row_bytes = a.K * 2;
+    constexpr int PER = 8;
+
+    // DMA piece q (0..3) of wave wv = KiB-block (q*4 + wv) of a panel = rows 16*blk .. 16*blk + 15, 4 lanes per row
+    const int drow = lane >> 2;
+    const int dlog = (lane & 3) ^ ((lane >> 4) & 3);                    // logical chunk held by this physical slot
+    const uint32_t vlane = (uint32_t)((wv * 16 + drow) * 64 + dlog * 16);
+    const uint32_t slab = 64u * 64u;                                    // 64 rows per piece index q
+    const uint32_t advA = (uint32_t)(a.N * 64), advB = (uint32_t)(a.R * 64);   // one 32-k slice of every row
+    const uint32_t wvoff = (uint32_t)wv * 1024u;
+
+    // fragment addresses: slot j at j * 32 KiB; one base per pair of slots (+ immediate 0 / 32 KiB)
+    int offA[2][2][4], offB[2][2][4];                                  // [slot pair][kk][frag]
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int ra = wm * 128 + m * 32 + (lane & 31), rb = wn * 128 + m * 32 + (lane & 31);
+                const int cl = 2 * kk + (lane >> 5);
+                offA[pr][kk][m] = pr * 2 * L4_STAGE + ra * 64 + ((cl ^ ((ra >> 2) & 3)) << 4);
+                offB[pr][kk][m] = pr * 2 * L4_STAGE + L4_PANEL + rb * 64 + ((cl ^ ((rb >> 2) & 3)) << 4);
+            }
+
+    i32x4 rx, rw;
+    {
+        const int64_t xb = a.N * row_bytes, wb = a.R * row_bytes;
+        rx[0] = (int)(uint32_t)(uintptr_t)a.X;
+        rx[1] = (int)((uint32_t)((uintptr_t)a.X >> 32) & 0xffffu);
+        rx[2] = (int)(uint32_t)(xb > 0xffffffffll ? 0xffffffffll : xb);
+        rx[3] = 0x00020000;
+        rw[0] = (int)(uint32_t)(uintptr_t)a.W;
+        rw[1] = (int)((uint32_t)((uintptr_t)a.W >> 32) & 0xffffu);
+        rw[2] = (int)(uint32_t)(wb > 0xffffffffll ? 0xffffffffll : wb);
+        rw[3] = 0x00020000;
+    }
+    i32x4 ry = rx;
+    if (a.mode == 1) {
+        const int64_t yb = a.N * a.R * 2;
+        ry[0] = (int)(uint32_t)(uintptr_t)a.Y0;
+        ry[1] = (int)((uint32_t)((uintptr_t)a.Y0 >> 32) & 0xffffu);
+        ry[2] = (int)(uint32_t)(yb > 0xffffffffll ? 0xffffffffll : yb);
+    }
+    const int ngroups = (int)(a.K / (L4_KS * L4_RING));
+
+    for (int round = 0; round < a.nrounds; ++round) {
+        int tm, tn;
+        if (!lin_tile(a, round, tm, tn)) continue;
+        const int t = tm * a.ntn + tn;
+        const uint32_t vA = (uint32_t)(tm * LT * 64) + vlane;
+        const uint32_t vB = (uint32_t)(tn * LT * 64) + vlane;
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        uint32_t sA[4], sB[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sA[q] = sB[q] = (uint32_t)q * slab;
+        auto piece = [&](auto slc, auto dc) {
+            constexpr int SL = decltype(slc)::value;
+            constexpr int d = decltype(dc)::value;
+            constexpr int DSTB = SL * L4_STAGE + (d >> 2) * L4_PANEL + (d & 3) * 4 * 1024;
+            if constexpr (d < 4) l4_dma<DSTB>(rx, vA, sA[d & 3], wvoff, advA);
+            else l4_dma<DSTB>(rw, vB, sB[d & 3], wvoff, advB);
+        };
+        s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+        auto frag = [&](auto slc, auto kkc, auto fc, s16x8 (&fa)[4], s16x8 (&fb)[4]) {
+            constexpr int SL = decltype(slc)::value;
+            constexpr int KK = decltype(kkc)::value;
+            constexpr int f = decltype(fc)::value;
+            constexpr int IMM = (SL & 1) * L4_STAGE;
+            if constexpr (f == 0) fa[0] = *(LDS_AS s16x8*)(lds + offA[SL >> 1][KK][0] + IMM);
+            else if constexpr (f <= 4) fb[f - 1] = *(LDS_AS s16x8*)(lds + offB[SL >> 1][KK][f - 1] + IMM);
+            else fa[f - 4] = *(LDS_AS s16x8*)(lds + offA[SL >> 1][KK][f - 4] + IMM);
+        };
+        auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, auto kkc,
+                         auto dslc, auto d0c, auto dmac) {
+            constexpr int D0 = decltype(d0c)::value;
+            constexpr bool DMA = decltype(dmac)::value;
+            l4_static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int mi = i >> 2, ni = (mi & 1) ? 3 - (i & 3) : (i & 3);
+                acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
+                if constexpr ((i & 3) == 3) {
+                    if constexpr (DMA) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{});
+                } else if constexpr (i < 10) frag(rslc, kkc, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        constexpr std::integral_constant<int, 0> K0{};
+        constexpr std::integral_constant<int, 1> K1{};
+        l4_static_for<0, L4_RING - 1>([&](auto slc) { l4_static_for<0, 8>([&](auto dc) { piece(slc, dc); }); });
+        l4_static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, L4_RING - 1>{}, dc); });
+        l4_vmwait<(L4_RING - 2) * PER + PER / 2>();
+        __builtin_amdgcn_s_barrier();
+        l4_static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, K0, fc, fa0, fb0); });
+        // one ring turn = 4 stages. The LAST turn of a tile requests only what the tile still needs (the B half of its
+        // final stage) and counts the VM counter down to 0, so the ring is quiet and free when the turn ends.
+        auto turn = [&](auto lastc) {
+            constexpr bool LAST = decltype(lastc)::value;
+            l4_static_for<0, L4_RING>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                constexpr int JN = (J + 1) % L4_RING, JP = (J + L4_RING - 1) % L4_RING;
+                constexpr int AHEAD = LAST ? (J < 2 ? 2 - J : 0) : L4_RING - 2;    // stages that may still be in flight
+                burst(fa0, fb0, fa1, fb1, jc, K1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{},
+                      std::integral_constant<bool, !LAST || J == 0>{});
+                l4_vmwait<AHEAD * PER>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, K0, jc, std::integral_constant<int, 0>{},
+                      std::integral_constant<bool, !LAST>{});
+            });
+        };
+        for (int g = 0; g < ngroups - 1; ++g) turn(std::false_type{});
+        turn(std::true_type{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        if (a.mode == 1 && a.y0_lds) {
+            // loss epilogue: the Y0 tile (256 x 512 B) comes through the now idle ring by LDS-DMA, 32 KiB-pieces per wave
+            // all in flight at once (two 512-B row segments per piece), then every lane picks its 256 values with
+            // immediate-offset ds_read_u16. (Read straight from global, each of the 256 two-byte loads sat behind its
+            // own s_waitcnt: ~40 % of the tile time.)
+            uint32_t sy = 0;
+            const uint32_t vy = (uint32_t)((((int64_t)tm * LT + 2 * wv + (lane >> 5)) * a.R + (int64_t)tn * LT + (lane & 31) * 8) * 2);
+            const uint32_t advY = (uint32_t)(16 * a.R);        // 8 rows down
+            l4_static_for<0, 32>([&](auto ic) { l4_dma<decltype(ic)::value * 4096>(ry, vy, sy, wvoff, advY); });
+            l4_vmwait<0>();
+            __builtin_amdgcn_s_barrier();
+            const int ybase = (wm * 128 + 4 * (lane >> 5)) * 512 + (wn * 128 + (lane & 31)) * 2;
+            const int64_t col0 = (int64_t)tn * LT + wn * 128 + (lane & 31);
+            const int64_t tokb = (int64_t)tm * LT + wm * 128 + 4 * (lane >> 5);
+            // rows / columns of this lane's 128 x 128 block that exist (edge tiles); interior tiles take the unmasked copy
+            const int nrow = (int)(a.N - tokb < 128 ? a.N - tokb : 128);      // valid: trow < nrow (may be <= 0)
+            const int ncol = (int)(a.R - col0 <= 0 ? 0 : (a.R - col0 + 31) / 32);   // valid: n < ncol
+            const bool full = (int64_t)(tm + 1) * LT <= a.N && (int64_t)(tn + 1) * LT <= a.R;   // block-uniform
+            float lsum = 0.0f;
+            auto fold = [&](auto maskedc) {
+                constexpr bool MASKED = decltype(maskedc)::value;
+                l4_static_for<0, 16>([&](auto mnc) {
+                    constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
+                    uint16_t yb[16];
+                    l4_static_for<0, 16>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        constexpr int trow = m * 32 + (r & 3) + 8 * (r >> 2);
+                        yb[r] = *(LDS_AS const uint16_t*)(lds + ybase + trow * 512 + n * 64);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);   // 16 reads in flight, one wait (the scheduler pairs each read with its use)
+                    l4_static_for<0, 16>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        constexpr int trow = m * 32 + (r & 3) + 8 * (r >> 2);
+                        const float y0 = DT == LLMC_BF16 ? bf16_bits_to_f32(yb[r]) : f16_bits_to_f32(yb[r]);
+                        const float y = rndc<DT>(acc[m][n][r]);
+                        const float d = rndc<DT>(y0 - y);
+                        float d2 = d * d;
+                        if constexpr (MASKED) {
+                            // bit mask, not a select: the compiler turns `cond ? d2 : 0` into 256 exec-masked branches
+                            const uint32_t keep = (uint32_t)-(int)((trow < nrow) & (n < ncol));
+                            d2 = __uint_as_float(__float_as_uint(d2) & keep);
+                        }
+                        lsum += d2;
+                    });
+                });
+            };
+            if (full) fold(std::false_type{});
+            else fold(std::true_type{});
+            lsum = wave_sum(lsum, 64);
+            if (lane == 0) red[wv] = lsum;
+            __syncthreads();           // also: every wave is done with the staged tile before the next prologue
+            if (tid == 0) a.part[t] = (red[0] + red[1]) + (red[2] + red[3]);
+            __syncthreads();
+            continue;
+        }
+
+        float lsum = 0.0f;
+        l4_static_for<0, 16>([&](auto mnc) {
+            constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
+            const int64_t col = (int64_t)tn * LT + wn * 128 + n * 32 + (lane & 31);
+            const int64_t tok0 = (int64_t)tm * LT + wm * 128 + m * 32 + 4 * (lane >> 5);
+            l4_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int64_t tok = tok0 + (r & 3) + 8 * (r >> 2);
+                if (tok < a.N && col < a.R) {
+                    if (a.mode == 0) {
+                        const float b = a.Y0 ? load_as_f32(a.Y0, col, DT) : 0.0f;
+                        store_from_f32(a.Y, tok * a.R + col, DT, rndc<DT>(acc[m][n][r] + b));
+                    } else {
+                        const float y = rndc<DT>(acc[m][n][r]);
+                        const float y0 = load_as_f32(a.Y0, tok * a.R + col, DT);
+                        const float d = rndc<DT>(y0 - y);
+                        lsum += d * d;
+                    }
+                }
+            });
+        });
+        if (a.mode == 1) {
+            lsum = wave_sum(lsum, 64);
+            if (lane == 0) red[wv] = lsum;
+            __syncthreads();
+            if (tid == 0) a.part[t] = (red[0] + red[1]) + (red[2] + red[3]);
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores + trailing requests drain before the VM counter is counted again
+    }
+}
+
+// row-major [rows][K] (16-bit) -> k-tiled [K/32][rows][32]. One block: 64 rows x two 32-k slices (whole 128-B lines in,
+// 16 rows x 64 B = whole KiB runs out), thread = one 16-B chunk of each slice.
+__global__ __launch_bounds__(256) void k_ktile_pack(const char* __restrict__ src, int64_t rows, int64_t K,
+                                                    char* __restrict__ dst) {
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    const int64_t row = (int64_t)blockIdx.x * 64 + r;
+    if (row >= rows) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t kt = (int64_t)blockIdx.y * 2 + j;
+        if (kt * 32 >= K) break;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + row * K * 2 + kt * 64 + c * 16);
+        *reinterpret_cast<uint4*>(dst + (kt * rows + row) * 64 + c * 16) = v;
+    }
+}
+
 // sum of the per-tile partials in index order (one workgroup; fixed tree) -> *loss_sum += total
 __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ part, int n, float* __restrict__ out) {
     __shared__ double red[1024];
@@ -201,6 +507,8 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
     a.X = (const char*)X; a.W = (const char*)Wq; a.N = N; a.K = K; a.R = R; a.mode = mode;
     a.Y = (char*)Yout; a.Y0 = (const char*)Y0; a.part = (float*)ws;
     a.ntm = (int)ceil_div64(N, LT); a.ntn = (int)ceil_div64(R, LT);
+    lin_tile_order(a, 256);
+    a.y0_lds = 0;
     if (dt == LLMC_BF16) {
         if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_BF16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_BF16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
@@ -209,6 +517,48 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
         hipLaunchKernelGGL((k_linear_eval<LLMC_F16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
     }
     LLMC_LAUNCH_CHECK();
+    if (mode == 1) {
+        hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, (const float*)ws, a.ntm * a.ntn, loss_sum);
+        LLMC_LAUNCH_CHECK();
+    }
+    return LLMC_OK;
+}
+
+extern "C" int llmc_ktile_pack(const void* src, int dt, int64_t rows, int64_t K, void* dst, llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "ktile_pack: dtype must be f16 or bf16");
+    LLMC_REQUIRE(src && dst && src != dst && rows > 0 && K > 0, "ktile_pack: null/empty/in-place argument");
+    LLMC_REQUIRE(K % L4_KS == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+                 "ktile_pack: needs K % 32 == 0 and 16-B aligned buffers");
+    LLMC_REQUIRE(K / 64 < 65535, "ktile_pack: K too large");
+    hipLaunchKernelGGL(k_ktile_pack, dim3((unsigned)ceil_div64(rows, 64), (unsigned)ceil_div64(K, 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const char*)src, rows, K, (char*)dst);
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64_t N, int64_t K, int64_t R, int mode,
+                                   void* Yout, const void* Y0, float* loss_sum, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "linear_eval_kt: dtype must be f16 or bf16");
+    LLMC_REQUIRE(Xt && Wt && N > 0 && K > 0 && R > 0, "linear_eval_kt: null/empty argument");
+    LLMC_REQUIRE((mode == 0 && Yout) || (mode == 1 && Y0 && loss_sum && ws), "linear_eval_kt: outputs for the mode missing");
+    LLMC_REQUIRE(((uintptr_t)Xt & 15) == 0 && ((uintptr_t)Wt & 15) == 0, "linear_eval_kt: operands must be 16-B aligned");
+    if (K % (L4_KS * L4_RING) != 0 || N * K * 2 >= (1ll << 32) || R * K * 2 >= (1ll << 32)) {
+        set_last_error_msg("linear_eval_kt: needs K % 128 == 0 and operands below 4 GiB");
+        return LLMC_ENOTSUP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LinArgs a;
+    a.X = (const char*)Xt; a.W = (const char*)Wt; a.N = N; a.K = K; a.R = R; a.mode = mode;
+    a.Y = (char*)Yout; a.Y0 = (const char*)Y0; a.part = (float*)ws;
+    a.ntm = (int)ceil_div64(N, LT); a.ntn = (int)ceil_div64(R, LT);
+    const int grid = device_cu_count() & ~7;
+    LLMC_REQUIRE(grid >= 8, "linear_eval_kt: device has fewer than 8 compute units");
+    lin_tile_order(a, grid);
+    a.y0_lds = mode == 1 && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
+    const void* fn = dt == LLMC_BF16 ? (const void*)k_linear_eval4<LLMC_BF16> : (const void*)k_linear_eval4<LLMC_F16>;
+    if (int rc = ensure_dynamic_lds(fn, L4_LDS + 64)) return rc;
+    void* kargs[] = {(void*)&a};
+    LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(L4_THREADS), kargs, (size_t)(L4_LDS + 64), st));
     if (mode == 1) {
         hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, (const float*)ws, a.ntm * a.ntn, loss_sum);
         LLMC_LAUNCH_CHECK();

@@ -110,6 +110,36 @@ def test_linear_eval_vs_fp32(dt, shape):
     assert abs(loss.item() - expect) / expect < 1e-4
 
 
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(300, 128, 200), (1000, 512, 320), (4096, 4096, 1024), (777, 1152, 513)])
+def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape):
+    """llmc_ktile_pack + llmc_linear_eval_kt (the one-wave-per-SIMD GEMM the AWQ grid runs on) against llmc_linear_eval
+    on the same operands: same k order of the fp32 sum, so the same bits — ragged N and R, with and without bias,
+    and the same loss partials."""
+    from llmc_amd.compression.quantization import awq_ops
+    N, K, R = shape
+    gen = torch.Generator().manual_seed(N * 3 + R)
+    x = torch.randn(N, K, generator=gen).to(TD[dt]).cuda()
+    w = (torch.randn(R, K, generator=gen) * 0.05).to(TD[dt]).cuda()
+    b = torch.randn(R, generator=gen).to(TD[dt]).cuda()
+    assert awq_ops.ktile_supported(x, w)
+    xt, wt = awq_ops.ktile_pack(x), awq_ops.ktile_pack(w)
+    # the layout itself: T[kt][row][32]
+    assert torch.equal(xt.reshape(K // 32, N, 32), x.reshape(N, K // 32, 32).transpose(0, 1))
+    sc = (torch.rand(K, generator=gen) + 0.5).to(TD[dt]).cuda()
+    assert torch.equal(awq_ops.div_cols(x, sc, tiled=True).view(torch.int16),
+                       awq_ops.ktile_pack(awq_ops.div_cols(x, sc)).view(torch.int16))
+    for bias in (None, b):
+        y = awq_ops.linear_out(x, w, bias)
+        yt = awq_ops.linear_out(xt, wt, bias, tiled=True)
+        assert torch.equal(y.view(torch.int16), yt.view(torch.int16))
+    y0 = (y.float() * 0.9).to(TD[dt])
+    la = awq_ops.linear_loss_sum(x, w, y0)
+    lb = awq_ops.linear_loss_sum(xt, wt, y0, tiled=True)
+    assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item())
+
+
 def test_clip_search_matches_reference_golden():
     from llmc_amd.compression.quantization import awq_ops
     g = load_golden('clip')
