@@ -240,7 +240,13 @@ int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N, int64_t K
  * layout the one-wave-per-SIMD GEMM streams at whole cache lines. llmc_ktile_pack converts a row-major [rows, K]
  * 16-bit matrix; llmc_linear_eval_kt is llmc_linear_eval (same modes, outputs, Y0 and workspace, same bits) with
  * both operands k-tiled; K % 128 == 0. Used by the AWQ grid step, where x / s and fakequant(W * s) are produced
- * per evaluation anyway (awq.py:229-236). */
+ * per evaluation anyway (awq.py:229-236).
+ * mode | LLMC_LINEAR_YBLOCKED: Yout (mode 0) / Y0 (mode 1) is an opaque TILE-BLOCKED image of the [N, R] matrix,
+ * llmc_linear_eval_yblocked_bytes(N, R) bytes: per 256 x 256 tile one contiguous 128 KiB in the kernel's own
+ * accumulator order (tile, wave, 32 KiB-pieces, lane x 16 B), so that the reference output of the search
+ * (get_original_out) is written with 16-B stores and re-read 20 times as one contiguous run per tile. */
+#define LLMC_LINEAR_YBLOCKED 4
+size_t llmc_linear_eval_yblocked_bytes(int64_t N, int64_t R);
 int llmc_ktile_pack(const void* src, int dt, int64_t rows, int64_t K, void* dst, llmc_stream_t stream);
 int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64_t N, int64_t K, int64_t R, int mode,
                         void* Yout, const void* Y0, float* loss_sum, void* ws, llmc_stream_t stream);

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libllmc_hip.so')
 F16, BF16, F32 = 0, 1, 2
 OUT_FAKE, OUT_I32, OUT_I8, OUT_U8 = 0, 1, 2, 3
 SCALAR_QPARAM = 16   # LLMC_SCALAR_QPARAM
+LINEAR_YBLOCKED = 4   # LLMC_LINEAR_YBLOCKED
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     'llmc_clamp_groups': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp]),
     'llmc_linear_eval_ws_bytes': (_sz, [_i64, _i64, _i64]),
     'llmc_linear_eval': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'llmc_linear_eval_yblocked_bytes': (_sz, [_i64, _i64]),
     'llmc_ktile_pack': (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     'llmc_linear_eval_kt': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'llmc_awq_clip_search_ws_bytes': (_sz, [_i64, _i64, _i64, _i64]),

@@ -100,22 +100,40 @@ def linear_supported(x, w):
     return max(N * K, R * K, N * R) * 2 < (1 << 32)
 
 
-def linear_out(x, wq, bias=None, tiled=False):
+def linear_out(x, wq, bias=None, tiled=False, blocked=False):
     """F.linear(x, wq, bias) on the HIP GEMM: [N, K] x [R, K]^T (+ b) -> [N, R], rounded once to the model dtype.
-    tiled: x and wq are ktile_pack images (x 2-D)."""
+    tiled: x and wq are ktile_pack images (x 2-D). blocked (tiled only): the result is the opaque tile-blocked image
+    (LLMC_LINEAR_YBLOCKED) only linear_loss_sum(..., y0_blocked=True) and unblock_y read."""
     _ffi.require_gpu(x, wq, bias)
     L = _ffi.lib()
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     wq = wq.contiguous()
     N, K = x2.shape
     R = wq.shape[0]
-    y = torch.empty((N, R), dtype=x.dtype, device=x.device)
+    if blocked:
+        if not tiled:
+            raise ValueError('linear_out: blocked output needs tiled operands')
+        y = torch.empty(L.llmc_linear_eval_yblocked_bytes(N, R) // 2, dtype=x.dtype, device=x.device)
+    else:
+        y = torch.empty((N, R), dtype=x.dtype, device=x.device)
     if bias is not None:
         bias = bias.to(x.dtype).contiguous()
     fn, name = (L.llmc_linear_eval_kt, 'llmc_linear_eval_kt') if tiled else (L.llmc_linear_eval, 'llmc_linear_eval')
-    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 0, _ffi.ptr(y), _ffi.ptr(bias), 0, 0, _ffi.stream()),
-               name)
-    return y.reshape(*x.shape[:-1], R)
+    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, _ffi.LINEAR_YBLOCKED if blocked else 0, _ffi.ptr(y),
+                  _ffi.ptr(bias), 0, 0, _ffi.stream()), name)
+    return y if blocked else y.reshape(*x.shape[:-1], R)
+
+
+def unblock_y(yb, N, R):
+    """Tile-blocked image (linear_out(..., blocked=True)) -> row-major [N, R]. Index arithmetic in torch, for tests
+    and debugging: tile (tm, tn), wave (wm, wn), accumulator (m, n), register r = 8 v + j, lane ->
+    token tm*256 + wm*128 + m*32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column tn*256 + wn*128 + n*32 + (lane & 31)."""
+    ntm, ntn = (N + 255) // 256, (R + 255) // 256
+    t = yb.reshape(ntm, ntn, 2, 2, 4, 4, 2, 64, 8)            # tm tn wm wn m n v lane j
+    t = t.reshape(ntm, ntn, 2, 2, 4, 4, 2, 2, 32, 2, 4)        # ... v lh l31 jh jl   (r = 8v + 4jh + jl)
+    # token offset inside the 32-row accumulator block: (r & 3) + 8 (r >> 2) + 4 lh = jl + 8 (2v + jh) + 4 lh
+    t = t.permute(0, 2, 4, 6, 9, 7, 10, 1, 3, 5, 8)            # tm wm m v jh lh jl | tn wn n l31
+    return t.reshape(ntm * 256, ntn * 256)[:N, :R].contiguous()
 
 
 def ktile_supported(x, w):
@@ -134,22 +152,27 @@ def ktile_pack(m):
     return out
 
 
-def linear_loss_sum(x, wq, y0, loss_acc=None, tiled=False):
+def linear_loss_sum(x, wq, y0, loss_acc=None, tiled=False, y0_blocked=False):
     """sum((y0 - F.linear(x, wq))^2) with the difference formed in the model dtype; returns / accumulates into
-    a 1-element fp32 device tensor (no host sync). tiled: x and wq are ktile_pack images."""
+    a 1-element fp32 device tensor (no host sync). tiled: x and wq are ktile_pack images; y0_blocked: y0 is a
+    linear_out(..., blocked=True) image."""
     _ffi.require_gpu(x, wq, y0)
     L = _ffi.lib()
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     wq = wq.contiguous()
-    y0 = y0.reshape(-1, y0.shape[-1]).contiguous()
     N, K = x2.shape
     R = wq.shape[0]
+    if y0_blocked:
+        if not tiled or y0.numel() * 2 != L.llmc_linear_eval_yblocked_bytes(N, R):
+            raise ValueError('linear_loss_sum: y0_blocked needs tiled operands and a blocked image of the same [N, R]')
+    else:
+        y0 = y0.reshape(-1, y0.shape[-1]).contiguous()
     if loss_acc is None:
         loss_acc = torch.zeros(1, dtype=torch.float32, device=x.device)
     ws = _ffi.workspace(L.llmc_linear_eval_ws_bytes(N, K, R), x.device)
     fn, name = (L.llmc_linear_eval_kt, 'llmc_linear_eval_kt') if tiled else (L.llmc_linear_eval, 'llmc_linear_eval')
-    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 1, 0, _ffi.ptr(y0), _ffi.ptr(loss_acc), _ffi.ptr(ws),
-                  _ffi.stream()), name)
+    _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, 1 | (_ffi.LINEAR_YBLOCKED if y0_blocked else 0), 0,
+                  _ffi.ptr(y0), _ffi.ptr(loss_acc), _ffi.ptr(ws), _ffi.stream()), name)
     return loss_acc
 
 

@@ -42,7 +42,7 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
     kt = awq_ops.ktile_supported(x2, wcat) and os.environ.get('LLMC_AWQ_KT', '1') != '0'   # 0: diagnostic, row-major GEMM
     xa, wa = (awq_ops.ktile_pack(x2), awq_ops.ktile_pack(wcat)) if kt else (x2, wcat)
     e0 = _ev() if timing is not None else None
-    org_out = awq_ops.linear_out(xa, wa, tiled=kt)     # get_original_out (awq.py:128-132)
+    org_out = awq_ops.linear_out(xa, wa, tiled=kt, blocked=kt)     # get_original_out (awq.py:128-132)
     del xa, wa
     if timing is not None:
         timing.append((e0, _ev(), 2.0 * N * R * K))
@@ -56,7 +56,7 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
         if kt:
             wq = awq_ops.ktile_pack(wq)
         e0 = _ev() if timing is not None else None
-        awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1], tiled=kt)
+        awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1], tiled=kt, y0_blocked=kt)
         if timing is not None:
             timing.append((e0, _ev(), 2.0 * N * R * K))
         scales_all.append(s)

@@ -34,6 +34,7 @@ struct LinArgs {
     // tile order: each XCD (blockIdx & 7) works on one sbm x sbn block of tiles per round (sbm * sbn = gridDim / 8), so
     // the CUs that share an L2 share sbm + sbn operand panels instead of ~gridDim/8 + 1; blocks are numbered tn-fastest
     int sbm, sbn, nsn, nrounds;
+    int yblk;         // k_linear_eval4: Y (mode 0) / Y0 (mode 1) is tile-blocked in fragment order (LLMC_LINEAR_YBLOCKED)
     int y0_lds;       // k_linear_eval4, mode 1: Y0 tiles are staged through LDS (R % 8 == 0, Y0 16-B aligned, < 4 GiB)
 };
 
@@ -230,9 +231,24 @@ __device__ __forceinline__ void l4_dma(i32x4 rsrc, uint32_t voff, uint32_t& soff
     asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds\n\ts_add_u32 %0, %0, %5"
                  : "+s"(soff) : "v"(voff), "s"(rsrc), "s"(wvoff), "n"(DST), "s"(adv) : "memory", "scc");
 }
+template <int DST>
+__device__ __forceinline__ void l4_dma_at(i32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t wvoff) {
+    asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
+                 :: "s"(soff), "v"(voff), "s"(rsrc), "s"(wvoff), "n"(DST) : "memory", "scc");
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// (a, b) rounded to bf16 (RNE, one v_cvt_pk_bf16_f32) and widened back
+__device__ __forceinline__ f32x2 round_pair_bf16(f32x2 v) {
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
 template <int N> __device__ __forceinline__ void l4_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int DT>
+// STAGE_Y: loss mode with the Y0 tile staged through LDS: 1 row-major Y0 (a.y0_lds), 2 tile-blocked Y0 (a.yblk)
+template <int DT, int STAGE_Y>
 __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)(smem + L4_LDS);
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
     }
     i32x4 ry = rx;
     if (a.mode == 1) {
-        const int64_t yb = a.N * a.R * 2;
+        const int64_t yb = a.yblk ? (int64_t)a.ntm * a.ntn * 131072 : a.N * a.R * 2;
         ry[0] = (int)(uint32_t)(uintptr_t)a.Y0;
         ry[1] = (int)((uint32_t)((uintptr_t)a.Y0 >> 32) & 0xffffu);
         ry[2] = (int)(uint32_t)(yb > 0xffffffffll ? 0xffffffffll : yb);
@@ -310,6 +326,9 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             if constexpr (d < 4) l4_dma<DSTB>(rx, vA, sA[d & 3], wvoff, advA);
             else l4_dma<DSTB>(rw, vB, sB[d & 3], wvoff, advB);
         };
+        const uint32_t vy = (uint32_t)((((int64_t)tm * LT + 2 * wv + (lane >> 5)) * a.R + (int64_t)tn * LT + (lane & 31) * 8) * 2);
+        const uint32_t advY = (uint32_t)(16 * a.R);        // 8 rows down per piece index
+        const uint32_t vyb = (uint32_t)(((int64_t)t * 4 + wv) * 32768 + lane * 16);
         s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
         auto frag = [&](auto slc, auto kkc, auto fc, s16x8 (&fa)[4], s16x8 (&fb)[4]) {
             constexpr int SL = decltype(slc)::value;
@@ -320,16 +339,29 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             else if constexpr (f <= 4) fb[f - 1] = *(LDS_AS s16x8*)(lds + offB[SL >> 1][KK][f - 1] + IMM);
             else fa[f - 4] = *(LDS_AS s16x8*)(lds + offA[SL >> 1][KK][f - 4] + IMM);
         };
+        // Y0 tile piece I (0..31) of this wave. Row-major Y0: rows 2 * (wv + 4 I), + 1 (512 B each) -> LDS
+        // [I * 4 KiB + wv KiB). Tile-blocked Y0 (fragment order, LLMC_LINEAR_YBLOCKED): the wave's own KiB I of the
+        // tile's contiguous 128 KiB -> LDS [I/8 * 32 KiB + wv * 8 KiB + I%8 KiB): 8 pieces of every wave per ring slot
+        auto ypiece = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (STAGE_Y == 2) l4_dma_at<(I >> 3) * 32768 + (I & 7) * 1024>(ry, vyb, (uint32_t)I * 1024u, wvoff * 8);
+            else l4_dma_at<I * 4096>(ry, vy, (uint32_t)I * advY, wvoff);
+        };
+        // REQ: what rides behind the MFMAs. 0 nothing, 1 operand pieces D0.. of slot dslc (the steady state),
+        // 2 Y0 pieces D0..D0+3, 3 Y0 pieces D0..D0+7 and no fragment reads (the tile's very last burst)
         auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, auto kkc,
-                         auto dslc, auto d0c, auto dmac) {
+                         auto dslc, auto d0c, auto reqc) {
             constexpr int D0 = decltype(d0c)::value;
-            constexpr bool DMA = decltype(dmac)::value;
+            constexpr int REQ = decltype(reqc)::value;
             l4_static_for<0, 16>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int mi = i >> 2, ni = (mi & 1) ? 3 - (i & 3) : (i & 3);
                 acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
                 if constexpr ((i & 3) == 3) {
-                    if constexpr (DMA) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{});
+                    if constexpr (REQ == 1) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{});
+                    else if constexpr (REQ >= 2) ypiece(std::integral_constant<int, D0 + (i >> 2)>{});
+                } else if constexpr (REQ == 3) {
+                    if constexpr (i - (i >> 2) < 4) ypiece(std::integral_constant<int, D0 + 4 + i - (i >> 2)>{});
                 } else if constexpr (i < 10) frag(rslc, kkc, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -341,78 +373,105 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
         l4_vmwait<(L4_RING - 2) * PER + PER / 2>();
         __builtin_amdgcn_s_barrier();
         l4_static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, K0, fc, fa0, fb0); });
-        // one ring turn = 4 stages. The LAST turn of a tile requests only what the tile still needs (the B half of its
-        // final stage) and counts the VM counter down to 0, so the ring is quiet and free when the turn ends.
-        auto turn = [&](auto lastc) {
-            constexpr bool LAST = decltype(lastc)::value;
+        // one ring turn = 4 stages. The LAST turn of a tile (KIND 1) requests only what the tile still needs (the B half
+        // of its final stage) and counts the VM counter down to 0, so the ring is quiet and free when the turn ends.
+        // KIND 2 (loss mode): the ring slots the last turn leaves behind take the Y0 tile, a quarter (64 rows = 32 KiB =
+        // one slot = 8 pieces per wave) per stage, in the request slots the operands no longer use: the loss epilogue
+        // finds its reference tile in LDS.
+        auto turn = [&](auto kindc) {
+            constexpr int KIND = decltype(kindc)::value;
             l4_static_for<0, L4_RING>([&](auto jc) {
                 constexpr int J = decltype(jc)::value;
                 constexpr int JN = (J + 1) % L4_RING, JP = (J + L4_RING - 1) % L4_RING;
-                constexpr int AHEAD = LAST ? (J < 2 ? 2 - J : 0) : L4_RING - 2;    // stages that may still be in flight
-                burst(fa0, fb0, fa1, fb1, jc, K1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{},
-                      std::integral_constant<bool, !LAST || J == 0>{});
-                l4_vmwait<AHEAD * PER>();
+                // requests that may still be in flight when stage J + 1 must have landed
+                constexpr int AHEAD = KIND == 0 ? 2 * PER : KIND == 1 ? (J < 2 ? 2 - J : 0) * PER : 2 * PER;
+                constexpr int R1 = KIND == 0 ? 1 : J == 0 ? 1 : KIND == 1 ? 0 : 2;
+                constexpr int R2 = KIND == 0 ? 1 : KIND == 1 ? 0 : J == 3 ? 3 : 2;
+                burst(fa0, fb0, fa1, fb1, jc, K1, std::integral_constant<int, JP>{},
+                      std::integral_constant<int, R1 == 1 ? 4 : 8 * J - 4>{}, std::integral_constant<int, R1>{});
+                if constexpr (!(KIND == 2 && J == 3)) l4_vmwait<AHEAD>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, K0, jc, std::integral_constant<int, 0>{},
-                      std::integral_constant<bool, !LAST>{});
+                burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, K0, jc,
+                      std::integral_constant<int, R2 == 1 ? 0 : 8 * J>{}, std::integral_constant<int, R2>{});
             });
         };
-        for (int g = 0; g < ngroups - 1; ++g) turn(std::false_type{});
-        turn(std::true_type{});
+        for (int g = 0; g < ngroups - 1; ++g) turn(std::integral_constant<int, 0>{});
+        turn(std::integral_constant<int, STAGE_Y != 0 ? 2 : 1>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        if (a.mode == 1 && a.y0_lds) {
-            // loss epilogue: the Y0 tile (256 x 512 B) comes through the now idle ring by LDS-DMA, 32 KiB-pieces per wave
-            // all in flight at once (two 512-B row segments per piece), then every lane picks its 256 values with
-            // immediate-offset ds_read_u16. (Read straight from global, each of the 256 two-byte loads sat behind its
-            // own s_waitcnt: ~40 % of the tile time.)
-            uint32_t sy = 0;
-            const uint32_t vy = (uint32_t)((((int64_t)tm * LT + 2 * wv + (lane >> 5)) * a.R + (int64_t)tn * LT + (lane & 31) * 8) * 2);
-            const uint32_t advY = (uint32_t)(16 * a.R);        // 8 rows down
-            l4_static_for<0, 32>([&](auto ic) { l4_dma<decltype(ic)::value * 4096>(ry, vy, sy, wvoff, advY); });
-            l4_vmwait<0>();
+        if (a.mode == 2) {   // lab (LLMC_LIN_ABL=1): the main loop alone, nothing stored
             __builtin_amdgcn_s_barrier();
+            continue;
+        }
+
+        if constexpr (STAGE_Y != 0) {
+            // loss epilogue: the Y0 tile (256 x 512 B) arrived in the ring during the last turn; every lane picks its 256
+            // values with immediate-offset ds_read_u16. (Read straight from global, each of the 256 two-byte loads sat
+            // behind its own s_waitcnt: ~40 % of the tile time.)
+            l4_vmwait<0>();
+            if constexpr (STAGE_Y == 1) __builtin_amdgcn_s_barrier();   // blocked: a wave reads only what it requested itself
+            if (a.y0_lds == 2) { __syncthreads(); continue; }   // lab (LLMC_LIN_ABL=3): Y0 staged and waited for, not folded
             const int ybase = (wm * 128 + 4 * (lane >> 5)) * 512 + (wn * 128 + (lane & 31)) * 2;
+            const int yown = wv * 8192 + lane * 16;
             const int64_t col0 = (int64_t)tn * LT + wn * 128 + (lane & 31);
             const int64_t tokb = (int64_t)tm * LT + wm * 128 + 4 * (lane >> 5);
             // rows / columns of this lane's 128 x 128 block that exist (edge tiles); interior tiles take the unmasked copy
             const int nrow = (int)(a.N - tokb < 128 ? a.N - tokb : 128);      // valid: trow < nrow (may be <= 0)
             const int ncol = (int)(a.R - col0 <= 0 ? 0 : (a.R - col0 + 31) / 32);   // valid: n < ncol
             const bool full = (int64_t)(tm + 1) * LT <= a.N && (int64_t)(tn + 1) * LT <= a.R;   // block-uniform
-            float lsum = 0.0f;
+            f32x2 lsum2 = {0.0f, 0.0f};      // even / odd accumulator registers, fused multiply-add in fp32
             auto fold = [&](auto maskedc) {
                 constexpr bool MASKED = decltype(maskedc)::value;
                 l4_static_for<0, 16>([&](auto mnc) {
                     constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
                     uint16_t yb[16];
-                    l4_static_for<0, 16>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        constexpr int trow = m * 32 + (r & 3) + 8 * (r >> 2);
-                        yb[r] = *(LDS_AS const uint16_t*)(lds + ybase + trow * 512 + n * 64);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);   // 16 reads in flight, one wait (the scheduler pairs each read with its use)
-                    l4_static_for<0, 16>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        constexpr int trow = m * 32 + (r & 3) + 8 * (r >> 2);
-                        const float y0 = DT == LLMC_BF16 ? bf16_bits_to_f32(yb[r]) : f16_bits_to_f32(yb[r]);
-                        const float y = rndc<DT>(acc[m][n][r]);
-                        const float d = rndc<DT>(y0 - y);
-                        float d2 = d * d;
-                        if constexpr (MASKED) {
-                            // bit mask, not a select: the compiler turns `cond ? d2 : 0` into 256 exec-masked branches
-                            const uint32_t keep = (uint32_t)-(int)((trow < nrow) & (n < ncol));
-                            d2 = __uint_as_float(__float_as_uint(d2) & keep);
+                    if constexpr (STAGE_Y == 2) {
+                        constexpr int I = (m * 4 + n) * 2;
+                        const s16x8 v0 = *(LDS_AS const s16x8*)(lds + yown + (I >> 3) * 32768 + (I & 7) * 1024);
+                        const s16x8 v1 = *(LDS_AS const s16x8*)(lds + yown + (I >> 3) * 32768 + ((I & 7) + 1) * 1024);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            yb[j] = (uint16_t)v0[j];
+                            yb[8 + j] = (uint16_t)v1[j];
                         }
-                        lsum += d2;
+                    } else {
+                        l4_static_for<0, 16>([&](auto rc) {
+                            constexpr int r = decltype(rc)::value;
+                            constexpr int trow = m * 32 + (r & 3) + 8 * (r >> 2);
+                            yb[r] = *(LDS_AS const uint16_t*)(lds + ybase + trow * 512 + n * 64);
+                        });
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // 16 reads in flight, one wait (the scheduler pairs each read with its use)
+                    // two values per step: one packed conversion per rounding, packed fp32 subtract / multiply-add
+                    l4_static_for<0, 8>([&](auto pc) {
+                        constexpr int r = 2 * decltype(pc)::value;
+                        constexpr int trow = m * 32 + (r & 3) + 8 * (r >> 2);      // r + 1 is the next row
+                        f32x2 y0, y, d;
+                        if constexpr (DT == LLMC_BF16) {
+                            y0 = f32x2{bf16_bits_to_f32(yb[r]), bf16_bits_to_f32(yb[r + 1])};
+                            y = round_pair_bf16(f32x2{acc[m][n][r], acc[m][n][r + 1]});
+                            d = round_pair_bf16(y0 - y);
+                        } else {
+                            y0 = f32x2{f16_bits_to_f32(yb[r]), f16_bits_to_f32(yb[r + 1])};
+                            y = f32x2{rndc<DT>(acc[m][n][r]), rndc<DT>(acc[m][n][r + 1])};
+                            const f32x2 t = y0 - y;
+                            d = f32x2{rndc<DT>(t[0]), rndc<DT>(t[1])};
+                        }
+                        if constexpr (MASKED) {
+                            // bit mask, not a select: the compiler turns `cond ? d2 : 0` into exec-masked branches
+                            const uint32_t k0 = (uint32_t)-(int)((trow < nrow) & (n < ncol));
+                            const uint32_t k1 = (uint32_t)-(int)((trow + 1 < nrow) & (n < ncol));
+                            d = f32x2{__uint_as_float(__float_as_uint(d[0]) & k0), __uint_as_float(__float_as_uint(d[1]) & k1)};
+                        }
+                        lsum2 = __builtin_elementwise_fma(d, d, lsum2);
                     });
                 });
             };
             if (full) fold(std::false_type{});
             else fold(std::true_type{});
+            float lsum = lsum2[0] + lsum2[1];
             lsum = wave_sum(lsum, 64);
             if (lane == 0) red[wv] = lsum;
             __syncthreads();           // also: every wave is done with the staged tile before the next prologue
@@ -421,6 +480,31 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             continue;
         }
 
+        __builtin_amdgcn_s_barrier();    // every wave has read its last fragments before the next prologue refills the ring
+        if (a.mode == 0 && a.yblk) {
+            // tile-blocked output in fragment order: tile t = 128 KiB, wave wv = 32 KiB, piece I = (m*4 + n)*2 + v = 1 KiB,
+            // lane = 16 B = acc[m][n][8v .. 8v+7] rounded (+ bias): one coalesced 16-B store per piece
+            char* yt = a.Y + ((int64_t)t * 4 + wv) * 32768 + lane * 16;
+            l4_static_for<0, 16>([&](auto mnc) {
+                constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
+                const int64_t col = (int64_t)tn * LT + wn * 128 + n * 32 + (lane & 31);
+                const float b = (a.Y0 && col < a.R) ? load_as_f32(a.Y0, col, DT) : 0.0f;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    uint16_t o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = acc[m][n][8 * v + j] + b;
+                        o[j] = DT == LLMC_BF16 ? f32_to_bf16_bits(y) : f32_to_f16_bits(y);
+                    }
+                    uint4 ov;
+                    __builtin_memcpy(&ov, o, 16);
+                    *reinterpret_cast<uint4*>(yt + ((m * 4 + n) * 2 + v) * 1024) = ov;
+                }
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            continue;
+        }
         float lsum = 0.0f;
         l4_static_for<0, 16>([&](auto mnc) {
             constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
@@ -509,6 +593,7 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
     a.ntm = (int)ceil_div64(N, LT); a.ntn = (int)ceil_div64(R, LT);
     lin_tile_order(a, 256);
     a.y0_lds = 0;
+    a.yblk = 0;
     if (dt == LLMC_BF16) {
         if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_BF16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_BF16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
@@ -536,15 +621,29 @@ extern "C" int llmc_ktile_pack(const void* src, int dt, int64_t rows, int64_t K,
     return LLMC_OK;
 }
 
-extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64_t N, int64_t K, int64_t R, int mode,
+extern "C" size_t llmc_linear_eval_yblocked_bytes(int64_t N, int64_t R) {
+    if (N <= 0 || R <= 0) return 0;
+    return (size_t)(ceil_div64(N, LT) * ceil_div64(R, LT)) * (size_t)(LT * LT * 2);
+}
+
+extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64_t N, int64_t K, int64_t R, int mode_flags,
                                    void* Yout, const void* Y0, float* loss_sum, void* ws, llmc_stream_t stream) {
+    const int mode = mode_flags & 3, yblk = (mode_flags & LLMC_LINEAR_YBLOCKED) != 0;
     LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "linear_eval_kt: dtype must be f16 or bf16");
     LLMC_REQUIRE(Xt && Wt && N > 0 && K > 0 && R > 0, "linear_eval_kt: null/empty argument");
+    LLMC_REQUIRE((mode_flags & ~(1 | LLMC_LINEAR_YBLOCKED)) == 0, "linear_eval_kt: unknown mode bits");
     LLMC_REQUIRE((mode == 0 && Yout) || (mode == 1 && Y0 && loss_sum && ws), "linear_eval_kt: outputs for the mode missing");
     LLMC_REQUIRE(((uintptr_t)Xt & 15) == 0 && ((uintptr_t)Wt & 15) == 0, "linear_eval_kt: operands must be 16-B aligned");
     if (K % (L4_KS * L4_RING) != 0 || N * K * 2 >= (1ll << 32) || R * K * 2 >= (1ll << 32)) {
         set_last_error_msg("linear_eval_kt: needs K % 128 == 0 and operands below 4 GiB");
         return LLMC_ENOTSUP;
+    }
+    if (yblk) {
+        LLMC_REQUIRE((((uintptr_t)(mode == 0 ? (const void*)Yout : Y0)) & 15) == 0, "linear_eval_kt: blocked Y must be 16-B aligned");
+        if (llmc_linear_eval_yblocked_bytes(N, R) >= (1ull << 32)) {
+            set_last_error_msg("linear_eval_kt: tile-blocked Y must stay below 4 GiB");
+            return LLMC_ENOTSUP;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     LinArgs a;
@@ -554,8 +653,19 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     const int grid = device_cu_count() & ~7;
     LLMC_REQUIRE(grid >= 8, "linear_eval_kt: device has fewer than 8 compute units");
     lin_tile_order(a, grid);
-    a.y0_lds = mode == 1 && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
-    const void* fn = dt == LLMC_BF16 ? (const void*)k_linear_eval4<LLMC_BF16> : (const void*)k_linear_eval4<LLMC_F16>;
+    a.yblk = yblk;
+    a.y0_lds = mode == 1 && !yblk && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
+    int stage = mode == 1 ? (yblk ? 2 : a.y0_lds ? 1 : 0) : 0;
+    if (const char* e = getenv("LLMC_LIN_ABL")) {   // lab switches, never set by the package
+        const int v = atoi(e);
+        if (v == 1) { a.mode = 2; a.y0_lds = 0; stage = 0; }      // main loop only
+        if (v == 2 && stage == 1) { a.y0_lds = 0; stage = 0; }    // row-major Y0 straight from global
+        if (v == 3 && stage) a.y0_lds = 2;                        // Y0 staged and waited for, not folded
+    }
+    const bool bf = dt == LLMC_BF16;
+    const void* fn = stage == 2 ? (bf ? (const void*)k_linear_eval4<LLMC_BF16, 2> : (const void*)k_linear_eval4<LLMC_F16, 2>)
+                   : stage == 1 ? (bf ? (const void*)k_linear_eval4<LLMC_BF16, 1> : (const void*)k_linear_eval4<LLMC_F16, 1>)
+                                : (bf ? (const void*)k_linear_eval4<LLMC_BF16, 0> : (const void*)k_linear_eval4<LLMC_F16, 0>);
     if (int rc = ensure_dynamic_lds(fn, L4_LDS + 64)) return rc;
     void* kargs[] = {(void*)&a};
     LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(L4_THREADS), kargs, (size_t)(L4_LDS + 64), st));

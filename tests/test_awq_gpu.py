@@ -138,6 +138,14 @@ def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape):
     la = awq_ops.linear_loss_sum(x, w, y0)
     lb = awq_ops.linear_loss_sum(xt, wt, y0, tiled=True)
     assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item())
+    # tile-blocked reference output (what the search keeps): the same values in the kernel's accumulator order
+    yb = awq_ops.linear_out(xt, wt, b, tiled=True, blocked=True)
+    assert torch.equal(awq_ops.unblock_y(yb, N, R).view(torch.int16), y.view(torch.int16))
+    sc = (torch.rand(K, generator=gen) + 0.5).to(TD[dt]).cuda()
+    xs = awq_ops.div_cols(x, sc)
+    lc = awq_ops.linear_loss_sum(xs, w, y)
+    ld = awq_ops.linear_loss_sum(awq_ops.ktile_pack(xs), wt, yb, tiled=True, y0_blocked=True)
+    assert abs(lc.item() - ld.item()) <= 1e-5 * abs(lc.item())
 
 
 def test_clip_search_matches_reference_golden():
