@@ -67,6 +67,8 @@ def parse_args(argv=None):
                     help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
                          'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch')
     ap.add_argument('--mode', default='independent', choices=['independent', 'cooperative'])
+    ap.add_argument('--order', choices=['chain', 'k1first'], default='k1first',
+                    help='subset schedule when --overlap > 1 (see step_independent)')
     ap.add_argument('--overlap', type=int, default=4,
                     help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); '
                          '0 = one after the other on the current stream')
@@ -259,7 +261,9 @@ class HipOps:
 
     def stream(self, i):
         if i not in self.streams:
-            self.streams[i] = self.torch.cuda.Stream(device=self.dev)
+            # stream 0 carries the longest chain: its many short kernels go ahead of the other chains' in the queues
+            prio = -1 if (i == 0 and os.environ.get('LLMC_BENCH_PRIO', '0') == '1') else 0   # measured: no effect
+            self.streams[i] = self.torch.cuda.Stream(device=self.dev, priority=prio)
         return self.streams[i]
 
     def helper_streams(self, enable):
@@ -438,22 +442,31 @@ def main():
         ops.timing = timing if record else None
         outs = []
         Hs = {}
-        for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
-            Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
         if args.overlap <= 1 or args.dry:
+            for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
+                Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
             for name, K, layers in groups:
                 outs.append(ops.quantize(name, weights[name], Hs[name]))
             return outs
-        # the four subsets' factorisations and column loops are independent latency-bound chains: one stream each,
-        # widest first (its chain is the longest)
+        # the four subsets' factorisations and column loops are independent latency-bound chains: one stream each.
+        # --order k1first (default): all four Hessians, then the four chains, widest first.
+        # --order chain: the subset with the longest K1 -> K3 -> K4 chain (down: 39 + 22 + 11 ms) goes first and its
+        # chain starts the moment its Hessian is done, the other Hessians and chains behind it. Measured on one box:
+        # 99.2 ms/step against 98.0 for k1first (K1 drops from 0.564 to 0.535 of peak): a k_syrk4 block owns its CU
+        # (512 VGPRs, 128 KiB LDS) and its tile list is static, so every CU a chain kernel holds when a Hessian starts
+        # delays that Hessian's tail, and the chain in turn waits for whole Hessians to retire.
         cur = torch.cuda.current_stream()
         order = sorted(range(len(groups)), key=lambda i: -groups[i][1] * sum(r for _, r in groups[i][2]))
+        if args.order == 'k1first':
+            for name, K, layers in groups:
+                Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
         evs = []
         for si, gi in enumerate(order):
-            name = groups[gi][0]
+            name, K = groups[gi][0], groups[gi][1]
+            if args.order != 'k1first':
+                Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
             st = ops.stream(si % args.overlap)
-            if si < args.overlap:
-                st.wait_stream(cur)
+            st.wait_stream(cur)
             # one stream per chain and no internal helper streams: measured 94.5 ms/step, against 96.3 with a helper for
             # the longest chain and 108 without overlap (more streams than hardware queues start to serialise)
             with torch.cuda.stream(st), ops.helper_streams(False):
