@@ -67,7 +67,9 @@ def parse_args(argv=None):
                     help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
                          'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch')
     ap.add_argument('--mode', default='independent', choices=['independent', 'cooperative'])
-    ap.add_argument('--order', choices=['chain', 'k1first'], default='k1first',
+    ap.add_argument('--wide-helper', type=int, default=1, help='--order shadow: the widest chain, alone by then, keeps its helper stream')
+    ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
+    ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
                     help='subset schedule when --overlap > 1 (see step_independent)')
     ap.add_argument('--overlap', type=int, default=4,
                     help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); '
@@ -270,6 +272,10 @@ class HipOps:
         from llmc_amd import _ffi
         return _ffi.helper_streams(enable)
 
+    def cu_reserve(self, n):
+        from llmc_amd import _ffi
+        return _ffi.cu_reserve(n)
+
     def sync(self):
         self.torch.cuda.synchronize()
 
@@ -457,21 +463,39 @@ def main():
         # delays that Hessian's tail, and the chain in turn waits for whole Hessians to retire.
         cur = torch.cuda.current_stream()
         order = sorted(range(len(groups)), key=lambda i: -groups[i][1] * sum(r for _, r in groups[i][2]))
-        if args.order == 'k1first':
-            for name, K, layers in groups:
-                Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
         evs = []
-        for si, gi in enumerate(order):
-            name, K = groups[gi][0], groups[gi][1]
-            if args.order != 'k1first':
-                Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+
+        def chain(si, gi, helper=False):
+            name = groups[gi][0]
             st = ops.stream(si % args.overlap)
             st.wait_stream(cur)
             # one stream per chain and no internal helper streams: measured 94.5 ms/step, against 96.3 with a helper for
             # the longest chain and 108 without overlap (more streams than hardware queues start to serialise)
-            with torch.cuda.stream(st), ops.helper_streams(False):
+            with torch.cuda.stream(st), ops.helper_streams(helper):
                 outs.append(ops.quantize(name, weights[name], Hs[name]))
             evs.append(st)
+
+        if args.order == 'shadow':
+            # the narrow subsets first: their Hessians (3 x 3.3 ms), then their chains on streams 1.., and BEHIND them the
+            # widest subset's Hessian (39 ms) with --reserve CUs left free: the narrow chains run in its shadow on those
+            # CUs, and the widest chain has the device to itself afterwards
+            for gi in order[1:]:
+                Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs)
+            for si, gi in enumerate(order[1:]):
+                chain(si + 1, gi)
+            g0 = groups[order[0]]
+            with ops.cu_reserve(args.reserve):
+                Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
+            chain(0, order[0], helper=args.wide_helper)
+        else:
+            if args.order == 'k1first':
+                for name, K, layers in groups:
+                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+            for si, gi in enumerate(order):
+                name, K = groups[gi][0], groups[gi][1]
+                if args.order != 'k1first':
+                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+                chain(si, gi)
         for st in set(evs):
             cur.wait_stream(st)
         return outs

@@ -39,6 +39,9 @@ extern "C" {
  * (per_tensor qparams): it is used at its own precision but ATen leaves it out of type promotion, so every op still
  * rounds to the weight dtype (quant.py:699-717 with the 0-dim scales of quant.py:132-136,555-556). */
 #define LLMC_SCALAR_QPARAM 16
+/* OR-ed into llmc_quant_static's zdt: round_zp = False (quant.py:557-558, 702-707): the zero point is not an integer and
+ * the code is clamp(round(x / max(s, 1e-9) + z)) instead of clamp(round(x / s) + z). */
+#define LLMC_FRACTIONAL_ZP 32
 
 /* integer code container for llmc_quant_static / llmc_quant_dynamic */
 #define LLMC_OUT_FAKE 0 /* dequantised values, written in the weight dtype              */
@@ -58,6 +61,12 @@ int llmc_hip_last_error(char* buf_host, size_t n);
  * chain: every entry point still completes, in stream order, on the stream it was given. Returns the previous value.
  * No reference counterpart (the reference runs one default stream). */
 int llmc_hip_set_helper_streams(int enable);
+
+/* Per calling-thread: the Hessian kernel (llmc_hessian_accum*) is persistent, one workgroup per compute unit, and a
+ * workgroup owns its CU (all VGPRs, 128 KiB LDS). n_cus > 0 makes it leave that many CUs (rounded up to a multiple of
+ * 8, one per XCD) to kernels the caller runs on other streams meanwhile; 0 (default) = the whole device. Returns the
+ * previous value. No reference counterpart. */
+int llmc_hip_set_cu_reserve(int n_cus);
 
 /* ------------------------------------------------------------------------------------------------
  * Quantizer arithmetic (llmc/compression/quantization/quant.py)
@@ -189,6 +198,25 @@ int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, int64_t K, i
                        float qmax, int64_t group_size, int static_groups, const int32_t* col_group,
                        float* scales, float* zeros, float* Wout, float* losses, int blocksize,
                        void* ws, llmc_stream_t stream);
+
+/* SpQR.weight_transform (spqr.py:185-254) for asymmetric per-group weights (a symmetric weight quantizer crashes in the
+ * reference's get_group_qparams): the blocked column loop with
+ *   - leave-one-out outlier detection per group (spqr.py:186-203, 214-229) unless simplified_outliers or threshold = inf,
+ *   - the round_zp = False quantizer (quant.py:555-559, 702-707),
+ *   - the second-level scale / zero quantizers as the reference executes them on its [R, 1] tensors (spqr.py:323-345):
+ *     stored scale = fl(fl(s / ss) * ss), ss = 1e-5 / (scale_qmax - scale_qmin), zero point likewise,
+ *   - outlier mask err^2 > threshold, masked weights keep their value (spqr.py:239-244),
+ *   - W[:, i+1:i2] -= err x Hinv[i, i+1:i2] in the block, W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] after it.
+ * W [R, K] fp32 running weights (in/out), Hinv [K, K] fp32 upper factor, threshold = relative_threshold * outlier_scale
+ * (caller computes spqr.py:205-206; INFINITY = no outliers), group_size in {16, 32, 64, 128}, blocksize 128.
+ * Outputs: Wout (tmp) / losses [R, K] fp32, mask [R, K] uint8, scales / zeros [R, K/group_size] fp32 in processing
+ * order. Bit-exact against oracle/csrc/spqr_canon.c, which is pinned bit-exactly to the reference (tests/golden/spqr.npz). */
+size_t llmc_spqr_quantize_ws_bytes(int64_t R, int64_t K);
+int llmc_spqr_quantize(float* W, const float* Hinv, int64_t R, int64_t K, float qmin, float qmax,
+                       int64_t group_size, float threshold, int simplified_outliers, float scale_qmin,
+                       float scale_qmax, float zero_qmin, float zero_qmax, float* scales, float* zeros,
+                       float* Wout, float* losses, uint8_t* mask, int blocksize, void* ws,
+                       llmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * AWQ (llmc/compression/quantization/awq.py, auto_clip.py)

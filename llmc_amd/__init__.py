@@ -8,7 +8,7 @@ non-GPU tensors, the product path raises.
 __version__ = '0.1.0'
 
 
-def register_into(registry, names=('GPTQ', 'Awq', 'RTN')):
+def register_into(registry, names=('GPTQ', 'Awq', 'RTN', 'SpQR')):
     """Bind this package's algorithm classes under llmc's keys in `registry` (llmc.utils.registry_factory.ALGO_REGISTRY,
     llmc/utils/registry_factory.py:9-23). Uses item assignment, which llmc's Register supports and which REPLACES an
     existing key, so it works before or after llmc has registered its own classes, in any import order; returns the

@@ -12,6 +12,7 @@ F16, BF16, F32 = 0, 1, 2
 OUT_FAKE, OUT_I32, OUT_I8, OUT_U8 = 0, 1, 2, 3
 SCALAR_QPARAM = 16   # LLMC_SCALAR_QPARAM
 LINEAR_YBLOCKED = 4   # LLMC_LINEAR_YBLOCKED
+FRACTIONAL_ZP = 32    # LLMC_FRACTIONAL_ZP
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 
@@ -23,6 +24,7 @@ SIGNATURES = {
     'llmc_hip_abi_version': (_i32, []),
     'llmc_hip_last_error': (_i32, [C.c_char_p, _sz]),
     'llmc_hip_set_helper_streams': (_i32, [_i32]),
+    'llmc_hip_set_cu_reserve': (_i32, [_i32]),
     'llmc_minmax_qparams_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_minmax_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     'llmc_mse_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -44,6 +46,9 @@ SIGNATURES = {
                                   _i32, _vp, _vp]),
     'llmc_gptq_quantize_cols': (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _f32, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                        _i32, _vp, _vp]),
+    'llmc_spqr_quantize_ws_bytes': (_sz, [_i64, _i64]),
+    'llmc_spqr_quantize': (_i32, [_vp, _vp, _i64, _i64, _f32, _f32, _i64, _f32, _i32, _f32, _f32, _f32, _f32, _vp, _vp,
+                                  _vp, _vp, _vp, _i32, _vp, _vp]),
     'llmc_awq_act_mean_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_awq_act_mean': (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     'llmc_awq_weight_mean_ws_bytes': (_sz, [_i64, _i64]),
@@ -169,4 +174,19 @@ class helper_streams:
 
     def __exit__(self, *exc):
         lib().llmc_hip_set_helper_streams(self.prev)
+        return False
+
+
+class cu_reserve:
+    """with _ffi.cu_reserve(32): ...  — Hessian kernels launched inside leave 32 CUs to the other streams
+    (llmc_hip_set_cu_reserve)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = lib().llmc_hip_set_cu_reserve(self.n)
+
+    def __exit__(self, *exc):
+        lib().llmc_hip_set_cu_reserve(self.prev)
         return False

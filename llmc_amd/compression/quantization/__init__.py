@@ -7,3 +7,4 @@ from .auto_clip import AutoClipper  # noqa: F401
 from .rtn import RTN  # noqa: F401
 from .gptq import GPTQ  # noqa: F401
 from .awq import Awq  # noqa: F401
+from .spqr import SpQR  # noqa: F401

@@ -193,8 +193,7 @@ class IntegerQuantizer(BaseQuantizer):
     # ---- static arithmetic with given qparams (quant.py:699-717) ------------------------------------
     def _static(self, tensor, scales, zeros, qmax, qmin, out_kind):
         _ffi.require_gpu(tensor, scales)
-        if not self.round_zp:
-            raise NotImplementedError('round_zp=False quant() is outside the hot path')
+        fz = 0 if self.round_zp else _ffi.FRACTIONAL_ZP     # quant.py:702-707: round(x / s.clamp_min(1e-9) + z)
         L = _ffi.lib()
         tensor = tensor.contiguous()
         g = tensor.shape[-1] if self.granularity != 'per_tensor' else tensor.numel()
@@ -229,7 +228,7 @@ class IntegerQuantizer(BaseQuantizer):
             out = torch.empty(tensor.shape, dtype=odt, device=tensor.device)
         _ffi.check(L.llmc_quant_static(
             _ffi.ptr(tensor), _ffi.dt(tensor), G, g, _ffi.ptr(scales_f), _ffi.dt(scales_f) | s_flag,
-            _ffi.ptr(zt), (_ffi.dt(zt) | z_flag) if zt is not None else 0, float(qmin), float(qmax), out_kind,
+            _ffi.ptr(zt), ((_ffi.dt(zt) | z_flag) if zt is not None else 0) | fz, float(qmin), float(qmax), out_kind,
             _ffi.ptr(out), _ffi.stream()), 'llmc_quant_static')
         return out
 

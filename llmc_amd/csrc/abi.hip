@@ -8,6 +8,8 @@ namespace llmc {
 static thread_local char g_last_error[512] = "";
 static thread_local int g_helper_streams = 1;
 bool helper_streams_enabled() { return g_helper_streams != 0; }
+static thread_local int g_cu_reserve = 0;
+int cu_reserve() { return g_cu_reserve; }
 
 void set_last_error(const char* where, hipError_t e) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
@@ -48,6 +50,12 @@ int ensure_dynamic_lds(const void* fn, int bytes) {
 extern "C" int llmc_hip_set_helper_streams(int enable) {
     int prev = llmc::g_helper_streams;
     llmc::g_helper_streams = enable ? 1 : 0;
+    return prev;
+}
+
+extern "C" int llmc_hip_set_cu_reserve(int n_cus) {
+    int prev = llmc::g_cu_reserve;
+    llmc::g_cu_reserve = n_cus < 0 ? 0 : n_cus;
     return prev;
 }
 

@@ -43,6 +43,7 @@ void set_last_error_msg(const char* msg);
 static constexpr int LLMC_MAX_DEVICES = 64;
 int device_cu_count();                                  // CUs of the current device (256 on MI355X)
 int ensure_dynamic_lds(const void* fn, int bytes);
+int cu_reserve();                                       // llmc_hip_set_cu_reserve (per calling thread)
 bool helper_streams_enabled();                          // llmc_hip_set_helper_streams (per calling thread)      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
 
 static inline int dtype_size(int dt) { return dt == LLMC_F32 ? 4 : 2; }

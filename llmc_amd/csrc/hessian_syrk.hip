@@ -849,7 +849,10 @@ static int syrk_partials(const void* X, int dt, int64_t T, int64_t K, int64_t ld
     if (const char* e = getenv("LLMC_SYRK_KALIGN")) a.kalign = atoi(e) > 0 ? atoi(e) : SYRK_KALIGN;   // lab: 10 suits both rings
     if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
     if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
-    const int grid = device_cu_count();   // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous)
+    // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous), minus the CUs the caller keeps free for
+    // kernels of other streams (llmc_hip_set_cu_reserve): a k_syrk4 workgroup owns its CU, nothing co-resides with it
+    int grid = (device_cu_count() - cu_reserve()) & ~7;
+    if (grid < 8) grid = 8;
     // Kernel variant. Default k_syrk4 (one wave per SIMD, 128x128 wave tiles) with a 4-slot ring; LLMC_SYRK_V=5 its
     // 5-slot ring (all 160 KiB of LDS), =8 the 8-wave kernel, =2 its 4-stage ring, =88 its phase-split schedule.
     // All variants produce identical partial tiles for the same chunk alignment.

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W
     constexpr int WDT = dt_of<T>::value;
     // LLMC_SCALAR_QPARAM: a 0-dim operand keeps its own precision but does not take part in type promotion
     const int sd = sdt & 3, zd = zdt & 3;
+    const bool fz = (zdt & LLMC_FRACTIONAL_ZP) != 0;
     const int p1 = (sdt & LLMC_SCALAR_QPARAM) ? WDT : promote(WDT, sd);
     const int p2 = (zeros && !(zdt & LLMC_SCALAR_QPARAM)) ? promote(p1, zd) : p1;
     const int64_t nvec_row = g / VEC;
@@ -189,12 +190,15 @@ __global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W
         float am = 0.0f;   // bound of |x| over this thread's elements for the hoisted divisor (quant_math.h)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) am = fmaxf(am, fabsf(to_f32<T>(v.v[k])));
-        const Divisor dv = make_divisor(s, am);
+        // LLMC_FRACTIONAL_ZP (round_zp=False, quant.py:702-707): the divisor is s.clamp_min(1e-9) in the scale's dtype
+        const float sdiv = fz ? fmaxf(s, rnd(1e-9f, sd)) : s;
+        const Divisor dv = make_divisor(sdiv, am);
         if constexpr (KIND == LLMC_OUT_FAKE) {
             RowVec<T, VEC> o;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float q = quant_code(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax);
+                float q = fz ? quant_code_fz(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax)
+                             : quant_code(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax);
                 o.v[k] = from_f32<T>(dequant_code(q, s, z, p2));
             }
             store_vec<T, VEC>((T*)out + row * g + c, o);
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(kBlock) void k_quant_static(const T* __restrict__ W
             RowVec<C, VEC> o;
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
-                o.v[k] = (C)quant_code(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax);
+                o.v[k] = (C)(fz ? quant_code_fz(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax)
+                                : quant_code(to_f32<T>(v.v[k]), dv, z, p1, p2, qmin, qmax));
             C* op = (C*)out + row * g + c;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) op[k] = o.v[k];
@@ -595,7 +600,7 @@ static int quant_static_t(const void* W, int64_t G, int64_t g, const void* scale
 extern "C" int llmc_quant_static(const void* W, int wdt, int64_t G, int64_t g, const void* scales, int sdt,
                                  const void* zeros, int zdt, float qmin, float qmax, int out_kind,
                                  void* out, llmc_stream_t stream) {
-    LLMC_REQUIRE(dtype_ok(wdt) && dtype_ok(sdt & ~LLMC_SCALAR_QPARAM) && (!zeros || dtype_ok(zdt & ~LLMC_SCALAR_QPARAM)),
+    LLMC_REQUIRE(dtype_ok(wdt) && dtype_ok(sdt & ~LLMC_SCALAR_QPARAM) && (!zeros || dtype_ok(zdt & ~(LLMC_SCALAR_QPARAM | LLMC_FRACTIONAL_ZP))),
                  "quant_static: bad dtype");
     LLMC_REQUIRE(W && scales && out && G > 0 && g > 0, "quant_static: null/empty argument");
     hipStream_t st = (hipStream_t)stream;

@@ -87,6 +87,14 @@ __device__ __forceinline__ float quant_code(float x, const Divisor& d, float z, 
     t = rnd(t + z, p2);
     return fminf(fmaxf(t, qmin), qmax);
 }
+// quant, round_zp=False branch (quant.py:702-707): round(x / s.clamp_min(1e-9) + z); d is the divisor of the CLAMPED scale
+__device__ __forceinline__ float quant_code_fz(float x, const Divisor& d, float z, int p1, int p2, float qmin,
+                                               float qmax) {
+    float t = rnd(div_by(x, d), p1);
+    t = rnd(t + z, p2);
+    t = rintf(t);
+    return fminf(fmaxf(t, qmin), qmax);
+}
 // dequant (quant.py:709-712)
 __device__ __forceinline__ float dequant_code(float q, float s, float z, int p2) {
     float t = rnd(q - z, p2);

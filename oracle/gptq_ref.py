@@ -88,7 +88,8 @@ def _clib():
         here = os.path.dirname(os.path.abspath(__file__))
         so = os.path.join(here, '_build', 'liboracle_gptq.so')
         src = os.path.join(here, 'csrc', 'gptq_canon.c')
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        src2 = os.path.join(here, 'csrc', 'spqr_canon.c')
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2)):
             subprocess.check_call(['make', '-C', here, '-s'])
         _lib = ctypes.CDLL(so)
         _lib.gptq_weight_transform.restype = ctypes.c_int

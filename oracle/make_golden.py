@@ -735,6 +735,126 @@ def suite_e2e():
 
 
 
+def suite_e2e_spqr():
+    """The reference's SpQR class (ctor -> run_block_loop() -> deploy('fake_quant')) on the toy adapter, CPU."""
+    import torch.distributed as dist
+    from easydict import EasyDict
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from toy_model import ToyModel, calib_input
+    from llmc.compression.quantization.spqr import SpQR
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29594', rank=0, world_size=1)
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()
+    out = {}
+
+    def linears(model):
+        return {f'{i}.{n}': m for i, b in enumerate(model.get_blocks()) for n, m in b.named_modules()
+                if hasattr(m, 'weight') and m.weight is not None and m.weight.dim() == 2}
+
+    config = EasyDict(calib={'seq_len': 64}, model={'type': 'Toy'}, eval={})
+    model = ToyModel(hidden=128, inner=256, seed=3)
+    q2 = {'bit': 3, 'symmetric': False, 'granularity': 'per_group', 'group_size': 16, 'round_zp': False}
+    qc = EasyDict(weight={'bit': 4, 'symmetric': False, 'granularity': 'per_group', 'group_size': 16, 'round_zp': False},
+                  special={'actorder': True, 'percdamp': 1, 'blocksize': 128, 'true_sequential': True,
+                           'relative_threshold': 0.2, 'simplified_outliers': False, 'scale': dict(q2), 'zero': dict(q2)},
+                  quant_out=True, modality='language')
+    algo = SpQR(model, qc, calib_input(model), None, config)
+    algo.dev = torch.device('cpu')
+    algo.run_block_loop()
+    for n, m in linears(model).items():
+        out[f'w/{n}'] = f32(m.weight.data)
+        out[f'scales/{n}'] = f32(m.buf_scales).reshape(-1)
+        out[f'zeros/{n}'] = f32(m.buf_zeros).reshape(-1)
+        out[f'nout/{n}'] = np.int64(m.buf_mask.to_dense().sum().item())
+    algo.deploy('fake_quant')
+    for n, m in linears(model).items():
+        if n in ('0.gate_proj', '1.down_proj'):
+            out[f'fake/{n}'] = f32(m.weight.data)
+    save('e2e_spqr', **out)
+
+
+def suite_spqr():
+    """SpQR.add_batch / layer_transform (Hessian prep, weight_transform with leave-one-out outlier detection and the
+    second-level scale / zero quantizers) / set_model_qparams / w_qdq (spqr.py:116-380) on small seeded layers."""
+    import math
+    from llmc.compression.quantization.spqr import SpQR
+    out = {}
+    cfgs = [
+        # (name, bit, gs, actorder, percdamp, rel_threshold, simplified, dtype, R, K, dead)
+        ('g16_act_thr02', 4, 16, True, 1.0, 0.2, False, 'f16', 32, 256, True),
+        ('g32_noact_thr01', 3, 32, False, 0.01, 0.1, False, 'bf16', 24, 256, False),
+        ('g16_act_inf', 4, 16, True, 1.0, 'inf', False, 'f16', 16, 128, False),
+        ('g64_act_simplified', 4, 64, True, 1.0, 0.2, True, 'f16', 16, 256, False),
+    ]
+    gen = torch.Generator().manual_seed(77)
+    for (name, bit, gs, actorder, percdamp, thr, simplified, dt, R, K, dead) in cfgs:
+        sp = SpQR.__new__(SpQR)
+        sp.dev = torch.device('cpu')
+        sp.model_dtype = DT[dt]
+        sp.wquantizer = IntegerQuantizer(bit, False, 'per_group', group_size=gs, round_zp=False)
+        sp.actorder, sp.percdamp, sp.blocksize = actorder, percdamp, 128
+        sp.relative_threshold = math.inf if thr == 'inf' else thr
+        sp.simplified_outliers = simplified
+        if actorder:
+            sp.need_perm = True
+        qc = dict(bit=3, symmetric=False, granularity='per_group', group_size=16, round_zp=False)
+        sp.scale_quantizer = IntegerQuantizer(**qc)
+        sp.zero_quantizer = IntegerQuantizer(**qc)
+        sp.Q = IntegerQuantizer(bit, False, 'per_channel', round_zp=False)
+        sp.layers_cache = {}
+        layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+        layer.weight.data = rand_weight(gen, R, K, dt)
+        lname = 'fc'
+        sp.layers_cache[lname] = {}
+        sp.layer_init(layer, lname)
+        xs = []
+        for b in range(2):
+            x = torch.randn(1, 96, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))
+            x[..., 5] *= 30
+            if dead:
+                x[..., 17] = 0
+                x[..., 200] = 0
+            x = x.to(DT[dt])
+            xs.append(x)
+            sp.add_batch(layer, lname, x, None)
+        H = sp.layers_cache[lname]['H'].clone()
+        W0 = layer.weight.data.clone()
+        rec = {}
+        org_wt = sp.weight_transform
+
+        def wt(W, Hinv, Losses, tmp, mask):
+            rec['Wp'], rec['U'] = W.clone(), Hinv.clone()
+            org_wt(W, Hinv, Losses, tmp, mask)
+            rec['tmp'], rec['losses'], rec['mask'] = tmp.clone(), Losses.clone(), mask.clone()
+            rec['threshold'] = sp.relative_threshold * (rec['Wp'].var(dim=0) / torch.diag(Hinv).square()).mean().item()
+        sp.weight_transform = wt
+        sp.layer_transform(layer, lname)
+        wqdq = sp.w_qdq(layer, sp.wquantizer)
+        p = name + '/'
+        if name == 'g16_act_thr02':
+            out[p + 'x'] = np.stack([f32(x[0]) for x in xs])
+        out[p + 'H'] = f32(H)
+        out[p + 'W0'] = f32(W0)
+        out[p + 'perm'] = layer.buf_perm.numpy().astype(np.int64) if actorder else np.zeros(0, np.int64)
+        out[p + 'Wp'] = f32(rec['Wp'])
+        out[p + 'U'] = f32(rec['U'])
+        out[p + 'tmp'] = f32(rec['tmp'])
+        out[p + 'losses'] = f32(rec['losses'])
+        out[p + 'mask'] = rec['mask'].numpy().astype(np.uint8)
+        out[p + 'threshold'] = np.float64(rec['threshold'])
+        out[p + 'weight'] = f32(layer.weight.data)
+        out[p + 'buf_scales'] = f32(layer.buf_scales)
+        out[p + 'buf_zeros'] = f32(layer.buf_zeros)
+        out[p + 'buf_mask'] = layer.buf_mask.to_dense().numpy().astype(np.uint8)
+        out[p + 'w_qdq'] = f32(wqdq)
+        out[p + 'cfg'] = np.array([bit, gs, int(actorder), R, K, int(simplified)], np.int64)
+        out[p + 'percdamp'] = np.float64(percdamp)
+        out[p + 'rel_threshold'] = np.float64(math.inf if thr == 'inf' else thr)
+        print(name, 'outliers', int(rec['mask'].sum()), '/', rec['mask'].numel(), 'thr', rec['threshold'])
+    save('spqr', **out)
+
+
 def suite_mse():
     """calib_algo='mse' weight ranges (quant.py:145-203): the searched (min, max) per row/group and the qparams and
     fake-quantized weights that follow from them."""
@@ -770,7 +890,7 @@ def suite_mse():
     save('mse', **out)
 
 SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block}
+          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

@@ -28,18 +28,20 @@ class GPTQ: pass
 class Awq: pass
 @R
 class RTN: pass
+@R
+class SpQR: pass
 
 # ---- INTEGRATION.md section 1, verbatim ----
 import llmc_amd
 llmc_amd.register_into(R)
 # --------------------------------------------
 import llmc_amd.compression.quantization as Q
-for key in ('GPTQ', 'Awq', 'RTN'):
+for key in ('GPTQ', 'Awq', 'RTN', 'SpQR'):
     assert R[key] is getattr(Q, key), key          # llmc/__main__.py:62: ALGO_REGISTRY[config.quant.method]
     assert key in R
 # and the decorator protocol of the reference's Register accepts our classes too (a fresh registry)
 R2 = reg.Register()
-for key in ('GPTQ', 'Awq', 'RTN'):
+for key in ('GPTQ', 'Awq', 'RTN', 'SpQR'):
     assert R2(getattr(Q, key)) is getattr(Q, key)
 try:
     R2(Q.GPTQ)
@@ -62,4 +64,4 @@ def test_register_into_any_mapping_in_process():
     import llmc_amd.compression.quantization as Q
     d = {'GPTQ': object}
     bound = llmc_amd.register_into(d)
-    assert d['GPTQ'] is Q.GPTQ and d['Awq'] is Q.Awq and d['RTN'] is Q.RTN and set(bound) == {'GPTQ', 'Awq', 'RTN'}
+    assert d['GPTQ'] is Q.GPTQ and d['Awq'] is Q.Awq and d['RTN'] is Q.RTN and d['SpQR'] is Q.SpQR and set(bound) == {'GPTQ', 'Awq', 'RTN', 'SpQR'}

@@ -309,3 +309,39 @@ def test_gptq_owq_loop_bit_exact():
         np.testing.assert_array_equal(r['W'][:, nn_:].view(np.uint32), g[p + 'W_after'][:, nn_:].view(np.uint32), err_msg=name)
         if gs:
             np.testing.assert_array_equal(r['scales'].reshape(-1).view(np.uint32), g[p + 'buf_scales'].view(np.uint32), err_msg=name)
+
+
+def test_spqr_oracle_bit_exact_vs_reference():
+    """oracle/spqr_ref.py + csrc/spqr_canon.c against the reference's SpQR.layer_transform / w_qdq (spqr.py:116-380):
+    prep and threshold by tolerance (LAPACK / reduction order), the column loop — leave-one-out detection, second-level
+    qparams, mask, tmp, losses — and the deploy-time fake quantization bit for bit."""
+    from oracle import spqr_ref as S
+    g = load_golden('spqr')
+    names = sorted({k.split('/')[0] for k in g.files})
+    assert len(names) == 4
+    for n in names:
+        p = n + '/'
+        bit, gs, act, R, K, simp = [int(v) for v in g[p + 'cfg']]
+        dt = 'bf16' if n == 'g32_noact_thr01' else 'f16'
+        Wp, U, perm = S.process_hessian_and_weights(g[p + 'W0'], g[p + 'H'], bool(act), float(g[p + 'percdamp']))
+        np.testing.assert_array_equal(Wp, g[p + 'Wp'], err_msg=n)
+        if act:
+            np.testing.assert_array_equal(perm, g[p + 'perm'], err_msg=n)
+        assert np.abs(U - g[p + 'U']).max() <= 2e-6 * np.abs(g[p + 'U']).max(), n
+        thr = S.outlier_threshold(g[p + 'Wp'], g[p + 'U'], float(g[p + 'rel_threshold']))
+        ref_thr = float(g[p + 'threshold'])
+        assert (np.isinf(thr) and np.isinf(ref_thr)) or abs(thr - ref_thr) <= 1e-5 * ref_thr, n
+        o = S.weight_transform(g[p + 'Wp'], g[p + 'U'], bit, gs, ref_thr, bool(simp))
+        np.testing.assert_array_equal(o['mask'], g[p + 'mask'], err_msg=n)
+        np.testing.assert_array_equal(o['tmp'], g[p + 'tmp'], err_msg=n)
+        np.testing.assert_array_equal(o['losses'], g[p + 'losses'], err_msg=n)
+        np.testing.assert_array_equal(o['scales'].reshape(-1, 1), g[p + 'buf_scales'], err_msg=n)
+        np.testing.assert_array_equal(o['zeros'].reshape(-1, 1), g[p + 'buf_zeros'], err_msg=n)
+        wq = S.w_qdq(g[p + 'weight'], g[p + 'buf_mask'], g[p + 'buf_scales'], g[p + 'buf_zeros'], bit, gs, dt,
+                     g[p + 'perm'] if act else None)
+        np.testing.assert_array_equal(wq, g[p + 'w_qdq'], err_msg=n)
+    # the detection branch is exercised: it changes the qparams of some groups
+    p = 'g16_act_thr02/'
+    a = S.weight_transform(g[p + 'Wp'], g[p + 'U'], 4, 16, float(g[p + 'threshold']), False)
+    b = S.weight_transform(g[p + 'Wp'], g[p + 'U'], 4, 16, float(g[p + 'threshold']), True)
+    assert (a['scales'] != b['scales']).sum() > 0

@@ -1,9 +1,9 @@
 #!/bin/bash
 # GPTQ bench: subset schedules
 mkdir -p gpurun_out/m
-run() {  # name, env/args...
+run() {  # name, args...
   name=$1; shift
-  env $ENVV timeout 300 python bench.py --steps 3 --warmup 1 "$@" > gpurun_out/m/$name.json 2> gpurun_out/m/$name.err
+  timeout 120 python bench.py --steps 3 --warmup 1 "$@" > gpurun_out/m/$name.json 2> gpurun_out/m/$name.err
   python - "$name" <<'PY'
 import json, sys
 f = sys.argv[1]
@@ -12,6 +12,6 @@ try:
 except Exception as e: print(f, 'fail', e)
 PY
 }
-ENVV="X=1" run chain_prio
-ENVV="LLMC_BENCH_PRIO=0" run chain_noprio
-ENVV="X=1" run k1first --order k1first
+run shadow32h --order shadow --reserve 32 --wide-helper 1
+run shadow0h --order shadow --reserve 0 --wide-helper 1
+run shadow32 --order shadow --reserve 32 --wide-helper 0
