@@ -387,7 +387,7 @@ def test_hessian_prep_vs_oracle():
     assert Hd.cpu().numpy()[dead, dead].tolist() == [1.0, 1.0]           # in-place dead fix like the reference
 
 
-@pytest.mark.parametrize('K', [14336, 2560])
+@pytest.mark.parametrize('K', [14336, 2560, 2432])
 def test_chol_inv_upper_large_property(K):
     """Uneven doubling levels (14336 = 7 * 2048): U H U^T = I in fp32 on the GPU."""
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
