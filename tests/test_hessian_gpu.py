@@ -87,3 +87,23 @@ def test_llama_k4096_chunked_and_deterministic(dt):
         acc3.add(xd[i])
     e_3 = ((acc3.H.double() - ref).abs() / d).max().item()
     assert e_3 <= max(4 * e_t, 2e-6), (e_3, e_t)
+
+
+def test_cu_reserve_leaves_compute_units_free_and_changes_no_bit():
+    """llmc_hip_set_cu_reserve: the persistent Hessian kernel launches on fewer compute units (the caller keeps the rest
+    for kernels of other streams); chunking does not depend on the grid, so H is bit-identical. The setter is per
+    thread and returns the previous value."""
+    from llmc_amd import _ffi
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    x = make_x(3000, 1024, 'bf16', 3).cuda()
+    a = HessianAccumulator(1024, 'cuda')
+    a.add(x)
+    h0 = a.H.clone()
+    assert _ffi.lib().llmc_hip_set_cu_reserve(0) == 0
+    with _ffi.cu_reserve(64):
+        b = HessianAccumulator(1024, 'cuda')
+        b.add(x)
+        h1 = b.H.clone()
+        assert _ffi.lib().llmc_hip_set_cu_reserve(64) == 64
+    assert _ffi.lib().llmc_hip_set_cu_reserve(0) == 0
+    assert torch.equal(h0, h1)
