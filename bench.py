@@ -163,6 +163,36 @@ def cpu_baseline_reference(model, n_seq, seq):
     }
 
 
+def cpu_baseline_reference_awq(groups, N):
+    """The reference's own AWQ grid step (oracle/ref_baseline.py --workload awq: Awq.get_scales / fake_quantize_weight /
+    inspect_module_forward / calculate_loss of oracle/_ref) on two token counts of one 4096 x 4096 layer: t = a + b * tokens
+    separates the per-weight work from the per-token work; a block = 4 searches of 21 evaluations, scaled by R * K."""
+    script = os.path.join(ROOT, 'oracle', 'ref_baseline.py')
+    if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'llmc')):
+        raise RuntimeError('oracle/_ref missing (built by __graft_entry__.build() where /root/reference exists)')
+    K0, ts = 4096, {}
+    thr = min(os.cpu_count() or 1, 32)      # 256 threads: 3.4 s per step whatever the token count (thread overhead); 16-32 suit these ops
+    for tok in (2048, 4096):
+        r = subprocess.run([sys.executable, script, '--workload', 'awq', '--K', str(K0), '--tokens', str(tok), '--threads', str(thr)],
+                           capture_output=True, text=True, timeout=200)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode != 0 or not line:
+            raise RuntimeError('reference AWQ baseline failed: ' + (r.stderr or r.stdout)[-300:])
+        ts[tok] = json.loads(line[-1])
+    b = max(0.0, (ts[4096]['t_grid_step'] - ts[2048]['t_grid_step']) / 2048)
+    a = max(0.0, ts[2048]['t_grid_step'] - b * 2048)
+    t_block, layers = 0.0, 0
+    for _, K, ls in groups:
+        rk = sum(r for _, r in ls) * K / (K0 * K0)
+        t_block += 21 * (a + b * N) * rk
+        layers += len(ls)
+    return {'value': layers / t_block, 'unit': 'layers/s', 'cores': ts[2048]['threads'], 'kind': 'reference',
+            'sample': (f"llmc's own Awq methods (oracle/_ref), torch CPU, {ts[2048]['threads']} threads: 3 grid steps (get_scales, x / s, "
+                       f"fake_quantize_weight, F.linear through inspect_module_forward, calculate_loss, state-dict restore) of one "
+                       f"{K0}x{K0} layer on 2048 and 4096 tokens ({ts[2048]['t_grid_step']:.2f} s and {ts[4096]['t_grid_step']:.2f} s per "
+                       f'step); linear in tokens and in R*K to {N} tokens and the 4 stacked subsets, 21 evaluations per search')}
+
+
 def cpu_baseline_port(model, n_seq, seq, cfg):
     """Fallback: the oracle (a CPU port of the reference path) timed on the host cores on a bounded sample."""
     import numpy as np
@@ -361,6 +391,13 @@ def run_awq(args):
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_ev)
     if rank == 0:
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline_reference_awq(groups, N)
+            except Exception as e:
+                cpu = {'value': None, 'unit': 'layers/s', 'cores': os.cpu_count(), 'kind': 'reference',
+                       'sample': f'failed: {type(e).__name__}: {str(e)[:160]}'}
         print(json.dumps({
             'metric': 'layers/sec (AWQ W4A16 g128 scale search + fake-quant eval, %s Linear shapes, 128x512 calib)' % args.model,
             'value': n_layers * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
@@ -374,6 +411,7 @@ def run_awq(args):
                          'kernel': 'k_linear_eval4 (llmc_linear_eval_kt, the 21 products of a search; k_linear_eval when K % 128 != 0)', 'launches': len(gemm_ev),
                          'algorithmic_flops_per_launch': fl / max(1, len(gemm_ev)), 'avg_launch_ms': ms / max(1, len(gemm_ev)),
                          'whole_search_tflops': 21 * fl_eval * args.steps / dt / 1e12},
+            'cpu_baseline': cpu,
         }), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -22,7 +22,11 @@ def main():
     ap.add_argument('--seq', type=int, default=2048)
     ap.add_argument('--batches', type=int, default=4)
     ap.add_argument('--threads', type=int, default=0)
+    ap.add_argument('--workload', default='gptq')
+    ap.add_argument('--tokens', type=int, default=2048)
     a = ap.parse_args()
+    if a.workload == 'awq':
+        return main_awq(a)
     import torch
     import torch.distributed as dist
     # the Hessian GEMM scales with the cores; the factorisations and the column loop (thousands of small ATen ops) get
@@ -75,6 +79,42 @@ def main():
     print(json.dumps({'K': K, 'seq': a.seq, 'batches': a.batches, 'threads': cores, 'threads_small_ops': small, 't_hessian_per_seq': t_h,
                       't_factor': t_c, 't_loop': t_l, 'blas': torch.__config__.parallel_info().split('\n')[0:3],
                       'finite': bool(torch.isfinite(tmp).all())}), flush=True)
+
+
+def main_awq(a):
+    """The reference's AWQ grid step (awq.py:229-236) through its own methods, inspect = the Linear itself: per ratio
+    get_scales -> scaling_input -> fake_quantize_weight -> inspect_module_forward -> calculate_loss, plus the state-dict
+    restore the reference does per step, on `--tokens` tokens of one K x K layer."""
+    import copy
+    import torch
+    cores = a.threads or os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    from llmc.compression.quantization.awq import Awq
+    from llmc.compression.quantization.quant import IntegerQuantizer
+    K = a.K
+    aw = Awq.__new__(Awq)
+    aw.wquantizer = IntegerQuantizer(4, True, 'per_group', group_size=128)
+    aw.trans_version = 'v2'
+    aw._bs = 1
+    gen = torch.Generator().manual_seed(0)
+    fc = torch.nn.Linear(K, K, bias=False).to(torch.bfloat16)
+    fc.weight.data = (torch.randn(K, K, generator=gen) * 0.02).to(torch.bfloat16)
+    x = (torch.randn(1, a.tokens, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(torch.bfloat16)
+    w_max = aw.get_weight_scale({'fc': fc})
+    org_sd = {k: v.clone() for k, v in fc.state_dict().items()}
+    org_out = aw.get_original_out(x, fc, {})
+    n_grid = 3                                   # of 20: every step does the same work
+    t0 = time.perf_counter()
+    for n in range(n_grid):
+        ratio = n / 20
+        scales = aw.get_scales(None, x, w_max, False, ratio)
+        xs = x / scales.view(1, -1)              # scaling_input (base_blockwise_quantization.py:877-889)
+        aw.fake_quantize_weight(fc, scales, False, 'fc')
+        out = aw.inspect_module_forward(xs, fc, {})
+        loss = aw.calculate_loss(org_out, out)
+        fc.load_state_dict(org_sd)
+    t_step = (time.perf_counter() - t0) / n_grid
+    print(json.dumps({'K': K, 'tokens': a.tokens, 'threads': cores, 't_grid_step': t_step, 'loss': loss}), flush=True)
 
 
 if __name__ == '__main__':
