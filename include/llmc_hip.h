@@ -81,6 +81,14 @@ int llmc_minmax_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, in
                         float qmin, float qmax, void* scales, void* zeros, void* ws,
                         llmc_stream_t stream);
 
+/* calib_algo 'static_hist', data pass (quant.py:462-512): torch.histc(sample.float(), bins, min, max) -> out fp32 [bins]
+ * counts; bin = int((x - min) * bins / (max - min)) in fp32, the right edge belongs to the last bin, values outside the
+ * range are dropped, min == max widens the range by one on both sides (ATen). ws: llmc_histc_ws_bytes(bins). The merge
+ * of the per-sample histograms and the range search (quant.py:279-460) work on `bins` numbers and stay host code. */
+size_t llmc_histc_ws_bytes(int bins);
+int llmc_histc(const void* x, int dt, int64_t n, int bins, float min, float max, float* out, void* ws,
+               llmc_stream_t stream);
+
 /* calib_algo 'mse': BaseQuantizer.get_mse_range (quant.py:145-203) followed by get_qparams (:545-559) on a [G, g]
  * view. The reference casts the tensor to fp32 first, so ranges and qparams are fp32 whatever `dt` is:
  * scales / zeros / min_out / max_out are fp32 [G] (zeros may be NULL when sym, min_out / max_out may be NULL).

@@ -263,9 +263,16 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             # quant.py:253-263: mean over samples of per-sample min / max (fp32), then get_qparams on the means
             mx = torch.stack([s.max().float() for s in samples]).mean()
             mn = torch.stack([s.min().float() for s in samples]).mean()
+        elif algo == 'static_hist':
+            # quant.py:462-512 (+ get_batch_tensors_qparams' assert, :564-568): histogram-observer range, data pass in HIP
+            assert aq.sym is True and aq.granularity == 'per_tensor', \
+                'Only support per tensor static symmetric int quantize.'
+            from .hist_range import static_hist_range
+            lo, hi = static_hist_range(samples, aq.bins, aq.upsample_rate, aq.bit)
+            mn = torch.tensor(lo, dtype=torch.float32, device=samples[0].device)
+            mx = torch.tensor(hi, dtype=torch.float32, device=samples[0].device)
         else:
-            raise NotImplementedError(f'static activation calibration {algo}: static_minmax and static_moving_minmax '
-                                      'are on the accelerated path (static_hist is not)')
+            raise NotImplementedError(f'static activation calibration {algo}')
         qmax, qmin = aq.qmax.to(mx.device), aq.qmin.to(mx.device)
         abs_max = torch.max(mx.abs(), mn.abs()).clamp(min=1e-5)
         if aq.sym:

@@ -29,9 +29,12 @@ class BaseQuantizer(object):
         self.kwargs = kwargs
 
         self.calib_algo = self.kwargs.get('calib_algo', 'minmax')
-        if self.calib_algo not in ('minmax', 'static_minmax', 'static_moving_minmax', 'mse'):
+        if self.calib_algo not in ('minmax', 'static_minmax', 'static_moving_minmax', 'static_hist', 'mse'):
             raise NotImplementedError(
-                f'calib_algo={self.calib_algo}: only minmax and mse ranges are on the accelerated path')
+                f'calib_algo={self.calib_algo}: learnable / hqq ranges are outside the hot path')
+        # hist config (quant.py:81-86)
+        self.bins = self.kwargs.get('bins', 2048)
+        self.upsample_rate = self.kwargs.get('upsample_rate', 16)
         # mse config (quant.py:78-81)
         self.mse_b_num = self.kwargs.get('mse_b_num', 1)
         self.maxshrink = self.kwargs.get('maxshrink', 0.8)

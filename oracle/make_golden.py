@@ -774,6 +774,41 @@ def suite_e2e_spqr():
     save('e2e_spqr', **out)
 
 
+def suite_hist():
+    """IntegerQuantizer(calib_algo='static_hist').get_static_hist_range + get_qparams (quant.py:462-512, 545-559)."""
+    out = {}
+    gen = torch.Generator().manual_seed(11)
+    cases = {
+        'growing': [torch.randn(1, 64, 256, generator=gen) * (1 + i) for i in range(4)],          # range grows: re-binning
+        'outlier_tail': [torch.cat([torch.randn(1, 128, 128, generator=gen), torch.tensor([[[40.0] * 128]])], 1) for _ in range(3)],
+        'same_range': [torch.randn(1, 32, 64, generator=gen).clamp(-2, 2).index_put((torch.tensor([0]), torch.tensor([0]), torch.tensor([0, 1])), torch.tensor([-2.0, 2.0])) for _ in range(3)],
+        'skewed': [torch.rand(1, 200, 100, generator=gen) ** 4 * 9 - 0.5 for _ in range(2)],
+    }
+    for name, acts in cases.items():
+        for dt in ('bf16',):
+            q = IntegerQuantizer(8, True, 'per_tensor', calib_algo='static_hist')
+            xs = [a.to(DT[dt]) for a in acts]
+            rec = {}
+            org = q.get_hist_threshold
+
+            def thr(h, mn, mx):
+                rec['hist'], rec['min'], rec['max'] = h.clone(), mn.clone(), mx.clone()
+                return org(h, mn, mx)
+            q.get_hist_threshold = thr
+            mins, maxs = q.get_static_hist_range(list(xs))
+            sl, zl, _, _ = IntegerQuantizer(8, True, 'per_tensor', calib_algo='static_hist').get_batch_tensors_qparams(list(xs))
+            p = f'{name}/'
+            out[p + 'x'] = np.stack([f32(x[0]) for x in xs])
+            out[p + 'hist'] = f32(rec['hist'])
+            out[p + 'min'] = f32(rec['min'])
+            out[p + 'max'] = f32(rec['max'])
+            out[p + 'new_min'] = f32(mins[0])
+            out[p + 'new_max'] = f32(maxs[0])
+            out[p + 'scale'] = f32(sl[0])
+            print(name, float(rec['min']), float(rec['max']), '->', float(mins[0]), float(maxs[0]))
+    save('hist', **out)
+
+
 def suite_spqr():
     """SpQR.add_batch / layer_transform (Hessian prep, weight_transform with leave-one-out outlier detection and the
     second-level scale / zero quantizers) / set_model_qparams / w_qdq (spqr.py:116-380) on small seeded layers."""
@@ -890,7 +925,7 @@ def suite_mse():
     save('mse', **out)
 
 SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr}
+          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

@@ -345,3 +345,32 @@ def test_spqr_oracle_bit_exact_vs_reference():
     a = S.weight_transform(g[p + 'Wp'], g[p + 'U'], 4, 16, float(g[p + 'threshold']), False)
     b = S.weight_transform(g[p + 'Wp'], g[p + 'U'], 4, 16, float(g[p + 'threshold']), True)
     assert (a['scales'] != b['scales']).sum() > 0
+
+
+def test_static_hist_oracle_and_host_search_bit_exact_vs_reference():
+    """calib_algo static_hist (quant.py:264-512): the oracle (oracle/hist_ref.py) reproduces the reference's merged
+    histograms bin for bin (incl. the re-binning when the range grows) and its searched range exactly; the product's host
+    search (llmc_amd/.../hist_range.py, whose data pass is llmc_histc on the GPU) gives the same range from the same
+    histogram."""
+    from llmc_amd.compression.quantization.hist_range import HistRange
+    from oracle import hist_ref as Hs
+    g = load_golden('hist')
+    names = sorted({k.split('/')[0] for k in g.files})
+    assert len(names) == 4
+    for n in names:
+        p = n + '/'
+        a, b, hist, mn, mx, _, _ = Hs.static_hist_range(list(g[p + 'x']), 'bf16')
+        np.testing.assert_array_equal(hist, g[p + 'hist'], err_msg=n)
+        assert mn == g[p + 'min'] and mx == g[p + 'max'], n
+        assert a == g[p + 'new_min'] and b == g[p + 'new_max'], (n, a, b)
+        h = HistRange(2048, 16, 256)
+        h.hist, h.lo, h.hi = g[p + 'hist'].copy(), np.float32(g[p + 'min']), np.float32(g[p + 'max'])
+        lo, hi = h.range()
+        assert lo == g[p + 'new_min'] and hi == g[p + 'new_max'], (n, lo, hi)
+    # the re-binning of the product against the oracle's on the case whose range grows with every sample
+    p = 'growing/'
+    xs = list(g[p + 'x'])
+    h = HistRange(2048, 16, 256)
+    h.hist, h.lo, h.hi = Hs.histc(xs[0], 2048, xs[0].min(), xs[0].max()), np.float32(xs[0].min()), np.float32(xs[0].max())
+    lo, hi = min(h.lo, np.float32(xs[1].min())), max(h.hi, np.float32(xs[1].max()))
+    np.testing.assert_array_equal(h._rebin(lo, hi), Hs.upscale_histogram(h.hist, h.lo, h.hi, lo, hi))

@@ -226,3 +226,60 @@ def test_per_tensor_asymmetric_qparams_are_fp32_like_the_reference():
         np.testing.assert_array_equal(codes.cpu().numpy().astype(np.int32), g[p + 'codes'], err_msg=str(ci))
         np.testing.assert_array_equal(rs.float().reshape(-1).cpu().numpy().view(np.uint32), g[p + 'rscales'].view(np.uint32))
         np.testing.assert_array_equal(rz.reshape(-1).cpu().numpy().astype(np.int32), g[p + 'rzeros'])
+
+
+def test_static_hist_range_matches_reference_golden():
+    """llmc_histc (torch.histc's binning) bit-exact against the oracle on awkward ranges, and the whole static_hist
+    calibration (data pass on the GPU + host search) equal to the reference's range on the goldens."""
+    from llmc_amd.compression.quantization.hist_range import HistRange, static_hist_range
+    from oracle import hist_ref as Hs
+    g = load_golden('hist')
+    rs = np.random.RandomState(0)
+    for dt, n in ((torch.bfloat16, 1000003), (torch.float16, 4099), (torch.float32, 77777)):
+        x = torch.from_numpy((rs.randn(n) * 3).astype(np.float32)).to(dt).cuda()
+        xf = x.float().cpu().numpy()
+        for lo, hi in ((float(xf.min()), float(xf.max())), (-1.7, 2.9), (0.25, 0.25)):
+            got = HistRange(2048)._histc(x, lo, hi)
+            np.testing.assert_array_equal(got, Hs.histc(xf, 2048, lo, hi))
+    for name in sorted({k.split('/')[0] for k in g.files}):
+        p = name + '/'
+        xs = [torch.from_numpy(s).to(torch.bfloat16).cuda() for s in g[p + 'x']]
+        h = HistRange(2048, 16, 256)
+        for s in xs:
+            h.add(s)
+        np.testing.assert_array_equal(h.hist, g[p + 'hist'], err_msg=name)
+        lo, hi = static_hist_range(xs)
+        assert np.float32(lo) == g[p + 'new_min'] and np.float32(hi) == g[p + 'new_max'], (name, lo, hi)
+        # get_qparams on the searched range (quant.py:545-553): the scale the reference registers
+        s_ref = float(g[p + 'scale'])
+        s = max(abs(lo), abs(hi)) / 127.0
+        assert abs(np.float32(s) - np.float32(s_ref)) <= 1e-7 * abs(s_ref), name
+
+
+@pytest.mark.parametrize('algo', ['static_hist', 'static_minmax', 'static_moving_minmax'])
+def test_register_act_qparams_all_static_calibrations(algo):
+    """BaseBlockwiseQuantization.register_act_qparams (base_blockwise_quantization.py:567-588) for the three calibrations
+    get_batch_tensors_qparams accepts (quant.py:561-574); static_hist against the reference's scale (goldens), the others
+    against their definitions (mean of per-sample extrema; exponential moving average with alpha = 0.01)."""
+    from llmc_amd.compression.quantization.base_blockwise_quantization import BaseBlockwiseQuantization
+    from llmc_amd.compression.quantization.quant import IntegerQuantizer
+    g = load_golden('hist')
+    p = 'growing/'
+    xs = [torch.from_numpy(s).to(torch.bfloat16).cuda().unsqueeze(0) for s in g[p + 'x']]
+    obj = BaseBlockwiseQuantization.__new__(BaseBlockwiseQuantization)
+    obj.aquantizer = IntegerQuantizer(8, True, 'per_tensor', calib_algo=algo)
+    layer = torch.nn.Linear(4, 4).cuda()
+    obj.register_act_qparams({'fc': layer}, list(xs))
+    s = float(layer.buf_act_scales_0)
+    mx = [float(x.max()) for x in xs]
+    mn = [float(x.min()) for x in xs]
+    if algo == 'static_hist':
+        assert abs(s - float(g[p + 'scale'])) <= 1e-6 * float(g[p + 'scale'])
+    elif algo == 'static_minmax':
+        assert abs(s - max(abs(np.mean(mx)), abs(np.mean(mn))) / 127) <= 1e-3 * s
+    else:
+        a = b = None
+        for lo, hi in zip(mn, mx):
+            a, b = (lo, hi) if a is None else (a + 0.01 * (lo - a), b + 0.01 * (hi - b))
+        assert abs(s - max(abs(a), abs(b)) / 127) <= 1e-2 * s
+    assert float(layer.buf_act_qmax_0) == 127 and float(layer.buf_act_zeros_0) == 0
