@@ -40,7 +40,8 @@ def test_column_loop_bit_exact_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize('gs,R,K,simp,thr', [(16, 200, 512, False, 0.05), (128, 70, 384, False, 0.02),
-                                             (32, 33, 256, True, 0.1), (64, 48, 256, False, math.inf)])
+                                             (32, 33, 256, True, 0.1), (64, 48, 256, False, math.inf),
+                                             (16, 1000, 1536, False, 0.1)])
 def test_column_loop_bit_exact_vs_oracle_random(gs, R, K, simp, thr):
     """Sizes with ragged row counts, several blocks and all group sizes; many detected outliers (small thresholds)."""
     from llmc_amd.compression.quantization.spqr import SpqrConfig, spqr_quantize
