@@ -35,7 +35,6 @@ struct LinArgs {
     // the CUs that share an L2 share sbm + sbn operand panels instead of ~gridDim/8 + 1; blocks are numbered tn-fastest
     int sbm, sbn, nsn, nrounds;
     int yblk;         // k_linear_eval4: Y (mode 0) / Y0 (mode 1) is tile-blocked in fragment order (LLMC_LINEAR_YBLOCKED)
-    int lab_nob;      // lab (LLMC_LIN_ABL=4): B fragments are not re-read from LDS
     int y0_lds;       // k_linear_eval4, mode 1: Y0 tiles are staged through LDS (R % 8 == 0, Y0 16-B aligned, < 4 GiB)
 };
 
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             constexpr int f = decltype(fc)::value;
             constexpr int IMM = (SL & 1) * L4_STAGE;
             if constexpr (f == 0) fa[0] = *(LDS_AS s16x8*)(lds + offA[SL >> 1][KK][0] + IMM);
-            else if constexpr (f <= 4) { if (!a.lab_nob) fb[f - 1] = *(LDS_AS s16x8*)(lds + offB[SL >> 1][KK][f - 1] + IMM); }
+            else if constexpr (f <= 4) fb[f - 1] = *(LDS_AS s16x8*)(lds + offB[SL >> 1][KK][f - 1] + IMM);
             else fa[f - 4] = *(LDS_AS s16x8*)(lds + offA[SL >> 1][KK][f - 4] + IMM);
         };
         // Y0 tile piece I (0..31) of this wave. Row-major Y0: rows 2 * (wv + 4 I), + 1 (512 B each) -> LDS
@@ -595,7 +594,6 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
     lin_tile_order(a, 256);
     a.y0_lds = 0;
     a.yblk = 0;
-    a.lab_nob = 0;
     if (dt == LLMC_BF16) {
         if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_BF16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_BF16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
@@ -656,13 +654,11 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     LLMC_REQUIRE(grid >= 8, "linear_eval_kt: device has fewer than 8 compute units");
     lin_tile_order(a, grid);
     a.yblk = yblk;
-    a.lab_nob = 0;
     a.y0_lds = mode == 1 && !yblk && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
     int stage = mode == 1 ? (yblk ? 2 : a.y0_lds ? 1 : 0) : 0;
     if (const char* e = getenv("LLMC_LIN_ABL")) {   // lab switches, never set by the package
         const int v = atoi(e);
-        if (v == 1 || v == 4) { a.mode = 2; a.y0_lds = 0; stage = 0; }      // main loop only
-        if (v == 4) a.lab_nob = 1;
+        if (v == 1) { a.mode = 2; a.y0_lds = 0; stage = 0; }      // main loop only
         if (v == 2 && stage == 1) { a.y0_lds = 0; stage = 0; }    // row-major Y0 straight from global
         if (v == 3 && stage) a.y0_lds = 2;                        // Y0 staged and waited for, not folded
     }

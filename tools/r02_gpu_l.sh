@@ -13,3 +13,4 @@ PY
 }
 run mainloop LLMC_LIN_ABL=1
 run mainloop_noBreads LLMC_LIN_ABL=4
+run mainloop_constBreads LLMC_LIN_ABL=5
