@@ -391,6 +391,14 @@ def run_awq(args):
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_ev)
     if rank == 0:
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        awq_traffic = awq_traffic_src = None
+        tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_awq.json')
+        if args.model == 'llama3-8b' and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))['k_linear_eval4']
+                awq_traffic, awq_traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic_awq.json (' + tj['note'] + ')'
+            except Exception:
+                pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -407,7 +415,7 @@ def run_awq(args):
                                    f'{args.model}-shaped random-init layers, 1 block (7 Linear, 4 subsets) per step per GPU',
                        'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                         'frac': ach * 1e12 / PEAK_MFMA_16BIT, 'traffic': None,
+                         'frac': ach * 1e12 / PEAK_MFMA_16BIT, 'traffic': awq_traffic, 'traffic_source': awq_traffic_src,
                          'kernel': 'k_linear_eval4 (llmc_linear_eval_kt, the 21 products of a search; k_linear_eval when K % 128 != 0)', 'launches': len(gemm_ev),
                          'algorithmic_flops_per_launch': fl / max(1, len(gemm_ev)), 'avg_launch_ms': ms / max(1, len(gemm_ev)),
                          'whole_search_tflops': 21 * fl_eval * args.steps / dt / 1e12},
