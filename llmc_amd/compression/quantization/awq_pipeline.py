@@ -38,27 +38,39 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
-    # K % 128 == 0: the 21 products run on the k-tiled GEMM (llmc_linear_eval_kt), operands re-laid by llmc_ktile_pack
-    kt = awq_ops.ktile_supported(x2, wcat) and os.environ.get('LLMC_AWQ_KT', '1') != '0'   # 0: diagnostic, row-major GEMM
-    xa, wa = (awq_ops.ktile_pack(x2), awq_ops.ktile_pack(wcat)) if kt else (x2, wcat)
-    e0 = _ev() if timing is not None else None
-    org_out = awq_ops.linear_out(xa, wa, tiled=kt, blocked=kt)     # get_original_out (awq.py:128-132)
+    # K % 128 == 0: the 21 products run on the k-tiled GEMM (llmc_linear_eval_kt), operands re-laid by llmc_ktile_pack.
+    # The output rows are walked in chunks whose [N, R_c] reference output stays below the GEMM's 4-GiB offset range
+    # (70B-class gate|up stacks at 65 536 tokens): the loss is a sum over outputs, so chunk sums add up.
+    kt_ok = x2.is_cuda and awq_ops.ktile_supported(x2, wcat[:min(R, 256)]) and os.environ.get('LLMC_AWQ_KT', '1') != '0'
+    lim = int(os.environ.get('LLMC_AWQ_Y_BYTES', str((1 << 32) - (1 << 20))))      # test hook: smaller chunks
+    rc = max(256, (lim // (2 * max(N, K))) // 256 * 256)
+    chunks = [(r0, min(R, r0 + rc)) for r0 in range(0, R, rc)] if kt_ok else [(0, R)]
+    kt = kt_ok and all(awq_ops.ktile_supported(x2, wcat[r0:r1]) for r0, r1 in chunks)
+    if not kt:
+        chunks = [(0, R)]
+    xa = awq_ops.ktile_pack(x2) if kt else x2
+    org_out = []
+    for r0, r1 in chunks:                               # get_original_out (awq.py:128-132)
+        wa = awq_ops.ktile_pack(wcat[r0:r1]) if kt else wcat[r0:r1]
+        e0 = _ev() if timing is not None else None
+        org_out.append(awq_ops.linear_out(xa, wa, tiled=kt, blocked=kt))
+        if timing is not None:
+            timing.append((e0, _ev(), 2.0 * N * (r1 - r0) * K))
     del xa, wa
-    if timing is not None:
-        timing.append((e0, _ev(), 2.0 * N * R * K))
     losses = torch.zeros(n_grid, dtype=torch.float32, device=x.device)
     scales_all = []
     for n in range(n_grid):
         ratio = n * 1 / n_grid
         s = awq_ops.awq_scales(x_mean, w_max, ratio, trans_version)
-        wq = awq_ops.scale_fakequant(wcat, s, wquantizer)
         xs = awq_ops.div_cols(x2, s, tiled=kt)
-        if kt:
-            wq = awq_ops.ktile_pack(wq)
-        e0 = _ev() if timing is not None else None
-        awq_ops.linear_loss_sum(xs, wq, org_out, losses[n:n + 1], tiled=kt, y0_blocked=kt)
-        if timing is not None:
-            timing.append((e0, _ev(), 2.0 * N * R * K))
+        for ci, (r0, r1) in enumerate(chunks):
+            wq = awq_ops.scale_fakequant(wcat[r0:r1], s, wquantizer)
+            if kt:
+                wq = awq_ops.ktile_pack(wq)
+            e0 = _ev() if timing is not None else None
+            awq_ops.linear_loss_sum(xs, wq, org_out[ci], losses[n:n + 1], tiled=kt, y0_blocked=kt)
+            if timing is not None:
+                timing.append((e0, _ev(), 2.0 * N * (r1 - r0) * K))
         scales_all.append(s)
     losses /= float(N * R)                               # .pow(2).mean() (awq.py:136)
     best = int(torch.argmin(losses).item())              # strict '<' keeps the first minimum (awq.py:245)

@@ -321,3 +321,21 @@ def test_fake_quant_linear_forward_runs_on_the_hip_gemm(dt, bias, monkeypatch):
     lin2 = torch.nn.Linear(100, 16, bias=False).to(TD[dt]).cuda()
     m2 = EffcientFakeQuantLinear.new(lin2, lambda m: m.weight.data, None)
     assert m2(torch.randn(2, 100).to(TD[dt]).cuda()).shape == (2, 16) and len(calls) == 2
+
+
+def test_search_in_output_row_chunks_matches_unchunked(monkeypatch):
+    """The search walks the stacked output rows in chunks when the [N, R] reference output would leave the k-tiled GEMM's
+    4-GiB offset range (70B-class gate|up at 65 536 tokens); forced small here: same losses, same argmin, same scales."""
+    from llmc_amd.compression.quantization.awq_pipeline import search_scale_stacked
+    from llmc_amd.compression.quantization.quant import IntegerQuantizer
+    gen = torch.Generator().manual_seed(9)
+    N, K = 1536, 512
+    x = (torch.randn(N, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(torch.bfloat16).cuda()
+    ws = [(torch.randn(r, K, generator=gen) * 0.03).to(torch.bfloat16).cuda() for r in (512, 256, 300)]
+    wq = IntegerQuantizer(4, True, 'per_group', group_size=128)
+    monkeypatch.delenv('LLMC_AWQ_Y_BYTES', raising=False)
+    s0, l0, b0 = search_scale_stacked(ws, x, wq, 'v2', return_losses=True)
+    monkeypatch.setenv('LLMC_AWQ_Y_BYTES', str(2 * N * 512))          # 512 output rows per chunk -> 3 chunks
+    s1, l1, b1 = search_scale_stacked(ws, x, wq, 'v2', return_losses=True)
+    assert b0 == b1 and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5)
