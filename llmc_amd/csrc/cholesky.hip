@@ -294,6 +294,16 @@ __global__ __launch_bounds__(256, 2) void k_potrf_inv(float* __restrict__ W, int
 }
 #undef PBLK
 
+// gemm6 skips the zero part of a triangular operand at 256 granularity: the 128 x 128 block below the diagonal inside
+// every 256-aligned diagonal tile must really be zero (nothing else reads that part of the work matrix)
+__global__ __launch_bounds__(256) void k_zero_subdiag(float* __restrict__ W, int64_t ld, int K) {
+    const int r0 = blockIdx.x * 256 + 128, c0 = blockIdx.x * 256;
+    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+        const int i = r0 + (e >> 7), j = c0 + (e & 127);
+        if (i < K && j < K) W[(int64_t)i * ld + j] = 0.0f;
+    }
+}
+
 // copy the inverted diagonal blocks into the work matrix (upper), before the doubling levels
 __global__ __launch_bounds__(256) void k_place_diag_inv(float* __restrict__ W, int64_t ld, int K,
                                                         const float* __restrict__ Vbuf) {
@@ -494,12 +504,24 @@ extern "C" int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, in
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// doubling levels of the triangular inverse from this block size on run on the one-wave-per-SIMD GEMM (gemm6_launch)
+static constexpr int64_t GEMM6_MIN_H = 4096;
+static size_t gemm6_bytes(int64_t K) {
+    size_t mx = 0;
+    for (int64_t h = NB; h < K; h *= 2)
+        if (h >= GEMM6_MIN_H) {
+            const size_t b = gemm6_ws_bytes((int)h, (int)h, (int)h);
+            if (b > mx) mx = b;
+        }
+    return align256(mx);
+}
+
 extern "C" size_t llmc_chol_inv_upper_ws_bytes(int64_t K) {
     if (K <= 0) return 0;
     size_t work = align256((size_t)K * K * 4);
     size_t vbuf = align256((size_t)ceil_div64(K, NB) * NB * NB * 4);
     size_t xbuf = align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
-    return work + vbuf + xbuf;
+    return work + vbuf + xbuf + gemm6_bytes(K);
 }
 
 extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
@@ -511,6 +533,8 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     float* Wk = (float*)ws;
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
+    void* G6buf = (char*)Xbuf + align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
+    const bool use_g6 = getenv("LLMC_K3_NO_GEMM6") == nullptr;
     LLMC_HIP_CHECK(hipMemsetAsync(info_dev, 0, 4, st));
     if (int rc = ensure_dynamic_lds((const void*)k_potrf_inv, (NB * PLD + 32 * PLD + 64) * (int)sizeof(float))) return rc;
 
@@ -610,6 +634,10 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     // ---- V = U'^-1: inverted diagonal blocks, then doubling levels
     hipLaunchKernelGGL(k_place_diag_inv, dim3((K + NB - 1) / NB), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf);
     LLMC_LAUNCH_CHECK();
+    if (use_x3t && use_g6 && K > GEMM6_MIN_H) {
+        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
+        LLMC_LAUNCH_CHECK();
+    }
     for (int64_t h = NB; h < K; h *= 2) {
         const int npairs = (int)((K - h + 2 * h - 1) / (2 * h));  // pairs with a non-empty right block
         if (npairs <= 0) break;
@@ -626,7 +654,22 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2_last; x.Kd = x.Kd_last = (int)h;
         x.epilogue = SG_SET; x.a_upper = 1; x.batch = npairs;
         const bool lvl_x3 = use_x3t && h >= 512;   // small levels are latency-bound: the fp32 kernels stay
-        int rc = lvl_x3 ? gemm3_launch(x, false, st) : sgemm_launch(x, false, false, st);
+        // large, deep levels: operands split once into stacked bf16 planes, product on the one-wave-per-SIMD GEMM
+        const bool lvl_g6 = lvl_x3 && use_g6 && h >= GEMM6_MIN_H && h % 256 == 0 && n2_last % 256 == 0;
+        int rc = LLMC_OK;
+        if (lvl_g6) {
+            for (int z = 0; z < npairs && !rc; ++z) {
+                const int n2 = z == npairs - 1 ? n2_last : (int)h;
+                rc = gemm6_launch(x.A + z * stride, K, x.B + z * stride, K, Xbuf + (int64_t)z * h * h, ldX, (int)h, n2, (int)h,
+                                  1, 0, 1.0f, G6buf, st);
+                if (rc) return rc;
+                rc = gemm6_launch(Xbuf + (int64_t)z * h * h, ldX, Wk + h * ((int64_t)K + 1) + z * stride, K,
+                                  Wk + h + z * stride, K, (int)h, n2, n2, 0, 1, -1.0f, G6buf, st);
+            }
+            if (rc) return rc;
+            continue;
+        }
+        rc = lvl_x3 ? gemm3_launch(x, false, st) : sgemm_launch(x, false, false, st);
         if (rc) return rc;
         // C = -X B^-1
         SgemmArgs y{};

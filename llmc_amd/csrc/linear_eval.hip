@@ -12,6 +12,7 @@
 #include <type_traits>
 #include "common.h"
 #include "mfma_common.h"
+#include "sgemm.h"
 
 namespace llmc {
 
@@ -36,6 +37,14 @@ struct LinArgs {
     int sbm, sbn, nsn, nrounds;
     int yblk;         // k_linear_eval4: Y (mode 0) / Y0 (mode 1) is tile-blocked in fragment order (LLMC_LINEAR_YBLOCKED)
     int y0_lds;       // k_linear_eval4, mode 1: Y0 tiles are staged through LDS (R % 8 == 0, Y0 16-B aligned, < 4 GiB)
+    // mode 3 (gemm6, K3's large products): C fp32 [N, R] window with row stride ldc = csign * (X W^T); krange limits a
+    // tile's k loop: 1 = op(A) upper triangular (k >= first row of the tile), 2 = op(B) upper triangular (k < last column of
+    // the tile + 1), in units of kunit k per source k (the stacked planes: 6)
+    float* C;
+    int64_t ldc;
+    float csign;
+    int krange, kunit;
+    unsigned* queue;  // gemm6: tile counter (zeroed before the launch), or null = the static XCD block order
 };
 
 // (round, block) -> tile; false = padding of a ragged block
@@ -301,12 +310,27 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
         ry[1] = (int)((uint32_t)((uintptr_t)a.Y0 >> 32) & 0xffffu);
         ry[2] = (int)(uint32_t)(yb > 0xffffffffll ? 0xffffffffll : yb);
     }
-    const int ngroups = (int)(a.K / (L4_KS * L4_RING));
-
     for (int round = 0; round < a.nrounds; ++round) {
         int tm, tn;
-        if (!lin_tile(a, round, tm, tn)) continue;
+        if (a.queue) {
+            // gemm6: tiles differ in depth (triangular operand), so workgroups pull them from a counter, deepest first
+            // (a_upper: small tm first; b_upper: large tn first); the 256 tiles in flight still share few operand panels
+            __syncthreads();
+            if (tid == 0) *(int*)red = (int)atomicAdd(a.queue, 1u);
+            __syncthreads();
+            const int q = __builtin_amdgcn_readfirstlane(*(volatile int*)red);
+            if (q >= a.ntm * a.ntn) break;
+            if (a.krange == 2) { tn = a.ntn - 1 - q / a.ntm; tm = q - (q / a.ntm) * a.ntm; }
+            else { tm = q / a.ntn; tn = q - tm * a.ntn; }
+            round = -1;     // the loop ends by the break above
+        } else if (!lin_tile(a, round, tm, tn)) continue;
         const int t = tm * a.ntn + tn;
+        // triangular operands (gemm6): stages [st0, st1) of 32 k; both ends are multiples of a ring turn
+        int st0 = 0, st1 = (int)(a.K / L4_KS);
+        if (a.krange == 1) st0 = tm * LT * a.kunit / L4_KS;
+        if (a.krange == 2) st1 = min(st1, (tn + 1) * LT * a.kunit / L4_KS);
+        const int ngroups = (st1 - st0) / L4_RING;
+        if (ngroups <= 0 && a.mode != 3) continue;
         const uint32_t vA = (uint32_t)(tm * LT * 64) + vlane;
         const uint32_t vB = (uint32_t)(tn * LT * 64) + vlane;
         f32x16 acc[4][4];
@@ -318,7 +342,10 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
         uint32_t sA[4], sB[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sA[q] = sB[q] = (uint32_t)q * slab;
+        for (int q = 0; q < 4; ++q) {
+            sA[q] = (uint32_t)q * slab + (uint32_t)st0 * advA;
+            sB[q] = (uint32_t)q * slab + (uint32_t)st0 * advB;
+        }
         auto piece = [&](auto slc, auto dc) {
             constexpr int SL = decltype(slc)::value;
             constexpr int d = decltype(dc)::value;
@@ -368,11 +395,13 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
         };
         constexpr std::integral_constant<int, 0> K0{};
         constexpr std::integral_constant<int, 1> K1{};
+        if (ngroups > 0) {
         l4_static_for<0, L4_RING - 1>([&](auto slc) { l4_static_for<0, 8>([&](auto dc) { piece(slc, dc); }); });
         l4_static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, L4_RING - 1>{}, dc); });
         l4_vmwait<(L4_RING - 2) * PER + PER / 2>();
         __builtin_amdgcn_s_barrier();
         l4_static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, K0, fc, fa0, fb0); });
+        }
         // one ring turn = 4 stages. The LAST turn of a tile (KIND 1) requests only what the tile still needs (the B half
         // of its final stage) and counts the VM counter down to 0, so the ring is quiet and free when the turn ends.
         // KIND 2 (loss mode): the ring slots the last turn leaves behind take the Y0 tile, a quarter (64 rows = 32 KiB =
@@ -399,7 +428,7 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             });
         };
         for (int g = 0; g < ngroups - 1; ++g) turn(std::integral_constant<int, 0>{});
-        turn(std::integral_constant<int, STAGE_Y != 0 ? 2 : 1>{});
+        if (ngroups > 0) turn(std::integral_constant<int, STAGE_Y != 0 ? 2 : 1>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (a.mode == 2) {   // lab (LLMC_LIN_ABL=1): the main loop alone, nothing stored
             __builtin_amdgcn_s_barrier();
@@ -481,6 +510,23 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
         }
 
         __builtin_amdgcn_s_barrier();    // every wave has read its last fragments before the next prologue refills the ring
+        if (a.mode == 3) {
+            // gemm6: C = csign * acc in fp32; a lane's 32 consecutive columns per row segment are one 128-B line
+            l4_static_for<0, 16>([&](auto mnc) {
+                constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
+                const int64_t col = (int64_t)tn * LT + wn * 128 + n * 32 + (lane & 31);
+                const int64_t tok0 = (int64_t)tm * LT + wm * 128 + m * 32 + 4 * (lane >> 5);
+                if (col < a.R) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t tok = tok0 + (r & 3) + 8 * (r >> 2);
+                        if (tok < a.N) a.C[tok * a.ldc + col] = a.csign * acc[m][n][r];
+                    }
+                }
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            continue;
+        }
         if (a.mode == 0 && a.yblk) {
             // tile-blocked output in fragment order: tile t = 128 KiB, wave wv = 32 KiB, piece I = (m*4 + n)*2 + v = 1 KiB,
             // lane = 16 B = acc[m][n][8v .. 8v+7] rounded (+ bias): one coalesced 16-B store per piece
@@ -594,6 +640,7 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
     lin_tile_order(a, 256);
     a.y0_lds = 0;
     a.yblk = 0;
+    a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr;
     if (dt == LLMC_BF16) {
         if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_BF16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_BF16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
@@ -654,6 +701,7 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     LLMC_REQUIRE(grid >= 8, "linear_eval_kt: device has fewer than 8 compute units");
     lin_tile_order(a, grid);
     a.yblk = yblk;
+    a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr;
     a.y0_lds = mode == 1 && !yblk && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
     int stage = mode == 1 ? (yblk ? 2 : a.y0_lds ? 1 : 0) : 0;
     if (const char* e = getenv("LLMC_LIN_ABL")) {   // lab switches, never set by the package
@@ -675,3 +723,115 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     }
     return LLMC_OK;
 }
+
+// ---- gemm6: K3's large products C = +-op(A) B on k_linear_eval4 (declared in sgemm.h) --------------------------------
+// fp32 operands are split exactly into three bf16 terms (gemm3.hip) ONCE, into k-tiled planes stacked along k: per 32-k
+// block six slices, A side (lo, hi, mid, mid, hi, hi), B side (hi, lo, mid, hi, mid, hi), so that the k-sum of the stacked
+// product is lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi = the fp32 product to fp32 accuracy (small terms first per
+// block). k_gemm3 re-splits every operand element in every tile that uses it and reads a fragment from LDS per MFMA.
+namespace llmc {
+
+__device__ __forceinline__ void split3(float v, uint16_t (&pl)[3]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const uint16_t b = f32_to_bf16_bits(v);
+        pl[t] = b;
+        v = v - bf16_bits_to_f32(b);
+    }
+}
+// plane (0 hi, 1 mid, 2 lo) of stacked slice q on the A / B side; compile-time so that the unrolled loops index registers
+__device__ __forceinline__ constexpr int g6_plane(int side, int q) {
+    return side ? (q == 1 ? 2 : (q == 2 || q == 4) ? 1 : 0) : (q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0);
+}
+
+// source [rows, Kd] row-major (k contiguous, row stride ld) -> planes T[(Kd/32) * 6][rows][32]. One workgroup: 64 rows x one
+// 32-k block; thread = 8 consecutive k of one row (4 threads per row: whole 128-B lines in, 16 rows x 64 B = KiB runs out).
+// side 0 = A order, 1 = B order.
+__global__ __launch_bounds__(256) void k_split6_rows(const float* __restrict__ src, int64_t ld, int rows, int Kd, int side,
+                                                     uint16_t* __restrict__ dst) {
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    const int64_t row = (int64_t)blockIdx.x * 64 + r;
+    const int kb = blockIdx.y;
+    if (row >= rows) return;
+    const float* p = src + row * ld + kb * 32 + c * 8;
+    const float4 f0 = *reinterpret_cast<const float4*>(p);
+    const float4 f1 = *reinterpret_cast<const float4*>(p + 4);
+    const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    uint16_t pl[8][3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(v[e], pl[e]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = side ? pl[e][g6_plane(1, q)] : pl[e][g6_plane(0, q)];
+        uint4 ov;
+        __builtin_memcpy(&ov, o, 16);
+        *reinterpret_cast<uint4*>(dst + (((int64_t)kb * 6 + q) * rows + row) * 32 + c * 8) = ov;
+    }
+}
+
+// source [Kd, cols] k-major (row stride ld) -> planes T[(Kd/32) * 6][cols][32]: a 32 x 32 tile through LDS.
+__global__ __launch_bounds__(256) void k_split6_cols(const float* __restrict__ src, int64_t ld, int cols, int Kd, int side,
+                                                     uint16_t* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int kb = blockIdx.y, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+#pragma unroll
+    for (int y = ty; y < 32; y += 8) {
+        const int c = c0 + tx;
+        tile[y][tx] = c < cols ? src[(int64_t)(kb * 32 + y) * ld + c] : 0.0f;
+    }
+    __syncthreads();
+    // thread -> column (row of the planes) c0 + (threadIdx >> 3), 4 consecutive k: (threadIdx & 7) * 4
+    const int cr = threadIdx.x >> 3, k4 = (threadIdx.x & 7) * 4;
+    if (c0 + cr >= cols) return;
+    uint16_t pl[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(tile[k4 + e][cr], pl[e]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        uint16_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = side ? pl[e][g6_plane(1, p)] : pl[e][g6_plane(0, p)];
+        uint2 ov;
+        __builtin_memcpy(&ov, o, 8);
+        *reinterpret_cast<uint2*>(dst + (((int64_t)kb * 6 + p) * cols + c0 + cr) * 32 + k4) = ov;
+    }
+}
+
+static inline size_t g6_align(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t gemm6_ws_bytes(int M, int N, int Kd) {
+    return g6_align((size_t)6 * Kd * M * 2) + g6_align((size_t)6 * Kd * N * 2) + 512;
+}
+// C [M, N] (row stride ldc) = sign * A B with A [M, Kd] row-major fp32 (lda), B [Kd, N] k-major fp32 (ldb).
+// a_upper: A[i][k] == 0 for k < i; b_upper: B[k][j] == 0 for k > j (at most one of them). Kd % 256 == 0.
+int gemm6_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int Kd,
+                 int a_upper, int b_upper, float sign, void* ws, hipStream_t st) {
+    LLMC_REQUIRE(A && B && C && ws && M > 0 && N > 0 && Kd > 0 && Kd % 256 == 0 && !(a_upper && b_upper), "gemm6: bad argument");
+    LLMC_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)ws & 255) == 0, "gemm6: alignment");
+    LLMC_REQUIRE((int64_t)6 * Kd * M * 2 < (1ll << 32) && (int64_t)6 * Kd * N * 2 < (1ll << 32), "gemm6: planes must stay below 4 GiB");
+    uint16_t* Ap = (uint16_t*)ws;
+    uint16_t* Bp = (uint16_t*)((char*)ws + g6_align((size_t)6 * Kd * M * 2));
+    hipLaunchKernelGGL(k_split6_rows, dim3((M + 63) / 64, Kd / 32), dim3(256), 0, st, A, lda, M, Kd, 0, Ap);
+    LLMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_split6_cols, dim3((N + 31) / 32, Kd / 32), dim3(256), 0, st, B, ldb, N, Kd, 1, Bp);
+    LLMC_LAUNCH_CHECK();
+    LinArgs a;
+    a.X = (const char*)Ap; a.W = (const char*)Bp; a.N = M; a.K = (int64_t)6 * Kd; a.R = N; a.mode = 3;
+    a.Y = nullptr; a.Y0 = nullptr; a.part = nullptr;
+    a.ntm = (int)ceil_div64(M, LT); a.ntn = (int)ceil_div64(N, LT);
+    const int grid = device_cu_count() & ~7;
+    LLMC_REQUIRE(grid >= 8, "gemm6: device has fewer than 8 compute units");
+    lin_tile_order(a, grid);
+    a.yblk = 0; a.y0_lds = 0;
+    a.C = C; a.ldc = ldc; a.csign = sign; a.krange = a_upper ? 1 : b_upper ? 2 : 0; a.kunit = 6;
+    a.queue = (unsigned*)((char*)Bp + g6_align((size_t)6 * Kd * N * 2));
+    LLMC_HIP_CHECK(hipMemsetAsync(a.queue, 0, 4, st));
+    const void* fn = (const void*)k_linear_eval4<LLMC_BF16, 0>;
+    if (int rc = ensure_dynamic_lds(fn, L4_LDS + 64)) return rc;
+    void* kargs[] = {(void*)&a};
+    LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(L4_THREADS), kargs, (size_t)(L4_LDS + 64), st));
+    return LLMC_OK;
+}
+}  // namespace llmc

@@ -43,4 +43,11 @@ int gemm3_tn_launch(const SgemmArgs& a, hipStream_t st);
 // general form: TA as in sgemm_launch, op(B) = N; hints a_upper / a_lower / b_upper / c_upper_only, all epilogues, batch
 int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st);
 
+// C [M, N] = sign * A B (A [M, Kd] row-major, B [Kd, N] k-major, fp32) with the same three-bf16-term arithmetic on the
+// one-wave-per-SIMD GEMM of linear_eval.hip: operands split ONCE into k-tiled stacked planes. For the large, deep levels of
+// K3's triangular inverse. Kd % 256 == 0; ws: gemm6_ws_bytes, 256-B aligned.
+size_t gemm6_ws_bytes(int M, int N, int Kd);
+int gemm6_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int Kd,
+                 int a_upper, int b_upper, float sign, void* ws, hipStream_t st);
+
 }  // namespace llmc

@@ -338,7 +338,7 @@ def test_split_bf16_factor_is_as_accurate_as_fp32_on_outlier_channels(monkeypatc
     assert e3 <= max(2 * e1, 1e-6), (e3, e1)
 
 
-@pytest.mark.parametrize('K', [128, 384, 1000, 4096])
+@pytest.mark.parametrize('K', [128, 384, 1000, 4096, 6144])
 def test_chol_inv_upper_vs_fp64(K):
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
     gen = torch.Generator().manual_seed(K)
@@ -387,7 +387,7 @@ def test_hessian_prep_vs_oracle():
     assert Hd.cpu().numpy()[dead, dead].tolist() == [1.0, 1.0]           # in-place dead fix like the reference
 
 
-@pytest.mark.parametrize('K', [14336, 2560, 2432])
+@pytest.mark.parametrize('K', [14336, 2560, 2432, 6144, 5248])
 def test_chol_inv_upper_large_property(K):
     """Uneven doubling levels (14336 = 7 * 2048): U H U^T = I in fp32 on the GPU."""
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper

@@ -1,10 +1,13 @@
 #!/bin/bash
 mkdir -p gpurun_out/o
-LLMC_NO_SIDE_STREAM=1 timeout 300 python tools/bench_stages.py > gpurun_out/o/stages_s3_noside.txt 2>&1; grep down gpurun_out/o/stages_s3_noside.txt
-LLMC_NO_SIDE_STREAM=1 LLMC_K3_NO_SYRK3=1 timeout 300 python tools/bench_stages.py > gpurun_out/o/stages_gemm3_noside.txt 2>&1; grep down gpurun_out/o/stages_gemm3_noside.txt
+timeout 900 python -m pytest tests/test_gptq_gpu.py -x -q -m gpu -k "chol or factor" > gpurun_out/o/tests.log 2>&1
+tail -3 gpurun_out/o/tests.log
+bash tools/r02_gpu_o2.sh
+timeout 300 python tools/bench_stages.py 2>&1 | grep down
+LLMC_K3_NO_GEMM6=1 timeout 300 python tools/bench_stages.py 2>&1 | grep down
 run() {  # name, args...
   name=$1; shift
-  timeout 120 python bench.py --steps 3 --warmup 1 "$@" > gpurun_out/o/$name.json 2> gpurun_out/o/$name.err
+  timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/o/$name.json 2> gpurun_out/o/$name.err
   python - "$name" <<'PY'
 import json, sys
 f = sys.argv[1]
@@ -13,5 +16,5 @@ try:
 except Exception as e: print(f, 'fail', e)
 PY
 }
-run bench_s3
-LLMC_K3_NO_SYRK3=1 run bench_gemm3
+run bench_g6
+LLMC_K3_NO_GEMM6=1 run bench_gemm3
