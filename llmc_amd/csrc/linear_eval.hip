@@ -6,8 +6,10 @@
 // Both operands are contiguous along the contraction axis ("NT"): tiles are staged row-major by LDS-DMA and
 // read with ds_read_b128; the 16-B chunk index is XOR-ed with ((row >> 1) & 7) on the DMA source address
 // and on the read, which makes every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
-// Tile 256 x 256, K-step 64, 8 waves (2 x 4), persistent grid with XCD-contiguous tile ranges: the 32
-// workgroups of an XCD walk 2 token panels x 16 weight panels at the same K position (L2-resident).
+// Two kernels: k_linear_eval (row-major operands: tile 256 x 256, K-step 64, 8 waves as 2 x 4; what FakeQuantLinear.forward
+// and any K % 128 != 0 shape run on) and k_linear_eval4 (k-tiled operands, one wave per SIMD: the AWQ grid, and K3's deep
+// products through gemm6 at the end of the file). Persistent grids; each XCD works on one block of tiles per round
+// (lin_tile_order), so the workgroups that share an L2 share few operand panels at the same K position.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
