@@ -2,9 +2,8 @@
 mkdir -p gpurun_out/o
 timeout 900 python -m pytest tests/test_gptq_gpu.py -x -q -m gpu -k "chol or factor" > gpurun_out/o/tests.log 2>&1
 tail -3 gpurun_out/o/tests.log
-bash tools/r02_gpu_o2.sh
-timeout 300 python tools/bench_stages.py 2>&1 | grep down
-LLMC_K3_NO_GEMM6=1 timeout 300 python tools/bench_stages.py 2>&1 | grep down
+timeout 300 python tools/bench_stages.py 2>&1 | grep "down\|gate"
+LLMC_K3_NO_PLANES=1 timeout 300 python tools/bench_stages.py 2>&1 | grep "down\|gate"
 run() {  # name, args...
   name=$1; shift
   timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/o/$name.json 2> gpurun_out/o/$name.err
@@ -16,5 +15,5 @@ try:
 except Exception as e: print(f, 'fail', e)
 PY
 }
-run bench_g6
-LLMC_K3_NO_GEMM6=1 run bench_gemm3
+run bench_planes
+LLMC_K3_NO_PLANES=1 run bench_noplanes
