@@ -175,3 +175,45 @@ def test_true_sequential_first_pass_feeds_only_the_first_subset(monkeypatch):
             assert len(g.layers_cache['o']['acc'].fed) == 1
         else:
             assert fed == {'q': 1, 'k': 1, 'o': 1, 'down': 1}
+
+
+def test_spqr_surface_and_config_errors_without_gpu():
+    """SpQR keeps the reference's constructor / method surface (spqr.py:18-398) and refuses what the reference cannot run
+    either (a symmetric weight quantizer) or what is not built (per_tensor second-level quantizers)."""
+    sig = lambda f: list(inspect.signature(f).parameters)  # noqa: E731
+    assert 'SpQR' in ALGO_REGISTRY.keys() and ALGO_REGISTRY['SpQR'] is Q.SpQR
+    assert sig(Q.SpQR.__init__)[:6] == ['self', 'model', 'quant_config', 'input', 'padding_mask', 'config']
+    assert sig(Q.SpQR.w_qdq) == ['self', 'module', 'wquantizer']
+    q2 = dict(bit=3, symmetric=False, granularity='per_group', group_size=16, round_zp=False)
+    special = dict(actorder=True, percdamp=1, blocksize=128, true_sequential=True, relative_threshold='inf',
+                   simplified_outliers=False, scale=dict(q2), zero=dict(q2))
+    s = Q.SpQR.__new__(Q.SpQR)
+    s.quant_config = {'special': special}
+    s.wquantizer = Q.IntegerQuantizer(4, False, 'per_group', group_size=16, round_zp=False)
+    s.add_quant_config()
+    import math
+    assert s.relative_threshold == math.inf and s.need_perm and s.scfg.group_size == 16 and s.scfg.scale_bit == 3
+    s.wquantizer = Q.IntegerQuantizer(4, True, 'per_group', group_size=16, round_zp=False)
+    with pytest.raises(NotImplementedError):
+        s.add_quant_config()
+    s.wquantizer = Q.IntegerQuantizer(4, False, 'per_group', group_size=16, round_zp=False)
+    s.quant_config = {'special': dict(special, scale=dict(q2, granularity='per_tensor'))}
+    with pytest.raises(NotImplementedError):
+        s.add_quant_config()
+    with pytest.raises(AssertionError):
+        s.deploy('real_quant')
+
+
+def test_blocked_output_index_map_without_gpu():
+    """awq_ops.unblock_y: the tile-blocked image (tile, wave, accumulator, register, lane) back to [N, R]."""
+    from llmc_amd.compression.quantization.awq_ops import unblock_y
+    N, R, ntm, ntn = 300, 520, 2, 3
+    ref = torch.arange(ntm * 256 * ntn * 256, dtype=torch.int32).reshape(ntm * 256, ntn * 256)
+    idx = torch.arange(ntm * ntn * 65536)
+    j, lane, piece, wv, t = idx % 8, (idx // 8) % 64, (idx // 512) % 32, (idx // 16384) % 4, idx // 65536
+    v, n, m, wm, wn, tm, tn = piece % 2, (piece // 2) % 4, piece // 8, wv // 2, wv % 2, t // ntn, t % ntn
+    r = 8 * v + j
+    tok = tm * 256 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    col = tn * 256 + wn * 128 + n * 32 + (lane & 31)
+    buf = ref[tok, col]
+    assert torch.equal(unblock_y(buf, N, R), ref[:N, :R])
