@@ -56,9 +56,10 @@ def parse_args(argv=None):
     ap.add_argument('--model', default='llama3-8b', choices=list(MODELS))
     ap.add_argument('--n-seq', type=int, default=128)
     ap.add_argument('--seq-len', type=int, default=2048)
-    ap.add_argument('--calib-bs', type=int, default=128,
-                    help='sequences per add_batch call (reference calib.bs; 128 = one call per input, 1 = the '
-                         "reference config's per-sample hook calls)")
+    ap.add_argument('--calib-bs', type=int, default=1,
+                    help='sequences per add_batch call (reference calib.bs). 1 (default) = the reference config\'s calling '
+                         'pattern (gptq_w_only.yml:12): 128 hook calls of [1, seq, K] per input, each sample its own '
+                         'allocation, walked by ONE kernel launch through the sample table; n_seq = one call on one tensor')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
     ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
                     help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
@@ -76,6 +77,9 @@ def parse_args(argv=None):
                          '0 = one after the other on the current stream')
     ap.add_argument('--dry', action='store_true', help='GPU-less plumbing check (gloo + CPU stand-ins)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the secondary workloads reported under "extra" (N = 1 only): AWQ (BASELINE configs[2]), the '
+                         'vLLM-exportable GPTQ variant with INT4 packing, Llama-3-70B shapes')
     return ap.parse_args(argv)
 
 
@@ -267,8 +271,12 @@ class HipOps:
     def hessian(self, name, K, x, calib_bs):
         a = self.acc(name, K)
         a.reset()
-        for i in range(0, x.shape[0], calib_bs):
-            a.add(x[i:i + calib_bs])
+        if isinstance(x, (list, tuple)):          # per-call tensors, each its own allocation (hook calls)
+            for xi in x:
+                a.add(xi)
+        else:
+            for i in range(0, x.shape[0], calib_bs):
+                a.add(x[i:i + calib_bs])
         return a.H
 
     def static_qparams(self, weights):
@@ -318,6 +326,8 @@ class DryOps:
         self.torch, self.cfg, self.timing = torch, cfg, None
 
     def hessian(self, name, K, x, calib_bs):
+        if isinstance(x, (list, tuple)):
+            x = self.torch.cat(list(x), 0)
         xf = x.reshape(-1, K).float()
         return (xf.T @ xf) * (2.0 / x.shape[0])
 
@@ -425,6 +435,32 @@ def run_awq(args):
         torch.distributed.destroy_process_group()
 
 
+def run_extras(args):
+    """The secondary workloads, a few steps each, as child runs of this script (same code path as their own bench
+    lines): value / ms_per_step / roofline of each go under "extra" of the one JSON line."""
+    runs = {
+        'awq_llama3_8b': ['--workload', 'awq', '--steps', '2', '--warmup', '1'],
+        'gptq_vllm_variant_packed': ['--variant', 'vllm', '--steps', '3', '--warmup', '1'],
+        'gptq_llama3_70b_shapes': ['--model', 'llama3-70b', '--steps', '2', '--warmup', '1'],
+    }
+    out = {}
+    for key, flags in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-cpu-baseline', '--no-extras',
+               '--dtype', args.dtype] + flags
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode != 0 or not line:
+                out[key] = {'error': (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline')
+                        if k in j}
+        except Exception as e:
+            out[key] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+    return out
+
+
 def main():
     args = parse_args()
     rc = maybe_spawn(args)
@@ -486,6 +522,11 @@ def main():
             acts[name] = synth_acts(args.n_seq, args.seq_len, K, gi, dev, dtype) if rank == 0 else None
         else:
             acts[name] = synth_acts(args.n_seq, args.seq_len, K, seed_r * 64 + gi, dev, dtype)
+            if args.calib_bs < args.n_seq and not args.dry:
+                # the hook calls' tensors: one allocation per call (calib.bs sequences each), nothing contiguous across calls
+                x = acts[name]
+                acts[name] = [x[i:i + args.calib_bs].clone() for i in range(0, args.n_seq, args.calib_bs)]
+                del x
         weights[name] = [synth_weight(R, K, seed_r * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
 
     timing = []
@@ -613,14 +654,15 @@ def main():
     # HBM-side bytes of the dominant kernel come from PMC passes that cannot run inside the timed process
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_bench.sh); the committed summary is reported with its source.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
-    if args.model == 'llama3-8b' and args.n_seq == 128 and args.seq_len == 2048 and args.calib_bs == 128 \
-            and os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))['k_syrk']
-            traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic.json (' + tj['note'] + ')'
-        except Exception:
-            traffic = None
+    for tname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+        tpath = os.path.join(ROOT, 'profiles', tname)
+        if args.model == 'llama3-8b' and args.n_seq == 128 and args.seq_len == 2048 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))['k_syrk']
+                traffic, traffic_src = tj['hbm_bytes_per_launch'], f'profiles/{tname} (' + tj['note'] + ')'
+                break
+            except Exception:
+                traffic = None
 
     if rank == 0:
         layers_step = n_layers_block * (1 if coop else world)
@@ -638,6 +680,12 @@ def main():
                              + ('1 transformer block (7 Linear, 4 distinct inputs) per step shared by all GPUs'
                                 if coop else '1 transformer block (7 Linear, 4 distinct inputs) per step per GPU')),
                 'n_seq': args.n_seq, 'seq_len': args.seq_len, 'calib_bs': args.calib_bs,
+                'hessian_feed': (f'{-(-args.n_seq // args.calib_bs)} add_batch calls per input (calib.bs = {args.calib_bs}, '
+                                 'one allocation per call), one launch through the sample table, no staging copy'
+                                 if args.calib_bs < args.n_seq else 'one add_batch call per input on one resident tensor'),
+                # w_only: a layer ends at compensated weights + scales / zeros (the reference cannot export actorder +
+                # dynamic groups either, gptq.py:455-457); vllm: + INT4 codes packed (SURVEY 8d's full definition)
+                'packs_codes': args.variant == 'vllm',
                 'symmetric': cfg.symmetric, 'actorder': cfg.actorder, 'static_groups': cfg.static_groups,
                 'subset_overlap_streams': 0 if (args.dry or coop) else args.overlap,
                 'parallelism': ('single GPU' if world == 1 else
@@ -653,6 +701,13 @@ def main():
                 'achieved_incl_fixup': achieved_fix, 'avg_fixup_ms': ms_fix / max(1, n_launch),
             },
         }
+        if world == 1 and not args.no_extras and not args.dry and args.model == 'llama3-8b' and args.variant == 'w_only':
+            # free this run's tensors first: the secondary workloads are child processes on the same GPU
+            acts.clear(); weights.clear(); ops.accs.clear(); ops.hwork.clear(); last = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out['extra'] = run_extras(args)
         if world == 1 and not args.no_cpu_baseline and not args.dry:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.model, args.n_seq, args.seq_len, cfg)

@@ -159,6 +159,25 @@ int llmc_hessian_accum_partials(const void* X, int dt, int64_t T, int64_t K, int
 int llmc_hessian_accum_reduce(float* H, int64_t T, int64_t K, int64_t ldx, double n_before, double n_after,
                               const void* ws, llmc_stream_t stream);
 
+/* The same update from a LIST of samples that stay where they are (no staging copy): llmc's hooks call add_batch once
+ * per calibration sample (calib.bs = 1, configs/quantization/methods/GPTQ/gptq_w_only.yml:12 -> 128 calls of
+ * [1, 2048, K] per layer, gptq.py:254-295); a caller that keeps those tensors resident passes their addresses here and
+ * gets ONE launch and ONE reduction for all of them:  X^T X = sum_i X_i^T X_i,  n_after - n_before = the number of
+ * sequences in the list. X_list_host / T_list_host: HOST arrays of n device pointers (16-B aligned rows, common row
+ * stride ldx and dtype dt) and their token counts (> 0; any lengths: every sample is walked in 128-token groups and
+ * the last group of a sample is zero-filled by its buffer descriptor). n <= llmc_hessian_max_samples(). The host arrays
+ * are consumed before the call returns (they travel in the kernel arguments). The result is bit-identical to
+ * llmc_hessian_accum on the concatenation of the samples whenever every T_i is a multiple of 128. ws from
+ * llmc_hessian_accum_ptrs_ws_bytes (0 = invalid arguments). */
+int llmc_hessian_max_samples(void);
+size_t llmc_hessian_accum_ptrs_ws_bytes(const int64_t* T_list_host, int n, int64_t K, int64_t ldx);
+int llmc_hessian_accum_ptrs(float* H, const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,
+                            int64_t K, int64_t ldx, double n_before, double n_after, void* ws, llmc_stream_t stream);
+int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,
+                                     int64_t K, int64_t ldx, void* ws, llmc_stream_t stream);
+int llmc_hessian_accum_ptrs_reduce(float* H, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
+                                   double n_before, double n_after, const void* ws, llmc_stream_t stream);
+
 /* GPTQ.process_hessian_and_weights, first half (gptq.py:135-152, 169-171):
  *   dead = diag(H) == 0 -> H[dead,dead] = 1, W[:,dead] = 0; optional symmetric gather by perm
  *   (Hout = H[perm][:,perm], Wout = W[:,perm]); damp = percdamp * mean(diag) ; Hout += damp * I.

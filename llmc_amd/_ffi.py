@@ -38,6 +38,11 @@ SIGNATURES = {
     'llmc_hessian_accum': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f64, _f64, _vp, _vp]),
     'llmc_hessian_accum_partials': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _vp]),
     'llmc_hessian_accum_reduce': (_i32, [_vp, _i64, _i64, _i64, _f64, _f64, _vp, _vp]),
+    'llmc_hessian_max_samples': (_i32, []),
+    'llmc_hessian_accum_ptrs_ws_bytes': (_sz, [_vp, _i32, _i64, _i64]),
+    'llmc_hessian_accum_ptrs': (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _f64, _f64, _vp, _vp]),
+    'llmc_hessian_accum_ptrs_partials': (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
+    'llmc_hessian_accum_ptrs_reduce': (_i32, [_vp, _vp, _i32, _i64, _i64, _f64, _f64, _vp, _vp]),
     'llmc_gather_cols': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'llmc_hessian_prep_ws_bytes': (_sz, [_i64]),
     'llmc_hessian_prep': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),

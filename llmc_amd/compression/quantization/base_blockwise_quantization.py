@@ -170,6 +170,9 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
                     kw[k] = v.to(device=dev)
                 elif isinstance(v, tuple):
                     kw[k] = tuple(t.to(device=dev) if torch.is_tensor(t) else t for t in v)
+            # one forward pass of the block = one calibration sample: hooks that dedupe work across the layers of a
+            # subset (GPTQ's shared Hessians) key on this counter
+            self._fwd_pass = getattr(self, '_fwd_pass', 0) + 1
             with torch.no_grad():
                 out = block(input_data[i], **kw)
             output.append(out[0] if isinstance(out, tuple) else out)
@@ -389,7 +392,13 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             os.makedirs(path, exist_ok=True)
             sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items() if torch.is_tensor(v)}
             save_file(sd, os.path.join(path, 'model.safetensors'))
-            cfg = dict(vars(getattr(self.model, 'model_config', None) or object()) if hasattr(self.model, 'model_config') else {})
+            mc = getattr(self.model, 'model_config', None)
+            if mc is not None and hasattr(mc, 'to_dict'):
+                cfg = dict(mc.to_dict())
+            elif mc is not None and hasattr(mc, '__dict__'):
+                cfg = dict(vars(mc))
+            else:
+                cfg = {}
             cfg = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool, list, type(None)))}
             with open(os.path.join(path, 'config.json'), 'w') as f:
                 json.dump(cfg, f, indent=4)

@@ -45,6 +45,9 @@ class GPTQ(BaseBlockwiseQuantization):
         self.percdamp = special['percdamp']
         self.blocksize = special['blocksize']
         self.chunk_num = special.get('chunk_num', 1)   # a memory lever of the reference's matmul; not needed here
+        # not a reference key: False makes the Hessian accumulators copy every hooked sample instead of keeping a
+        # reference to it until the subset's single launch (hessian.py)
+        self.hessian_defer = bool(special.get('hessian_defer', True))
         self.owq = bool(special.get('owq', False))
         if self.owq:                                   # gptq.py:47-50: OWQ fixes dynamic groups and no actorder
             self.n_outs = special['n_outs']
@@ -65,17 +68,23 @@ class GPTQ(BaseBlockwiseQuantization):
     @torch.no_grad()
     def cache_input_hook(self, m, inp, out, name, feat_dict):
         if isinstance(m, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)):
-            self.add_batch(self.named_layers[name], name, inp[0].data, out.data)
+            self.add_batch(self.named_layers[name], name, inp[0].detach(), out.data)
         if self.act_static:
             super().cache_input_hook(m, inp, out, name, feat_dict)
 
     # ---- Hessian groups -----------------------------------------------------------------------------------------
     # The layers of a subset are set up as ONE group sharing one accumulator (q/k/v and gate/up see the same tensor;
     # the reference accumulates the identical H once per layer). The sharing is only KEPT for layers whose hooked
-    # input is provably the very tensor the group's accumulator was fed with on the same calibration call: a layer
-    # that sees anything else on its first call — the experts and the router of a Mixtral / Qwen2-MoE / DeepSeek
-    # subset each see their own routed tokens (mixtral.py:65-66, qwen2moe.py:81-84, deepseekv2.py:130-135) — leaves the
-    # group and accumulates its own Hessian, exactly like the reference.
+    # input is provably the very tensor the group's accumulator was fed with IN THE SAME FORWARD PASS of the block:
+    #   * a pass is identified by `self._fwd_pass` (bumped by block_forward before every sample) and, for callers that
+    #     drive add_batch themselves, by a member being called a second time;
+    #   * the feeder's tensor is kept referenced for the duration of the pass, so its storage cannot be handed to
+    #     another tensor that would then alias its signature;
+    #   * a member that sees a different tensor, or whose first call comes after the group has already been fed
+    #     (an expert that received no token on earlier samples: HF / DeepSeek forwards skip it), leaves the group and
+    #     accumulates its own Hessian exactly like the reference — the experts and the router of a Mixtral / Qwen2-MoE /
+    #     DeepSeek subset each see their own routed tokens (mixtral.py:65-66, qwen2moe.py:81-84, deepseekv2.py:130-135);
+    #   * a member that DID share on earlier passes and then diverges cannot be repaired: loud failure.
     @staticmethod
     def _input_signature(inp):
         """What makes two hooked inputs THE SAME tensor (not merely equal): storage, view geometry, version."""
@@ -83,12 +92,34 @@ class GPTQ(BaseBlockwiseQuantization):
 
     def _new_group(self, names, K, device):
         gid = self._next_gid = getattr(self, '_next_gid', 0) + 1
-        acc = HessianAccumulator(K, device)
-        self._groups[gid] = {'acc': acc, 'feed': {}, 'members': list(names)}
+        acc = HessianAccumulator(K, device, defer=getattr(self, 'hessian_defer', True))
+        self._groups[gid] = {'acc': acc, 'pass': None, 'passes': 0, 'members': list(names)}
         for n in names:
             self._group_of[n] = gid
-            self.layers_cache[n] = {'acc': acc, 'H': acc.H, 'nsamples': 0, 'columns': K, 'calls': 0}
+            # 'H' is the accumulator's buffer; read `acc.H` to have the pending samples folded in first
+            self.layers_cache[n] = {'acc': acc, 'H': getattr(acc, '_H', None), 'nsamples': 0, 'columns': K,
+                                    'calls': 0, 'joined': 0, 'device': device}
         return gid
+
+    def _leave_group(self, name, device):
+        """`name` stops sharing: a group (accumulator) of its own, its call count kept."""
+        c = self.layers_cache[name]
+        g = self._groups[self._group_of[name]]
+        if c['joined']:
+            raise RuntimeError(f'GPTQ: layer {name} shared its Hessian on earlier calibration calls but now sees a '
+                               'different input tensor than its subset; per-layer Hessians cannot be recovered')
+        g['members'].remove(name)
+        calls = c['calls']
+        self._new_group([name], c['columns'], device)
+        self.layers_cache[name]['calls'] = calls
+        return self._groups[self._group_of[name]]
+
+    def _feed(self, g, name, inp):
+        g['acc'].add(inp)
+        g['passes'] += 1
+        for m in g['members']:
+            self.layers_cache[m]['nsamples'] = g['acc'].nsamples
+        self.layers_cache[name]['joined'] += 1
 
     @torch.no_grad()
     def add_batch(self, layer, name, inp, out):
@@ -102,29 +133,35 @@ class GPTQ(BaseBlockwiseQuantization):
             return
         c = self.layers_cache[name]
         c['calls'] += 1
-        call = c['calls']
         g = self._groups[self._group_of[name]]
-        if len(g['members']) > 1:
-            sig = self._input_signature(inp)
-            seen = g['feed'].get(call)
-            if seen is None:
-                g['feed'] = {call: sig}                      # first member called this time feeds the group
-            elif seen == sig:
-                c['nsamples'] = g['acc'].nsamples             # the very same tensor is already in H
+        if len(g['members']) == 1:
+            return self._feed(g, name, inp)
+        dev = layer.weight.device
+        token = getattr(self, '_fwd_pass', None)
+        sig = self._input_signature(inp)
+        p = g['pass']
+        new_pass = p is None or name in p['seen'] or (token is not None and p['token'] != token)
+        if not new_pass:
+            if sig == p['sig']:                                # the very same tensor is already in H
+                p['seen'].add(name)
+                c['joined'] += 1
+                c['nsamples'] = g['acc'].nsamples
                 return
-            elif call == 1:                                   # a different input from the start: its own Hessian
-                g['members'].remove(name)
-                calls = c['calls']
-                self._new_group([name], c['columns'], layer.weight.device)
-                c = self.layers_cache[name]
-                c['calls'] = calls
-                g = self._groups[self._group_of[name]]
-            else:
-                raise RuntimeError(f'GPTQ: layer {name} shared its Hessian on earlier calibration calls but now sees a '
-                                   'different input tensor than its subset; per-layer Hessians cannot be recovered')
-        g['acc'].add(inp)
-        for m in g['members']:
-            self.layers_cache[m]['nsamples'] = g['acc'].nsamples
+            return self._feed(self._leave_group(name, dev), name, inp)   # another tensor in the same pass: its own Hessian
+        if c['joined'] != g['passes']:                         # it missed passes the group has been fed with
+            return self._feed(self._leave_group(name, dev), name, inp)
+        g['pass'] = {'token': token, 'sig': sig, 'ref': inp, 'seen': {name}}
+        self._feed(g, name, inp)
+
+    def _settle_group(self, gid):
+        """Before a group's Hessian is used: the pass's reference is dropped and members that never took part leave
+        (the reference's Hessian of a layer that was never called is all zero); partial sharers cannot be repaired."""
+        g = self._groups[gid]
+        g['pass'] = None
+        for n in list(g['members']):
+            c = self.layers_cache[n]
+            if len(g['members']) > 1 and c['joined'] != g['passes']:
+                self._leave_group(n, c['device'])
 
     def _group_layers(self, named_layers, block=None):
         """lists of layer names that start out sharing a Hessian: the model's subsets (same-shaped inputs only)."""
@@ -184,6 +221,8 @@ class GPTQ(BaseBlockwiseQuantization):
     def subset_transform(self, subset, input_feat, subset_kwargs):
         layers_dict = {n: l for n, l in subset['layers'].items()
                        if isinstance(l, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_))}
+        for gid in {self._group_of[n] for n in layers_dict}:
+            self._settle_group(gid)
         by_group = {}
         for n in layers_dict:
             by_group.setdefault(self._group_of[n], []).append(n)
@@ -195,6 +234,7 @@ class GPTQ(BaseBlockwiseQuantization):
 
     @torch.no_grad()
     def layer_transform(self, layer, name):
+        self._settle_group(self._group_of[name])
         gid = self._group_of[name]
         self._sync_hessian(gid)
         self._transform_group(gid, [layer], [name])

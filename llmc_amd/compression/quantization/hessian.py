@@ -1,4 +1,6 @@
 """Hessian accumulation for GPTQ on the MFMA pipe (GPTQ.add_batch, gptq.py:254-295)."""
+import ctypes as C
+
 import torch
 
 from llmc_amd import _ffi
@@ -8,23 +10,34 @@ class HessianAccumulator:
     """Owns H [K,K] fp32 and the partial-tile workspace; `add(inp)` has add_batch's arithmetic:
     H <- H * n/(n+b) + (2/(n+b)) * X^T X with b = number of sequences in `inp`.
 
-    llmc's hooks call add_batch once per calibration sample (calib.bs = 1: 128 calls of 2048 tokens per layer). One
+    llmc's hooks call add_batch once per calibration sample (calib.bs = 1: 128 calls of [1, 2048, K] per layer). One
     SYRK launch per call would spend most of its time re-reading and re-writing H (64 MiB / 784 MiB per call) and
-    filling the chip with 32-K-step units, so small calls are STAGED: their tokens are copied into a resident
-    [stage_tokens, K] buffer and one launch covers up to `stage_tokens` of them — the running-mean update of b
-    sequences at once is the same matrix as b single updates. Reading `.H` flushes what is staged."""
+    filling the chip with short units, so small calls are DEFERRED: the accumulator keeps a reference to the hooked
+    tensor (no copy — the activations of a block forward stay resident on the GPU anyway) and ONE launch
+    walks all of them through a table of their addresses (`llmc_hessian_accum_ptrs`): the running-mean update of b
+    sequences at once is the same matrix as b single updates. Reading `.H` flushes what is pending.
 
-    STAGE_TOKENS = 65536          # 32 sequences of 2048 tokens: 512 MiB at K = 4096, 1.75 GiB at K = 14336 (16-bit)
-    DIRECT_TOKENS = 16384         # calls at least this large go straight to the kernel
+    A deferred tensor must not change before the flush: its version counter is checked then (pass `inp.detach()`, not
+    `inp.data`, so that the counter is the producer's). `defer=False` (or the `max_pending_tokens` bound) trades the
+    references for private copies / earlier launches. Inputs the kernel cannot read in place (rows not 16-B aligned, a
+    strided channel axis) and very short ones (MoE experts' routed tokens) are copied compactly — their size, not a
+    fixed staging buffer."""
 
-    def __init__(self, columns, device):
+    DIRECT_TOKENS = 16384          # calls at least this large go straight to the kernel
+    SHORT_TOKENS = 256             # samples shorter than this are packed together at flush time
+    MAX_PENDING_TOKENS = 1 << 19   # references held at most (4 GiB of 16-bit activations at K = 4096)
+    COPY_FLUSH_TOKENS = 65536      # defer=False: private copies are flushed at this many tokens
+
+    def __init__(self, columns, device, defer=True, max_pending_tokens=None):
         self.K = int(columns)
         self._H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
-        self.nsamples = 0         # sequences added (staged ones included)
+        self.nsamples = 0         # sequences added (pending ones included)
         self._flushed = 0         # sequences already in H
         self._ws = None
-        self._stage = None
-        self._stage_tok = 0
+        self.defer = bool(defer)
+        self.max_pending_tokens = int(max_pending_tokens or self.MAX_PENDING_TOKENS)
+        self._pending = []        # (x2d, b, src, version) — src is None for private copies
+        self._pending_tok = 0
         self.timing = None   # optional list of (e0, e1, e2, T, K): e0..e1 around the MFMA kernel, e1..e2 the reduction
 
     @property
@@ -32,74 +45,142 @@ class HessianAccumulator:
         self.flush()
         return self._H
 
+    @staticmethod
+    def _readable_in_place(x):
+        return x.stride(-1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) >= x.shape[1]
+
+    def _compact(self, x):
+        T, K = x.shape
+        ld = (K + 7) // 8 * 8                          # the kernel reads 16-B aligned rows
+        buf = torch.empty((T, ld), dtype=x.dtype, device=x.device)[:, :K]
+        buf.copy_(x)
+        return buf
+
     def add(self, inp):
         _ffi.require_gpu(inp)
         if inp.dim() == 2:
             inp = inp.unsqueeze(0)
         b = inp.shape[0]
-        x = inp.reshape(-1, inp.shape[-1])
-        if x.dtype not in (torch.float16, torch.bfloat16):
-            raise ValueError(f'hessian: activations must be fp16/bf16 (model dtype), got {x.dtype}')
-        T, K = x.shape
-        if K != self.K:
-            raise ValueError(f'hessian: expected {self.K} channels, got {K}')
-        if T >= self.DIRECT_TOKENS or T > self.STAGE_TOKENS:
+        if inp.dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f'hessian: activations must be fp16/bf16 (model dtype), got {inp.dtype}')
+        if inp.shape[-1] != self.K:
+            raise ValueError(f'hessian: expected {self.K} channels, got {inp.shape[-1]}')
+        viewable = True
+        try:
+            x = inp.view(-1, self.K)                   # a view keeps the producer's storage (and version counter)
+        except RuntimeError:
+            x, viewable = inp.reshape(-1, self.K), False   # not viewable as [T, K]: reshape made a private copy
+        T = x.shape[0]
+        if T == 0:                                     # an expert that received no token: nsamples still counts the call
+            self.nsamples += b
+            self._pending.append((None, b, None, 0))
+            return self._H
+        if T >= self.DIRECT_TOKENS:
             self.flush()
-            self._launch(x, b)
+            xs = x if self._readable_in_place(x) else self._compact(x)
+            self._launch([xs], b)
             self.nsamples += b
             return self._H
-        if self._stage is not None and (self._stage.dtype != x.dtype or self._stage_tok + T > self.STAGE_TOKENS):
-            self.flush()
-        if self._stage is None or self._stage.dtype != x.dtype:
-            ld = (K + 7) // 8 * 8                      # the kernel reads 16-B aligned rows
-            self._stage = torch.empty((self.STAGE_TOKENS, ld), dtype=x.dtype, device=x.device)[:, :K]
-        self._stage[self._stage_tok:self._stage_tok + T].copy_(x)
-        self._stage_tok += T
+        if not self._readable_in_place(x) or (viewable and (not self.defer or T < self.SHORT_TOKENS)):
+            self._pending.append((self._compact(x), b, None, 0))       # private compact copy
+        elif not viewable:
+            self._pending.append((x, b, None, 0))                      # reshape's copy is already private
+        else:
+            self._pending.append((x, b, inp, inp._version))            # deferred: a reference, checked at flush
+        self._pending_tok += T
         self.nsamples += b
+        if self._pending_tok >= (self.max_pending_tokens if self.defer else self.COPY_FLUSH_TOKENS):
+            self.flush()
         return self._H
 
     def flush(self):
-        """One launch for everything staged (no-op when nothing is)."""
-        if self._stage_tok:
-            b = self.nsamples - self._flushed
-            self._launch(self._stage[:self._stage_tok], b, staged=True)
-            self._stage_tok = 0
+        """One launch per (dtype, row stride) for everything pending (no-op when nothing is)."""
+        if not self._pending:
+            return
+        pend, self._pending, self._pending_tok = self._pending, [], 0
+        for x, _, src, ver in pend:
+            if src is not None and src._version != ver:
+                raise RuntimeError('hessian: a deferred calibration tensor was modified in place before its Hessian was '
+                                   'accumulated; construct the accumulator with defer=False (GPTQ: special.hessian_defer: False)')
+        # short samples (and whatever shares their dtype) are packed into one compact tensor per dtype
+        b_total = sum(b for _, b, _, _ in pend)
+        by_key, short = {}, {}
+        for x, _, _, _ in pend:
+            if x is None:
+                continue
+            if x.shape[0] < self.SHORT_TOKENS:
+                short.setdefault(x.dtype, []).append(x)
+            else:
+                by_key.setdefault((x.dtype, x.stride(0)), []).append(x)
+        for dtp, xs in short.items():
+            packed = self._compact(torch.cat(xs, 0)) if len(xs) > 1 else xs[0]
+            by_key.setdefault((dtp, packed.stride(0)), []).append(packed)
+        groups = list(by_key.values())
+        if not groups:                                  # only empty calls: H <- H * n/(n+b)
+            if self._flushed:
+                self._H.mul_(self._flushed / (self._flushed + b_total))
+            self._flushed += b_total
+            return
+        # the sequences of the whole flush enter the running mean with the first launch; the others add their products
+        first = True
+        for xs in groups:
+            self._launch(xs, b_total if first else 0)
+            first = False
 
-    def _launch(self, x, b, staged=False):
+    def _launch(self, xs, b):
+        """xs: [T_i, K] tensors of one dtype and one row stride; b sequences enter the running mean with this launch."""
         L = _ffi.lib()
-        T, K = x.shape
-        if x.stride(-1) != 1 or x.stride(0) % 8 != 0 or x.data_ptr() % 16 != 0:
-            ld = (K + 7) // 8 * 8
-            buf = torch.empty((T, ld), dtype=x.dtype, device=x.device)[:, :K]
-            buf.copy_(x)
-            x = buf
-        ldx = x.stride(0)
-        need = L.llmc_hessian_accum_ws_bytes(T, K, ldx)
+        nmax = L.llmc_hessian_max_samples()
+        for i in range(0, len(xs), nmax):
+            self._launch_some(xs[i:i + nmax], b if i == 0 else 0)
+
+    def _launch_some(self, xs, b):
+        L = _ffi.lib()
+        n, K, ldx = len(xs), self.K, xs[0].stride(0)
+        Ts = (C.c_int64 * n)(*[x.shape[0] for x in xs])
+        Xs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        need = L.llmc_hessian_accum_ptrs_ws_bytes(Ts, n, K, ldx)
+        if need == 0:
+            # the samples are too short / too many for one walk: pack them into one tensor
+            xs = [self._compact(torch.cat(xs, 0))]
+            n, ldx = 1, xs[0].stride(0)
+            Ts = (C.c_int64 * 1)(xs[0].shape[0])
+            Xs = (C.c_void_p * 1)(xs[0].data_ptr())
+            need = L.llmc_hessian_accum_ptrs_ws_bytes(Ts, n, K, ldx)
+            if need == 0:
+                _ffi.check(-22, 'llmc_hessian_accum_ptrs_ws_bytes')
         if self._ws is None or self._ws.numel() < need:
-            self._ws = _ffi.workspace(need, x.device)
+            self._ws = None
+            self._ws = _ffi.workspace(need, xs[0].device)
         st = _ffi.stream()
+        T = sum(x.shape[0] for x in xs)
         if self.timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _ffi.check(L.llmc_hessian_accum_partials(_ffi.ptr(x), _ffi.dt(x), T, K, ldx, _ffi.ptr(self._ws), st),
-                   'llmc_hessian_accum_partials')
+        _ffi.check(L.llmc_hessian_accum_ptrs_partials(Xs, Ts, n, _ffi.dt(xs[0]), K, ldx, _ffi.ptr(self._ws), st),
+                   'llmc_hessian_accum_ptrs_partials')
         if self.timing is not None:
             e1.record()
-        _ffi.check(L.llmc_hessian_accum_reduce(_ffi.ptr(self._H), T, K, ldx, float(self._flushed),
-                                               float(self._flushed + b), _ffi.ptr(self._ws), st),
-                   'llmc_hessian_accum_reduce')
+        # b = 0: a further launch of the same flush adds its products with the weights of the first (n stays)
+        nb, na = float(self._flushed), float(self._flushed + b)
+        if b == 0:
+            nb = na = float(self._flushed)
+        _ffi.check(L.llmc_hessian_accum_ptrs_reduce(_ffi.ptr(self._H), Ts, n, K, ldx, nb, na, _ffi.ptr(self._ws), st),
+                   'llmc_hessian_accum_ptrs_reduce')
         if self.timing is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
             self.timing.append((e0, e1, e2, T, K))
         self._flushed += b
+        # the tensors of xs may be released by the caller once this returns: the launches are stream-ordered and torch's
+        # allocator keeps a freed block out of other streams' hands until this stream has passed
 
     def reset(self):
         """Start a new Hessian in the same buffers (the first launch overwrites H: n_before = 0)."""
         self.nsamples = 0
         self._flushed = 0
-        self._stage_tok = 0
+        self._pending, self._pending_tok = [], 0
 
     def release_workspace(self):
         self._ws = None
-        self._stage = None
+        self._pending, self._pending_tok = [], 0

@@ -149,6 +149,10 @@ class SpQR(GPTQ):
         if self.wquantizer.sym:
             raise NotImplementedError('SpQR needs an asymmetric weight quantizer (the reference crashes on the symmetric '
                                       'quantizer\'s 0-dim zero point in get_group_qparams, spqr.py:331)')
+        if getattr(self.wquantizer, 'round_zp', True):
+            # the column loop's kernel evaluates clamp(round(x / s + z)) with a fractional zero point (the shipped
+            # configs: round_zp False); with round_zp the reference rounds and clamps z and uses clamp(round(x / s) + z)
+            raise NotImplementedError('SpQR weight quantizer: only round_zp=False (the shipped configs) is built')
         self.scale_quantizer = IntegerQuantizer(**special['scale'])
         self.zero_quantizer = IntegerQuantizer(**special['zero'])
         for q, what in ((self.scale_quantizer, 'scale'), (self.zero_quantizer, 'zero')):

@@ -98,34 +98,41 @@ def _unflatten(sk, tensors):
 
 def _gather_p2p(mine, n_units, gather_to):
     rank, world = world_info()
+    backend = dist.get_backend()
     flat = []
     for r in mine:
         ts = []
         sk = _flatten(r.payload, ts)
+        if backend == 'nccl':
+            for t in ts:
+                assert t.is_cuda, 'layer_shard: RCCL sends device tensors only (a payload tensor lives on the CPU)'
         flat.append((r.unit, sk, [t.contiguous() for t in ts]))
     meta = [(u, sk, [(tuple(t.shape), t.dtype) for t in ts]) for u, sk, ts in flat]
     metas = [None] * world
     dist.all_gather_object(metas, meta)
     if rank != gather_to:
-        for u, sk, ts in flat:
-            for t in ts:
-                dist.send(t, dst=gather_to)
+        ops = [dist.P2POp(dist.isend, t, gather_to) for u, sk, ts in flat for t in ts]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         return [r.payload for r in mine]
-    dev = None
-    for _, _, ts in flat:
-        for t in ts:
-            dev = t.device
+    # receive buffers live where the backend moves data: the current GPU under RCCL (also when this rank owns no
+    # unit and has no payload tensor of its own to look at), the host under Gloo
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
     results = {u: p.payload for u, p in ((r.unit, r) for r in mine)}
+    ops, pending = [], []
     for src in range(world):
         if src == gather_to:
             continue
         for u, sk, shapes in metas[src]:
-            ts = []
-            for shp, dt in shapes:
-                buf = torch.empty(shp, dtype=dt, device=dev if dev is not None else 'cpu')
-                dist.recv(buf, src=src)
-                ts.append(buf)
-            results[u] = _unflatten(sk, ts)
+            ts = [torch.empty(shp, dtype=dt, device=dev) for shp, dt in shapes]
+            ops.extend(dist.P2POp(dist.irecv, t, src) for t in ts)
+            pending.append((u, sk, ts))
+    if ops:                                   # all transfers of all ranks in flight at once (one group call under RCCL)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for u, sk, ts in pending:
+        results[u] = _unflatten(sk, ts)
     assert sorted(results) == list(range(n_units)), 'every unit exactly once'
     return [results[u] for u in range(n_units)]
 

@@ -55,5 +55,28 @@ def build(verbose=False):
     return OUT
 
 
+OUT_GPU = os.path.join(HERE, '_ref_gpu')
+
+
+def build_gpu():
+    """oracle/_ref_gpu/ : a PLAIN copy of the reference's llmc package (no rewrite at all). On the GPU box the unmodified
+    reference runs on the MI355X through PyTorch-ROCm (last sentence): the third arm of
+    tools/parity_envelope.py and the source of the Triton-kernel goldens (tools/fp8_triton_golden.py). Git-ignored,
+    travels with the gpurun snapshot, never imported by the product."""
+    if not os.path.isdir(os.path.join(REF, 'llmc')):
+        return None
+    stamp = os.path.join(OUT_GPU, '.built')
+    if os.path.exists(stamp):
+        return OUT_GPU
+    if os.path.isdir(OUT_GPU):
+        shutil.rmtree(OUT_GPU)
+    os.makedirs(OUT_GPU)
+    shutil.copytree(os.path.join(REF, 'llmc'), os.path.join(OUT_GPU, 'llmc'),
+                    ignore=shutil.ignore_patterns('__pycache__', '*.pyc'))
+    open(stamp, 'w').write('plain copy of ' + REF + '/llmc\n')
+    return OUT_GPU
+
+
 if __name__ == '__main__':
     print(build(verbose=True))
+    print(build_gpu())

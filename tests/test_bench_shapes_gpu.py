@@ -145,14 +145,20 @@ def test_hessian_strided_rows_above_4gib():
     check_tiles(H, x, n_seq, tiles)
 
 
-def test_hessian_kernel_variants_bit_identical(monkeypatch):
-    """The 8-wave kernel and the one-wave-per-SIMD kernel accumulate the same tokens in the same order."""
-    T, K, n_seq = 16384, 2304, 8
-    x = synth_x(T, K, torch.bfloat16, 5)
-    monkeypatch.delenv('LLMC_SYRK_V', raising=False)
-    monkeypatch.setenv('LLMC_SYRK_KALIGN', '10')     # chunk boundaries that suit the 4- and the 5-slot ring alike
-    H4 = run_hessian(x, n_seq).clone()
-    for v in ('8', '2', '88', '4', '5'):
-        monkeypatch.setenv('LLMC_SYRK_V', v)
-        Hv = run_hessian(x, n_seq)
-        assert torch.equal(H4, Hv), v
+def test_hessian_per_sample_table_bit_identical_at_the_bench_launch():
+    """The reference's calling pattern (calib.bs = 1: 128 hook calls of [1, 2048, K], gptq_w_only.yml:12): the deferred
+    per-sample path walks 128 separately allocated tensors through the sample table in ONE launch and gives the bits
+    of the one-tensor launch over the same tokens."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    T, K, n_seq = 262144, 4096, 128
+    x = synth_x(T, K, torch.bfloat16, 6)
+    H1 = run_hessian(x, n_seq).clone()
+    seq = T // n_seq
+    samples = [x[i * seq:(i + 1) * seq].clone().unsqueeze(0) for i in range(n_seq)]    # separate allocations
+    acc = HessianAccumulator(K, 'cuda')
+    acc.timing = []
+    for smp in samples:
+        acc.add(smp)
+    H2 = acc.H
+    assert acc.nsamples == n_seq and len(acc.timing) == 1          # one launch for the 128 calls
+    assert torch.equal(H1, H2)

@@ -107,3 +107,107 @@ def test_cu_reserve_leaves_compute_units_free_and_changes_no_bit():
         assert _ffi.lib().llmc_hip_set_cu_reserve(64) == 64
     assert _ffi.lib().llmc_hip_set_cu_reserve(0) == 0
     assert torch.equal(h0, h1)
+
+
+def _fp64_hessian(samples, n_batches):
+    K = samples[0].shape[-1]
+    acc = torch.zeros(K, K, dtype=torch.float64, device='cuda')
+    for smp in samples:
+        xf = smp.reshape(-1, K).double()
+        acc += xf.T @ xf
+    return acc * (2.0 / n_batches)
+
+
+def _check_vs_fp64(H, samples, n_batches):
+    ref = _fp64_hessian(samples, n_batches)
+    d = torch.sqrt(torch.outer(torch.diag(ref), torch.diag(ref))) + 1e-30
+    K = ref.shape[0]
+    xf = torch.cat([s.reshape(-1, K) for s in samples], 0).float()
+    e_t = (((xf.T @ xf) * (2.0 / n_batches)).double() - ref).abs().div(d).max().item()
+    e = ((H.double() - ref).abs() / d).max().item()
+    assert e <= max(4 * e_t, 2e-6), (e, e_t)
+    assert torch.equal(H, H.T)
+
+
+def test_sample_table_equals_one_tensor_bitwise():
+    """llmc_hessian_accum_ptrs over separately allocated samples (lengths multiples of 128) == llmc_hessian_accum over
+    their concatenation, bit for bit; defer=False (private copies, same table walk) as well."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    K, seq, n = 1280, 512, 24
+    x = make_x(seq, K, 'bf16', 5, b=n).cuda()
+    one = HessianAccumulator(K, 'cuda')
+    one.add(x)                                              # 12288 tokens < DIRECT_TOKENS: a one-entry table
+    H1 = one.H.clone()
+    samples = [x[i:i + 1].clone() for i in range(n)]
+    for defer in (True, False):
+        acc = HessianAccumulator(K, 'cuda', defer=defer)
+        acc.timing = []
+        for smp in samples:
+            acc.add(smp)
+        assert torch.equal(acc.H, H1), defer
+        assert len(acc.timing) == 1 and acc.nsamples == n
+    # the C entry point with the flat signature agrees as well
+    from llmc_amd import _ffi
+    L = _ffi.lib()
+    xf = x.reshape(-1, K)
+    ws = _ffi.workspace(L.llmc_hessian_accum_ws_bytes(xf.shape[0], K, K), xf.device)
+    H0 = torch.empty(K, K, dtype=torch.float32, device='cuda')
+    _ffi.check(L.llmc_hessian_accum(_ffi.ptr(H0), _ffi.ptr(xf), _ffi.dt(xf), xf.shape[0], K, K, 0.0, float(n), _ffi.ptr(ws),
+                                    _ffi.stream()), 'llmc_hessian_accum')
+    assert torch.equal(H0, H1)
+
+
+def test_sample_table_ragged_lengths_and_many_samples():
+    """Samples of any length (each walked in 128-token groups, the last one zero-filled by its own descriptor), more
+    samples than one launch takes (several launches, one running mean), short samples (packed), an empty call."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    K = 776
+    gen = torch.Generator().manual_seed(11)
+    lens = [300, 1000, 257, 4096, 129, 640, 2047, 511] + [260 + 3 * i for i in range(200)] + [5, 17, 200, 64]
+    samples = [(torch.randn(1, t, K, generator=gen) * 3).to(torch.bfloat16).cuda() for t in lens]
+    acc = HessianAccumulator(K, 'cuda')
+    acc.timing = []
+    for smp in samples:
+        acc.add(smp)
+    acc.add(torch.empty(1, 0, K, dtype=torch.bfloat16, device='cuda'))      # counts as a batch, adds nothing
+    H = acc.H
+    assert acc.nsamples == len(lens) + 1 and len(acc.timing) >= 2
+    _check_vs_fp64(H, samples, len(lens) + 1)
+    # running mean across flushes: two flushes == what the reference's per-call update converges to
+    acc2 = HessianAccumulator(K, 'cuda')
+    for smp in samples[:100]:
+        acc2.add(smp)
+    acc2.flush()
+    for smp in samples[100:]:
+        acc2.add(smp)
+    _check_vs_fp64(acc2.H, samples, len(lens))
+
+
+def test_sample_table_strided_rows_in_place_and_padding_never_read():
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    T, K, ld = 640, 300, 320
+    gen = torch.Generator().manual_seed(3)
+    bases = []
+    for i in range(3):
+        base = torch.zeros(T, ld, dtype=torch.bfloat16)
+        base[:, :K] = (torch.randint(-3, 4, (T, K), generator=gen)).to(torch.bfloat16)
+        base[:, K:] = 1000.0   # padding must never leak into H
+        bases.append(base.cuda())
+    acc = HessianAccumulator(K, 'cuda')
+    for b in bases:
+        acc.add(b[:, :K])                                   # read in place: row stride 320, 300 channels
+    assert all(src is not None for _, _, src, _ in acc._pending)
+    x = torch.cat([b[:, :K] for b in bases], 0).double().cpu().numpy()
+    exact = (2.0 / 3) * x.T @ x
+    np.testing.assert_allclose(acc.H.cpu().numpy(), exact, rtol=2e-6, atol=1e-4)
+
+
+def test_deferred_sample_modified_before_flush_raises():
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    K = 512
+    x = make_x(512, K, 'bf16', 1).cuda()
+    acc = HessianAccumulator(K, 'cuda')
+    acc.add(x)
+    x.mul_(2)                                               # the producer reuses the buffer
+    with pytest.raises(RuntimeError):
+        acc.H

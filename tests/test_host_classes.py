@@ -87,7 +87,7 @@ def test_gptq_hessian_sharing_needs_the_same_input_tensor(monkeypatch):
     import llmc_amd.compression.quantization.gptq as gq
 
     class FakeAcc:
-        def __init__(self, K, dev):
+        def __init__(self, K, dev, defer=True):
             self.K, self.nsamples, self.fed = K, 0, []
             self.H = torch.zeros(K, K)
 
@@ -134,13 +134,76 @@ def test_gptq_hessian_sharing_needs_the_same_input_tensor(monkeypatch):
         g2.add_batch(qkv['k'], 'k', h.clone(), None)
 
 
+def test_gptq_hessian_sharing_with_skipped_experts_and_pass_ids(monkeypatch):
+    """an expert that receives no token is skipped by the HF / DeepSeek forward, so the members of a
+    subset are called a different number of times. Sharing is keyed on the forward pass (block_forward's counter, or a
+    member being called again), the feeder's tensor stays referenced during the pass, and a member whose first call
+    comes after the group was fed leaves it — it must never inherit (or feed) the router's Hessian."""
+    import llmc_amd.compression.quantization.gptq as gq
+
+    class FakeAcc:
+        def __init__(self, K, dev, defer=True):
+            self.K, self.nsamples, self.fed = K, 0, []
+            self.H = torch.zeros(K, K)
+
+        def add(self, inp):
+            self.fed.append(tuple(inp.shape))
+            self.nsamples += inp.shape[0]
+    monkeypatch.setattr(gq, 'HessianAccumulator', FakeAcc)
+    lin = lambda: torch.nn.Linear(8, 4, bias=False)  # noqa: E731
+    for with_pass_id in (True, False):
+        for e1_first in (False, True):
+            g = gq.GPTQ.__new__(gq.GPTQ)
+            g.layers_cache, g._groups, g._group_of = {}, {}, {}
+            layers = {'gate': lin(), 'e0.w1': lin(), 'e0.w3': lin(), 'e1.w1': lin(), 'e1.w3': lin(), 'e2.w1': lin()}
+            g.subset_init({'layers': layers})
+            # sample 1: the router sends every token to expert 0; sample 2: tokens for experts 0 and 1; expert 2 never runs
+            x1 = torch.randn(1, 6, 8)
+            if with_pass_id:
+                g._fwd_pass = 1
+            for n, x in (('gate', x1), ('e0.w1', x1[:, :6]), ('e0.w3', x1[:, :6])):
+                g.add_batch(layers[n], n, x[:, :4] if n != 'gate' else x, None)
+            x2 = torch.randn(1, 6, 8)
+            # the allocator may hand sample 1's routed buffer to another expert: same pointer / shape / stride
+            r0 = x2[:, :4]
+            r1 = x2[:, 4:]
+            if with_pass_id:
+                g._fwd_pass = 2
+            calls = [('gate', x2), ('e0.w1', r0), ('e0.w3', r0), ('e1.w1', r1), ('e1.w3', r1)]
+            if e1_first and with_pass_id:
+                calls = [calls[3], calls[4], calls[0], calls[1], calls[2]]
+            for n, x in calls:
+                g.add_batch(layers[n], n, x, None)
+            fed = {n: g.layers_cache[n]['acc'].fed for n in layers}
+            assert fed['gate'] == [(1, 6, 8), (1, 6, 8)], (with_pass_id, e1_first, fed['gate'])
+            assert fed['e0.w1'] == [(1, 4, 8), (1, 4, 8)] and fed['e0.w3'] == [(1, 4, 8), (1, 4, 8)]
+            assert fed['e1.w1'] == [(1, 2, 8)] and fed['e1.w3'] == [(1, 2, 8)]
+            accs = {n: id(g.layers_cache[n]['acc']) for n in layers}
+            assert accs['gate'] not in (accs['e1.w1'], accs['e1.w3'], accs['e0.w1'], accs['e0.w3'])
+            assert g.layers_cache['e1.w1']['nsamples'] == 1 and g.layers_cache['gate']['nsamples'] == 2
+            # the expert that never ran still sits in the router's group: settling it gives it an (empty) Hessian of its own
+            assert g._group_of['e2.w1'] == g._group_of['gate']
+            g._settle_group(g._group_of['gate'])
+            assert g._group_of['e2.w1'] != g._group_of['gate'] and g.layers_cache['e2.w1']['acc'].fed == []
+
+
+def test_block_forward_counts_passes():
+    from toy_model import ToyModel, calib_input
+    from llmc_amd.compression.quantization.base_blockwise_quantization import BaseBlockwiseQuantization as B
+    model = ToyModel(hidden=32, inner=48, n_blocks=1, dtype=torch.float32)
+    b = B.__new__(B)
+    b.input = calib_input(model, n_seq=3, seq=4)
+    b.block_forward(model.get_blocks()[0])
+    assert b._fwd_pass == 3
+
+
 def test_true_sequential_first_pass_feeds_only_the_first_subset(monkeypatch):
     """under true_sequential the Hessians of subsets 2.. are re-accumulated after the earlier subsets are
     quantized (base_blockwise_quantization.py:506-526); the first pass must not compute them."""
     import llmc_amd.compression.quantization.gptq as gq
 
     class FakeAcc:
-        def __init__(self, K, dev):
+        def __init__(self, K, dev, defer=True):
             self.K, self.nsamples, self.fed = K, 0, []
             self.H = torch.zeros(K, K)
 
