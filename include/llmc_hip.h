@@ -315,6 +315,13 @@ size_t llmc_awq_clip_search_ws_bytes(int64_t R, int64_t K, int64_t g, int64_t n_
 int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g,
                          int64_t n_tok, int n_grid, int n_shrink, int clip_sym, int sym, float qmin,
                          float qmax, void* best_max, void* best_min, void* ws, llmc_stream_t stream);
+/* The same evaluation, returning the error table instead of its argmin: errs [n_shrink, R, K/g] (dt) = the
+ * token-mean squared output error of every shrink level (auto_clip.py:150-180, `err`). Callers with SEVERAL calibration
+ * batches (auto_clip_layer's `inputs` list) form err_mean = sum_i err_i / len(inputs) and the strict-< argmin
+ * themselves, in the tensor dtype like the reference (auto_clip.py:176-184). */
+int llmc_awq_clip_errs(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g, int64_t n_tok,
+                       int n_grid, int n_shrink, int clip_sym, int sym, float qmin, float qmax, void* errs,
+                       llmc_stream_t stream);
 
 /* apply_clip v1 (auto_clip.py:194-212): W = clamp(W, min, max) per (row, group). */
 int llmc_clamp_groups(void* W, int dt, int64_t R, int64_t K, int64_t g, const void* min_val,

@@ -37,19 +37,48 @@ class AutoClipper:
                     t /= dist.get_world_size()
             self.apply_clip(block_idx, m, min_val, max_val, n)
 
-    @torch.no_grad()
-    def auto_clip_layer(self, block_idx, layer_name, w, inputs, n_grid=20, max_shrink=0.5, n_sample_token=512,
-                        eps=0.0):
-        assert w.dim() == 2 and len(inputs) == 1, 'one calibration batch (calib.bs = -1) is the supported case'
-        x = inputs[0].to(w.device)
+    def _sample_tokens(self, x, i, w, n_sample_token):
+        """auto_clip.py:133-147: flatten, drop padded tokens, every step-th token."""
+        x = x.to(w.device)
         x = x.reshape(-1, x.shape[-1])
-        if self.padding_mask and self.padding_mask[0].numel() == x.shape[0]:
-            x = x[self.padding_mask[0].flatten().bool()]
+        if self.padding_mask and self.padding_mask[i].numel() == x.shape[0]:
+            x = x[self.padding_mask[i].flatten().bool()]
         if n_sample_token is None:
             n_sample_token = min(x.shape[0], 512)
         step = max(1, x.shape[0] // n_sample_token)
-        x = x[0::step].contiguous()
-        return awq_ops.clip_search(w.data, x, self.wquantizer, self.clip_sym, n_grid, max_shrink)
+        return x[0::step].contiguous(), n_sample_token
+
+    @torch.no_grad()
+    def auto_clip_layer(self, block_idx, layer_name, w, inputs, n_grid=20, max_shrink=0.5, n_sample_token=512,
+                        eps=0.0):
+        assert w.dim() == 2
+        if len(inputs) == 1:                    # what run() always passes (it concatenates the batches, auto_clip.py:63-67)
+            x, _ = self._sample_tokens(inputs[0], 0, w, n_sample_token)
+            return awq_ops.clip_search(w.data, x, self.wquantizer, self.clip_sym, n_grid, max_shrink)
+        # several batches (auto_clip.py:130-184): per shrink level err_mean = sum_i err_i / len(inputs) in the model
+        # dtype, strict-< argmin in shrink order; n_sample_token, once derived from the first batch, is kept (:144-145)
+        errs = None
+        for i in range(len(inputs)):
+            x, n_sample_token = self._sample_tokens(inputs[i], i, w, n_sample_token)
+            e = awq_ops.clip_errs(w.data, x, self.wquantizer, self.clip_sym, n_grid, max_shrink)
+            errs = e if errs is None else errs.add_(e)
+        errs /= len(inputs)
+        R, K = w.shape
+        g = self.wquantizer.group_size if self.wquantizer.granularity == 'per_group' else K
+        wg = w.data.reshape(R, K // g, g)
+        org_max = (wg.abs() if self.clip_sym else wg).amax(dim=-1, keepdim=True)
+        org_min = wg.amin(dim=-1, keepdim=True)
+        best_max, best_min = org_max.clone(), org_min.clone()
+        min_errs = torch.ones_like(org_max) * 1e9
+        for i_s in range(errs.shape[0]):
+            max_val = org_max * (1 - i_s / n_grid)
+            min_val = -max_val if self.clip_sym else org_min * (1 - i_s / n_grid)
+            err = errs[i_s].unsqueeze(-1)
+            better = err < min_errs
+            min_errs = torch.where(better, err, min_errs)
+            best_max = torch.where(better, max_val, best_max)
+            best_min = torch.where(better, min_val, best_min)
+        return best_max, best_min
 
     @torch.no_grad()
     def apply_clip(self, block_idx, layer, min_val, max_val, layer_name):

@@ -24,28 +24,28 @@ from .module_utils import (_LLMC_LINEAR_TYPES_, _LLMC_LN_TYPES_, _TRANSFORMERS_L
 
 
 class _hip_linear_forward:
-    """While active, `layers` (plain Linear modules of the inspected module) compute y = x W^T (+ b) with the HIP GEMM
-    (llmc_linear_eval mode 0) instead of the vendor BLAS behind F.linear; shapes the kernel does not take
-    (K % 64 != 0, operands >= 4 GiB) keep the module's own forward."""
+    """While active, `layers` (plain Linear modules of the inspected module) compute y = x W^T (+ b) with the HIP GEMMs
+    (awq_ops.linear_auto) instead of the vendor BLAS behind F.linear: the k-tiled one-wave-per-SIMD kernel where the
+    shape allows it — the activation tensor q / k / v (gate / up) share is packed k-tiled ONCE per grid point, each
+    fake-quantized weight once — else the row-major kernel; shapes neither takes (K % 64 != 0, operands >= 4 GiB) go to
+    the framework's GPU linear (logged once)."""
 
     def __init__(self, layers):
         self.layers = [l for l in layers if isinstance(l, nn.Linear)]
         self.saved = []
+        self.xcache = {}
 
-    @staticmethod
-    def _forward(layer, x):
-        w = layer.weight
-        if not awq_ops.linear_supported(x, w):
-            return nn.functional.linear(x, w, layer.bias)
-        return awq_ops.linear_out(x, w.data, None if layer.bias is None else layer.bias.data)
+    def _forward(self, layer, x):
+        return awq_ops.linear_auto(x, layer.weight.data, None if layer.bias is None else layer.bias.data, self.xcache)
 
     def __enter__(self):
         for l in self.layers:
             self.saved.append((l, l.__dict__.get('forward')))
-            l.forward = (lambda x, _l=l: _hip_linear_forward._forward(_l, x))
+            l.forward = (lambda x, _l=l: self._forward(_l, x))
         return self
 
     def __exit__(self, *exc):
+        self.xcache.clear()
         for l, f in self.saved:
             if f is None:
                 l.__dict__.pop('forward', None)
@@ -182,14 +182,28 @@ class Awq(BaseBlockwiseQuantization):
                     if self.padding_mask and org_out.shape[1] == self.padding_mask[i].shape[-1]:
                         m = self.padding_mask[i].unsqueeze(dim=-1).to(org_out.device)
                         org_out, out = org_out * m, out * m
-                    loss = float(self.calculate_loss(org_out, out))
-                    n_samples = x.shape[0] if len(input) == 1 else self.n_samples
-                    loss_mean += x.shape[0] * 1.0 / n_samples * loss
-                    scales_mean += x.shape[0] * 1.0 / n_samples * scales   # in place from the 2nd batch on: `best_scales` below aliases it, like the reference
+                    loss = self.calculate_loss(org_out, out)
                     for fc, w0 in zip(layers, org_w):      # inspect_module.load_state_dict(org_sd)
                         fc.weight.data = w0
+                    if len(input) == 1:
+                        # one batch (the shipped bs: -1): loss_mean = loss, scales_mean = scales; the 20 losses and
+                        # the running best stay on the device — no host sync per grid point (the reference's .item())
+                        loss = loss.reshape(1).float()
+                        if best_scales is None:
+                            best_err_dev, best_scales = loss, scales
+                        else:
+                            better = loss < best_err_dev
+                            best_scales = torch.where(better, scales, best_scales)
+                            best_err_dev = torch.where(better, loss, best_err_dev)
+                        continue
+                    loss = float(loss)
+                    n_samples = self.n_samples
+                    loss_mean += x.shape[0] * 1.0 / n_samples * loss
+                    scales_mean += x.shape[0] * 1.0 / n_samples * scales   # in place from the 2nd batch on: `best_scales` below aliases it, like the reference
                     if loss_mean < best_error:             # inside the batch loop, like the reference
                         best_error, best_scales = loss_mean, scales_mean
+        if len(input) == 1:
+            return best_scales, best_err_dev
         return best_scales, torch.tensor([best_error], dtype=torch.float32, device=dev)
 
     @torch.no_grad()
@@ -218,7 +232,13 @@ class Awq(BaseBlockwiseQuantization):
         if isinstance(prev_op[0], (nn.Linear, FakeQuantLinear)):
             of, inf = prev_op[0].out_features, layers[0].in_features
             if of not in (inf * 3, inf * 2, inf):
-                return                                                      # awq.py:338-351 (no GQA trans here)
+                if getattr(self, 'has_gqa', False) and getattr(self, 'do_gqa_trans', False):
+                    # awq.py:338-343 transforms v_proj -> o_proj with repeated scales here; not built: refuse loudly
+                    # instead of silently leaving the subset untransformed
+                    raise NotImplementedError('Awq: do_gqa_trans (GQA v_proj -> o_proj scale folding, awq.py:338-343) '
+                                              'is outside the hot path; set special.do_gqa_trans: False')
+                return                                                      # awq.py:344-346: "Cannot apply scale"
+
         scale = self.search_scale_subset(prev_op[0], layers_dict, input_feat[input_name], subset['inspect'], False,
                                          subset_kwargs)
         self.apply_scale(scale, prev_op, layers)

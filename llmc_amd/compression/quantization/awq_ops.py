@@ -1,4 +1,7 @@
 """Functional wrappers over the AWQ entry points of libllmc_hip.so (K8, K9)."""
+import os
+import sys
+
 import torch
 
 from llmc_amd import _ffi
@@ -124,6 +127,42 @@ def linear_out(x, wq, bias=None, tiled=False, blocked=False):
     return y if blocked else y.reshape(*x.shape[:-1], R)
 
 
+_FALLBACK_SEEN = set()
+
+
+def linear_auto(x, w, bias=None, xcache=None):
+    """F.linear(x, w, bias) on the best HIP GEMM the shapes allow — same bits on both HIP routes:
+      * k-tiled operands + the one-wave-per-SIMD kernel (llmc_linear_eval_kt) when K % 128 == 0 and there are enough
+        rows to fill 256-row tiles: x and w are packed k-tiled first (one HBM pass each). `xcache` (a dict owned by the
+        caller) keeps the packed image of the LAST activation tensor, so layers that consume the very same tensor
+        (q / k / v, gate / up inside an inspected module) pack it once;
+      * the row-major 8-wave kernel (llmc_linear_eval) for the remaining supported shapes;
+      * anything else (K % 64 != 0, fp32 activations, operands >= 4 GiB) goes to the framework's GPU linear — said once
+        per shape on stderr, never silently, never the CPU."""
+    R, K = w.shape
+    N = x.numel() // max(1, x.shape[-1])
+    if ktile_supported(x, w) and N >= 512 and os.environ.get('LLMC_AWQ_KT', '1') != '0':
+        key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
+        hit = xcache.get(key) if xcache is not None else None
+        if hit is None:
+            xt = ktile_pack(x)
+            if xcache is not None:
+                xcache.clear()
+                xcache[key] = (x, xt)          # x is kept referenced: its storage cannot be re-used under the key
+        else:
+            xt = hit[1]
+        y = linear_out(xt, ktile_pack(w), bias, tiled=True)
+        return y.reshape(*x.shape[:-1], R)
+    if linear_supported(x, w):
+        return linear_out(x, w, bias)
+    sig = (tuple(x.shape), tuple(w.shape), str(x.dtype), str(w.dtype))
+    if sig not in _FALLBACK_SEEN:
+        _FALLBACK_SEEN.add(sig)
+        print(f'[llmc_amd] linear {sig}: outside the HIP GEMM\'s shape rules (16-bit operands of one dtype, K % 64 == 0, '
+              'operands < 4 GiB) -> torch.nn.functional.linear on the GPU', file=sys.stderr)
+    return torch.nn.functional.linear(x, w if w.dtype == x.dtype else w.to(x.dtype), bias)
+
+
 def unblock_y(yb, N, R):
     """Tile-blocked image (linear_out(..., blocked=True)) -> row-major [N, R]. Index arithmetic in torch, for tests
     and debugging: tile (tm, tn), wave (wm, wn), accumulator (m, n), register r = 8 v + j, lane ->
@@ -192,3 +231,18 @@ def clip_search(w, x, wquantizer, clip_sym, n_grid=20, max_shrink=0.5):
                                       float(wquantizer.qmin), float(wquantizer.qmax), _ffi.ptr(bmax), _ffi.ptr(bmin),
                                       0, _ffi.stream()), 'llmc_awq_clip_search')
     return bmax, bmin
+
+
+def clip_errs(w, x, wquantizer, clip_sym, n_grid=20, max_shrink=0.5):
+    """The error table of clip_search: [n_shrink, R, ng] in the model dtype (auto_clip.py:150-180 `err` per shrink level)."""
+    _ffi.require_gpu(w, x)
+    L = _ffi.lib()
+    w, x = w.contiguous(), x.reshape(-1, x.shape[-1]).contiguous()
+    R, K = w.shape
+    g = wquantizer.group_size if wquantizer.granularity == 'per_group' else K
+    ns = int(max_shrink * n_grid)
+    errs = torch.empty((ns, R, K // g), dtype=w.dtype, device=w.device)
+    _ffi.check(L.llmc_awq_clip_errs(_ffi.ptr(w), _ffi.ptr(x), _ffi.dt(w), R, K, g, x.shape[0], int(n_grid), ns,
+                                    int(bool(clip_sym)), int(wquantizer.sym), float(wquantizer.qmin),
+                                    float(wquantizer.qmax), _ffi.ptr(errs), _ffi.stream()), 'llmc_awq_clip_errs')
+    return errs

@@ -11,18 +11,17 @@ from .quant import pack_awq_gemm, pack_lsb
 
 
 def hip_linear(x, weight, bias):
-    """y = x W^T + b for the fake-quant wrappers (module_utils.py:619-644, 706-741): the HIP MFMA GEMM
-    (llmc_linear_eval mode 0, fp32 accumulation, one rounding) where its shape rules hold; GPU shapes it does not
-    take (K % 64 != 0, fp32 activations, operands >= 4 GiB) use the framework's GPU linear. Never the CPU."""
+    """y = x W^T + b for the fake-quant wrappers (module_utils.py:619-644, 706-741): the HIP MFMA GEMMs
+    (awq_ops.linear_auto: k-tiled one-wave-per-SIMD kernel for large inputs, row-major kernel otherwise; fp32
+    accumulation, one rounding); GPU shapes they do not take (K % 64 != 0, fp32 activations, operands >= 4 GiB) use the
+    framework's GPU linear, logged once per shape. Never the CPU."""
     from llmc_amd import _ffi
 
     from . import awq_ops
     _ffi.require_gpu(x, weight)
     if weight.dtype != x.dtype:
         weight = weight.to(x.dtype)
-    if awq_ops.linear_supported(x, weight):
-        return awq_ops.linear_out(x, weight, bias)
-    return torch.nn.functional.linear(x, weight, bias)
+    return awq_ops.linear_auto(x, weight, bias)
 
 
 def _func_name(f):

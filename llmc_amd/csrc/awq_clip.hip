@@ -59,6 +59,7 @@ struct ClipArgs {
     float qmin, qmax;
     void* best_max;  // [R, ng]
     void* best_min;
+    void* errs;      // optional [n_shrink, R, ng] dt: the mean error of every shrink level (multi-batch callers)
 };
 
 template <typename T>
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
         float min_err = rndc<DT>(1e9f);
         for (int s = 0; s < ns; ++s) {
             const float e = rndc<DT>(esum_all[rr * CMAXS + s + 1] / (float)a.n_tok);
+            if (a.errs) ((T*)a.errs)[((int64_t)s * a.R + row) * a.ng + gi] = from_f32<T>(e);
             const float f = (float)(1.0 - (double)s / (double)a.n_grid);
             const float mx = rndc<DT>(org_max * f);
             const float mn = a.clip_sym ? -mx : rndc<DT>(org_min * f);
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
                 best_mn = mn;
             }
         }
-        ((T*)a.best_max)[row * a.ng + gi] = from_f32<T>(best_mx);
-        ((T*)a.best_min)[row * a.ng + gi] = from_f32<T>(best_mn);
+        if (a.best_max) ((T*)a.best_max)[row * a.ng + gi] = from_f32<T>(best_mx);
+        if (a.best_min) ((T*)a.best_min)[row * a.ng + gi] = from_f32<T>(best_mn);
     }
 }
 
@@ -202,11 +204,31 @@ using namespace llmc;
 
 extern "C" size_t llmc_awq_clip_search_ws_bytes(int64_t R, int64_t K, int64_t g, int64_t n_tok) { return 0; }
 
+static int clip_launch(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g, int64_t n_tok, int n_grid,
+                       int n_shrink, int clip_sym, int sym, float qmin, float qmax, void* best_max, void* best_min,
+                       void* errs, llmc_stream_t stream);
+
 extern "C" int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g,
                                     int64_t n_tok, int n_grid, int n_shrink, int clip_sym, int sym, float qmin,
                                     float qmax, void* best_max, void* best_min, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(best_max && best_min, "awq_clip_search: null output");
+    (void)ws;
+    return clip_launch(W, X, dt, R, K, g, n_tok, n_grid, n_shrink, clip_sym, sym, qmin, qmax, best_max, best_min, nullptr,
+                       stream);
+}
+
+extern "C" int llmc_awq_clip_errs(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g, int64_t n_tok,
+                                  int n_grid, int n_shrink, int clip_sym, int sym, float qmin, float qmax, void* errs,
+                                  llmc_stream_t stream) {
+    LLMC_REQUIRE(errs, "awq_clip_errs: null output");
+    return clip_launch(W, X, dt, R, K, g, n_tok, n_grid, n_shrink, clip_sym, sym, qmin, qmax, nullptr, nullptr, errs, stream);
+}
+
+static int clip_launch(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g, int64_t n_tok, int n_grid,
+                       int n_shrink, int clip_sym, int sym, float qmin, float qmax, void* best_max, void* best_min,
+                       void* errs, llmc_stream_t stream) {
     LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "awq_clip_search: dtype must be f16 or bf16");
-    LLMC_REQUIRE(W && X && best_max && best_min && R > 0 && K > 0 && n_tok > 0, "awq_clip_search: null/empty argument");
+    LLMC_REQUIRE(W && X && R > 0 && K > 0 && n_tok > 0, "awq_clip_search: null/empty argument");
     if (g <= 0) g = K;
     if (g > CG || K % g != 0 || n_shrink < 1 || n_shrink > CMAXS - 1 || n_grid < 1) {
         set_last_error_msg("awq_clip_search: needs group_size <= 128 dividing K and 1..11 shrink steps");
@@ -216,7 +238,7 @@ extern "C" int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_
     ClipArgs a;
     a.W = W; a.X = X; a.R = R; a.K = K; a.g = (int)g; a.ng = (int)(K / g); a.n_tok = (int)n_tok;
     a.n_grid = n_grid; a.n_shrink = n_shrink; a.clip_sym = clip_sym; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
-    a.best_max = best_max; a.best_min = best_min;
+    a.best_max = best_max; a.best_min = best_min; a.errs = errs;
     const size_t lds = (size_t)CG * CTOK * 2 + (size_t)(4 * CMAXS * CG + CROWS * CMAXS) * sizeof(float);
     dim3 grid((unsigned)a.ng, (unsigned)ceil_div64(R, CROWS));
     if (dt == LLMC_F16) {

@@ -432,10 +432,12 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
         for (int g = 0; g < ngroups - 1; ++g) turn(std::integral_constant<int, 0>{});
         if (ngroups > 0) turn(std::integral_constant<int, STAGE_Y != 0 ? 2 : 1>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef LLMC_LAB
         if (a.mode == 2) {   // lab (LLMC_LIN_ABL=1): the main loop alone, nothing stored
             __builtin_amdgcn_s_barrier();
             continue;
         }
+#endif
 
         if constexpr (STAGE_Y != 0) {
             // loss epilogue: the Y0 tile (256 x 512 B) arrived in the ring during the last turn; every lane picks its 256
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             // behind its own s_waitcnt: ~40 % of the tile time.)
             l4_vmwait<0>();
             if constexpr (STAGE_Y == 1) __builtin_amdgcn_s_barrier();   // blocked: a wave reads only what it requested itself
+#ifdef LLMC_LAB
             if (a.y0_lds == 2) { __syncthreads(); continue; }   // lab (LLMC_LIN_ABL=3): Y0 staged and waited for, not folded
+#endif
             const int ybase = (wm * 128 + 4 * (lane >> 5)) * 512 + (wn * 128 + (lane & 31)) * 2;
             const int yown = wv * 8192 + lane * 16;
             const int64_t col0 = (int64_t)tn * LT + wn * 128 + (lane & 31);
@@ -706,12 +710,14 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr;
     a.y0_lds = mode == 1 && !yblk && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
     int stage = mode == 1 ? (yblk ? 2 : a.y0_lds ? 1 : 0) : 0;
-    if (const char* e = getenv("LLMC_LIN_ABL")) {   // lab switches, never set by the package
+#ifdef LLMC_LAB   // lab builds only (tools/probes): wrong losses by design, never compiled into the shipped library
+    if (const char* e = getenv("LLMC_LIN_ABL")) {
         const int v = atoi(e);
         if (v == 1) { a.mode = 2; a.y0_lds = 0; stage = 0; }      // main loop only
         if (v == 2 && stage == 1) { a.y0_lds = 0; stage = 0; }    // row-major Y0 straight from global
         if (v == 3 && stage) a.y0_lds = 2;                        // Y0 staged and waited for, not folded
     }
+#endif
     const bool bf = dt == LLMC_BF16;
     const void* fn = stage == 2 ? (bf ? (const void*)k_linear_eval4<LLMC_BF16, 2> : (const void*)k_linear_eval4<LLMC_F16, 2>)
                    : stage == 1 ? (bf ? (const void*)k_linear_eval4<LLMC_BF16, 1> : (const void*)k_linear_eval4<LLMC_F16, 1>)

@@ -99,31 +99,36 @@ def search_scale(weights, x, dt, sym, qmin, qmax, group_size, version='v2', n_gr
 # ---- AutoClipper (llmc/compression/quantization/auto_clip.py:84-191, clip_version v1, w_only) ------------
 def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid=20, max_shrink=0.5,
                     n_sample_token=512):
-    """w [R,K], x [tokens,K] (values of dtype dt). Returns (best_max [R, ng, 1], best_min [R, ng, 1]).
+    """w [R,K], x [tokens,K] (values of dtype dt) or a LIST of such batches (auto_clip.py:130-184: the error is averaged
+    over the list in dt). Returns (best_max [R, ng, 1], best_min [R, ng, 1]).
     Per (row, group), for i_s in range(int(max_shrink * n_grid)):
         max = org_max * (1 - i_s / n_grid) ; min = -max (clip_sym) | org_min * (1 - i_s / n_grid)
         q_w = fakequant_dyn(clamp(w, min, max)) ; err = mean_tok((sum_k x*q_w - sum_k x*w)^2)   -> argmin.
-    All arithmetic in dt; `x * w` is rounded per product, the k-sum and the token mean accumulate in fp32."""
+    All arithmetic in dt; `x * w` is rounded per product, the k-sum and the token mean accumulate in fp32 (ATen casts
+    16-bit means to fp32, sums, divides and rounds once). Pinned 100 % to tests/golden/clip.npz and clip_mb.npz."""
     w = np.asarray(w, dtype=np.float32)
-    x = np.asarray(x, dtype=np.float32).reshape(-1, w.shape[1])
     R, K = w.shape
     g = group_size or K
     ng = K // g
-    step = max(1, x.shape[0] // n_sample_token)
-    x = x[0::step]                                   # auto_clip.py:146-147
-    xg = x.reshape(x.shape[0], ng, g)                # [tok, ng, g]
+    xs = x if isinstance(x, (list, tuple)) else [x]
+    xgs = []
+    for xi in xs:
+        xi = np.asarray(xi, dtype=np.float32).reshape(-1, K)
+        step = max(1, xi.shape[0] // n_sample_token)
+        xi = xi[0::step]                              # auto_clip.py:146-147
+        xgs.append(xi.reshape(xi.shape[0], ng, g))    # [tok, ng, g]
     wg = w.reshape(R, ng, g)
     org_max = np.abs(wg).max(axis=-1, keepdims=True) if clip_sym else wg.max(axis=-1, keepdims=True)
     org_min = wg.min(axis=-1, keepdims=True)
 
-    def out_of(wq):   # (x * w).sum(-1): [R, tok, ng]
+    def out_of(xg, wq):   # (x * w).sum(-1): [R, tok, ng]
         o = np.empty((R, xg.shape[0], ng), dtype=np.float32)
         for r in range(R):
             prod = rnd(xg * wq[r][None], dt)         # [tok, ng, g]
             o[r] = rnd(prod.sum(axis=-1, dtype=np.float32), dt)
         return o
 
-    org_out = out_of(wg)
+    org_outs = [out_of(xg, wg) for xg in xgs]
     best_max, best_min = org_max.copy(), org_min.copy()
     with np.errstate(over='ignore'):
         min_errs = rnd(np.full_like(org_max, 1e9), dt)
@@ -133,13 +138,16 @@ def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid
         min_val = -max_val if clip_sym else rnd(org_min * f, dt)
         cur_w = np.minimum(np.maximum(wg, min_val), max_val)
         qw, _, _ = Q.fake_quant_dynamic(cur_w.reshape(-1, g), dt, sym, qmin, qmax)
-        cur_out = out_of(qw.reshape(R, ng, g))
-        d = rnd(cur_out - org_out, dt)
-        sq = rnd(d * d, dt)
-        err = rnd(sq.sum(axis=1, dtype=np.float32) / np.float32(sq.shape[1]), dt).reshape(R, ng, 1)
-        # err_mean = 0 + err ; /= len(inputs) (1)
-        better = err < min_errs
-        min_errs = np.where(better, err, min_errs)
+        err_mean = None
+        for xg, org_out in zip(xgs, org_outs):
+            cur_out = out_of(xg, qw.reshape(R, ng, g))
+            d = rnd(cur_out - org_out, dt)
+            sq = rnd(d * d, dt)
+            err = rnd(sq.sum(axis=1, dtype=np.float32) / np.float32(sq.shape[1]), dt).reshape(R, ng, 1)
+            err_mean = err if err_mean is None else rnd(err_mean + err, dt)      # err_mean = 0; err_mean += err
+        err_mean = rnd(err_mean / np.float32(len(xgs)), dt)                      # err_mean /= len(inputs)
+        better = err_mean < min_errs
+        min_errs = np.where(better, err_mean, min_errs)
         best_max = np.where(better, max_val, best_max)
         best_min = np.where(better, min_val, best_min)
     return best_max, best_min

@@ -601,6 +601,35 @@ def suite_clip():
     save('clip', **out)
 
 
+def suite_clip_mb():
+    """AutoClipper.auto_clip_layer called with SEVERAL batches (auto_clip.py:130-184: err_mean over the list) — run() itself
+    always concatenates, so this pins the list form of the method's own surface."""
+    from llmc.compression.quantization.auto_clip import AutoClipper
+    out = {}
+    gen = torch.Generator().manual_seed(123)
+    cfgs = [('bf16_sym_g128_clipsym_3b', 'bf16', True, 128, True, 3), ('f16_asym_g64_noclipsym_2b', 'f16', False, 64, False, 2)]
+    for name, dt, sym, gs, clip_sym, nb in cfgs:
+        R, K, T = 64, 256, 80
+        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+        ac = AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v1', clip_sym=clip_sym,
+                         save_clip=False, padding_mask=None)
+        wt = torch.randn(R, K, generator=gen) * 0.02
+        wt[torch.rand(R, K, generator=gen) < 0.01] *= 8
+        w = wt.to(DT[dt])
+        c = torch.exp(0.5 * torch.randn(K, generator=gen))
+        xs = [(torch.randn(2, T // 2, K, generator=gen) * c).to(DT[dt]) for _ in range(nb)]
+        mx, mn = ac.auto_clip_layer(0, 'fc', w, [x.clone() for x in xs], n_sample_token=20)
+        p = name + '/'
+        out[p + 'w'] = f32(w)
+        for i, x in enumerate(xs):
+            out[p + f'x{i}'] = f32(x)
+        out[p + 'best_max'], out[p + 'best_min'] = f32(mx), f32(mn)
+        out[p + 'meta'] = np.array([int(sym), gs, int(clip_sym), 20, nb], dtype=np.int64)
+        out[p + 'dt'] = np.array(dt)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('clip_mb', **out)
+
+
 def suite_fp8():
     """FloatQuantizer e4m3 weight path. qtorch is not installed/vendored: float_quantize is bound to torch's own
     float8_e4m3fn round trip (the cast the reference's real-quant path ends in), which is what the oracle pins."""
@@ -924,7 +953,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

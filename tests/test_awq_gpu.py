@@ -149,6 +149,7 @@ def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape):
 
 
 def test_clip_search_matches_reference_golden():
+    """Every (row, group) gets the reference's clip level (auto_clip.py:84-191); the clamped weights follow bit for bit."""
     from llmc_amd.compression.quantization import awq_ops
     g = load_golden('clip')
     for name in [str(n) for n in g['names']]:
@@ -162,11 +163,10 @@ def test_clip_search_matches_reference_golden():
         w = dev(g[p + 'w'], dt)
         mx, mn = awq_ops.clip_search(w, xd, q, bool(clip_sym))
         ref_mx, ref_mn = g[p + 'best_max'], g[p + 'best_min']
-        agree = (host(mx) == ref_mx).mean()
-        assert agree >= 0.95, (name, agree)   # sequential k-sum on the GPU vs ATen's vectorised order: rare ties flip
-        assert (host(mn) == ref_mn).mean() >= 0.95, name
+        assert (host(mx) == ref_mx).mean() == 1.0, (name, (host(mx) == ref_mx).mean())
+        assert (host(mn) == ref_mn).mean() == 1.0, name
         awq_ops.clamp_groups_(w, mn if not clip_sym else -mx, mx, gs)
-        assert (host(w) == g[p + "clipped"]).mean() >= 0.995, name
+        np.testing.assert_array_equal(host(w), g[p + "clipped"], err_msg=name)
 
 
 def test_clip_search_many_tokens_vs_oracle():
@@ -180,7 +180,27 @@ def test_clip_search_many_tokens_vs_oracle():
     mx, mn = awq_ops.clip_search(w.to(torch.bfloat16).cuda(), x.to(torch.bfloat16).cuda(), q, True)
     rmx, rmn = A.auto_clip_layer(w.to(torch.bfloat16).float().numpy(), x.to(torch.bfloat16).float().numpy(), 'bf16',
                                  True, -8.0, 7.0, 128, True, n_sample_token=T)
-    assert (host(mx) == rmx).mean() >= 0.95
+    # fp32 summation order over 700 tokens (GPU lanes vs numpy) can move an error by one ulp of its 16-bit rounding
+    # between two near-equal shrink levels; everything else is the same arithmetic
+    assert (host(mx) == rmx).mean() >= 0.995
+
+
+def test_auto_clip_layer_with_several_batches_matches_reference_golden():
+    """auto_clip_layer's list form (auto_clip.py:130-184): per-batch error tables from the kernel (llmc_awq_clip_errs),
+    averaged in the model dtype, strict-< argmin — the reference's levels for every (row, group)."""
+    from llmc_amd.compression.quantization.auto_clip import AutoClipper
+    g = load_golden('clip_mb')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        sym, gs, clip_sym, nst, nb = [int(v) for v in g[p + 'meta']]
+        dt = str(g[p + 'dt'])
+        ac = AutoClipper(w_only=True, wquantizer=make_q(sym, gs), aquantizer=None, clip_version='v1', clip_sym=bool(clip_sym),
+                         save_clip=False, padding_mask=None)
+        w = dev(g[p + 'w'], dt)
+        xs = [dev(g[p + f'x{i}'], dt) for i in range(nb)]
+        mx, mn = ac.auto_clip_layer(0, 'fc', w, xs, n_sample_token=nst)
+        assert (host(mx) == g[p + 'best_max']).mean() == 1.0, (name, (host(mx) == g[p + 'best_max']).mean())
+        assert (host(mn) == g[p + 'best_min']).mean() == 1.0, name
 
 
 def test_fp8_vs_reference_golden():

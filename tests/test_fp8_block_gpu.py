@@ -1,7 +1,8 @@
 """§8(f) rank 4 — FP8 block-wise (DeepSeek-V3 layout) on MI355X: FloatQuantizer `per_block` and the reference's
 weight_cast_to_fp8 / weight_cast_to_bf16 bit-exact against goldens produced by the reference's own (non-Triton) code;
-act_quant / fp8_gemm / block_wise_fp8_forward_func against the restatement of kernel.py in oracle/quant_ref.py
-(the Triton kernels cannot run in the build container: parity unpinned for those, said so here and in DESIGN.md)."""
+act_quant / weight_cast_to_fp8 / fp8_gemm against goldens produced by the reference's own Triton kernels run unmodified
+on an MI355X (tests/golden/fp8_triton.npz, tools/fp8_triton_golden.py) and against the restatement of kernel.py in
+oracle/quant_ref.py, which those goldens pin (tests/test_oracle_golden.py)."""
 import numpy as np
 import pytest
 import torch
@@ -109,3 +110,33 @@ def test_llmc_fp8_linear_forward():
     full = x.float() @ w.float().T + m.bias.data.float()
     assert ((y.float() - full).norm() / full.norm()).item() < 0.06
     assert 'LlmcFp8Linear' in repr(m) and m.weight.dtype == torch.float8_e4m3fn
+
+
+def _from16(bits, dt):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(TD[dt])
+
+
+def test_triton_only_ops_match_goldens_of_the_reference_triton_kernels():
+    """kernel.py:7-242 as executed by the reference itself (Triton on ROCm, this GPU model): our HIP act_quant and
+    weight_cast_to_fp8 give the same fp8 codes and fp32 scales bit for bit (the 0 / 0 block included); the block-scaled
+    GEMM gives the same bf16 output up to one rounding of fp32 sums taken in a different order."""
+    from llmc_amd.compression.quantization import kernel as KN
+    g = load_golden('fp8_triton')
+    for dt in ('bf16', 'f16'):
+        x = _from16(g[f'aq_{dt}_x16'], dt).cuda()
+        y, s = KN.act_quant(x, 128)
+        np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), g[f'aq_{dt}_scales'].view(np.uint32))
+        np.testing.assert_array_equal(y.view(torch.uint8).cpu().numpy(), g[f'aq_{dt}_bits'])
+    for i in range(int(g['n_gemm'])):
+        p = f'g{i}_'
+        x, w = _from16(g[p + 'x16'], 'bf16').cuda(), _from16(g[p + 'w16'], 'bf16').cuda()
+        a8, a_s = KN.act_quant(x, 128)
+        w8, w_s = KN.weight_cast_to_fp8(w, 128)
+        np.testing.assert_array_equal(a8.view(torch.uint8).cpu().numpy(), g[p + 'a_bits'])
+        np.testing.assert_array_equal(a_s.cpu().numpy().view(np.uint32), g[p + 'a_s'].view(np.uint32))
+        np.testing.assert_array_equal(w8.view(torch.uint8).cpu().numpy(), g[p + 'w_bits'])
+        np.testing.assert_array_equal(w_s.cpu().numpy().view(np.uint32), g[p + 'w_s'].view(np.uint32))
+        c = KN.fp8_gemm(a8, a_s, w8, w_s).float().cpu().numpy()
+        cref = _from16(g[p + 'c_bf16_16'], 'bf16').float().numpy()
+        assert (np.abs(c - cref) <= 2.0 ** -7 * np.abs(cref) + 1e-4 * np.abs(cref).max()).all()
+        assert (c == cref).mean() > 0.97        # the single bf16 rounding hides almost every fp32-order difference

@@ -73,13 +73,13 @@ def main():
     dev = torch.device('cuda', 0)
     cores = os.cpu_count() or 1
     if a.quick:
-        shapes = [('tiny 256x512', 256, 512, 8, 256, [('ref_cpu', 4), ('ref_cpu', cores), ('ref_rocm', 0), ('ours', 0)])]
+        shapes = [('tiny 256x512', 256, 512, 8, 256, [('ref_cpu', 4), ('ref_cpu', 8), ('ref_rocm', 0), ('ours', 0)])]
     else:
         shapes = [
             ('q_proj 4096x4096, 128x2048 tokens', 4096, 4096, 128, 2048,
-             [('ref_cpu', 16), ('ref_cpu', cores), ('ref_rocm', 0), ('ours', 0)]),
+             [('ref_cpu', 16), ('ref_cpu', 32), ('ref_rocm', 0), ('ours', 0)]),
             ('down_proj 4096x14336, 32x2048 tokens', 4096, 14336, 32, 2048,
-             [('ref_cpu', cores), ('ref_rocm', 0), ('ours', 0)]),
+             [('ref_cpu', 32), ('ref_rocm', 0), ('ours', 0)]),
         ]
     report = {'cores': cores, 'torch': torch.__version__, 'shapes': []}
     lines = []
@@ -98,7 +98,11 @@ def main():
             if thr:
                 cmd += ['--threads', str(thr)]
             t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                lines.append(f'[{title}] arm {key} TIMED OUT (> 420 s)')
+                continue
             if r.returncode != 0:
                 lines.append(f'[{title}] arm {key} FAILED: {(r.stderr or r.stdout)[-600:]}')
                 continue
