@@ -43,7 +43,7 @@ static constexpr int TILE_FLOATS = TM * TM;
 static constexpr int GROUP_TOK = 128;            // tokens per group = one turn of the 4-slot ring of 32-token stages
 static constexpr int SYRK_MAX_SAMPLES = 192;     // table entries per launch (the whole argument block stays < 4 KiB)
 static constexpr int SYRK_MAX_CHUNKS = 32;
-static constexpr int SYRK_UNIT_SAMPLES = 64;     // samples one unit may cross (one per lane)
+static constexpr int SYRK_UNIT_SAMPLES = 64;     // samples one unit may cross (one per lane; the kernel clamps at 63)
 
 struct TileIdx {
     int bi, bj;
@@ -103,7 +103,7 @@ struct SyrkArgs {
     int pad_;
     float* part;       // [S * ntiles_p][256*256] fp32, fragment order
     unsigned* sync;    // round barrier counter (zeroed before the launch), or null
-    uint32_t cb[SYRK_MAX_CHUNKS + 1];   // chunk s = groups [cb[s], cb[s + 1]) of the padded token axis
+    uint32_t cb[SYRK_MAX_CHUNKS + 1];   // chunk s = groups [cb[s], cb[s + 1]) of the padded token axis (even boundaries)
     uint32_t ci[SYRK_MAX_CHUNKS + 1];   // the sample that holds group cb[s]
     SyrkSample smp[SYRK_MAX_SAMPLES];
 };
@@ -245,31 +245,40 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             const SyrkSample e = a.smp[li];
             const int64_t srel = ((int64_t)e.g0 - (int64_t)gb) * group_bytes;   // unit-relative offset of its first row
             const uint64_t vb = e.base - (uint64_t)srel;
-            const int64_t endb = srel + (int64_t)e.T * row_bytes;               // ... of the end of its last row
+            int64_t endb = srel + (int64_t)e.T * row_bytes;                     // ... of the end of its last row
+            const int64_t unit_end = (int64_t)ngroups * group_bytes;            // nothing past the chunk is ever read: the
+            if (endb > unit_end) endb = unit_end;                               // run-ahead requests and the padding group come back as zeros
             const uint32_t nrec = (!ok || endb <= 0) ? 0u : (endb > 0xffffffffll ? 0xffffffffu : (uint32_t)endb);
             v0 = (int)(uint32_t)vb;
             v1 = (int)((uint32_t)(vb >> 32) & 0xffffu);                         // stride 0
             v2 = (int)nrec;
             vend = ok ? (int)((int64_t)e.g0 + (int64_t)((e.T + GROUP_TOK - 1) / GROUP_TOK) - (int64_t)gb) : 0x7fffffff;
         }
-        // rsrcC: the sample of the current group, rsrcN: of the next one
-        int rel = 0;
+        // two descriptor sets that swap roles every group: in an even group dA is the current group's sample and dB the
+        // next group's, in an odd group the other way round. The set of group g is dead after the group's first burst
+        // and is then rebuilt for group g + 2 from the lane table, its few scalar instructions placed in MFMA gaps that
+        // carry neither a fragment read nor a DMA piece (one wave per SIMD: every issue slot outside a gap is lost).
+        int rel = __builtin_amdgcn_readfirstlane(0);     // lane of the sample the most recently built descriptor is in
         int cur_end = __builtin_amdgcn_readlane(vend, 0);
-        i32x4 rsrcC, rsrcN;
-        rsrcC[0] = __builtin_amdgcn_readlane(v0, 0);
-        rsrcC[1] = __builtin_amdgcn_readlane(v1, 0);
-        rsrcC[2] = __builtin_amdgcn_readlane(v2, 0);
-        rsrcC[3] = 0x00020000;
+        i32x4 dA, dB;
+        dA[0] = __builtin_amdgcn_readlane(v0, 0);
+        dA[1] = __builtin_amdgcn_readlane(v1, 0);
+        dA[2] = __builtin_amdgcn_readlane(v2, 0);
+        dA[3] = 0x00020000;
         {
-            rel += (1 >= cur_end) ? 1 : 0;
-            const int rc = rel < SYRK_UNIT_SAMPLES ? rel : SYRK_UNIT_SAMPLES - 1;
-            rsrcN[0] = __builtin_amdgcn_readlane(v0, rc);
-            rsrcN[1] = __builtin_amdgcn_readlane(v1, rc);
-            rsrcN[2] = __builtin_amdgcn_readlane(v2, rc);
-            rsrcN[3] = 0x00020000;
+            int rc;
+            const int one = __builtin_amdgcn_readfirstlane(1);
+            asm volatile("s_cmp_ge_i32 %2, %3\n\ts_addc_u32 %0, %0, 0\n\ts_min_i32 %1, %0, 63"
+                         : "+s"(rel), "=s"(rc) : "s"(one), "s"(cur_end) : "scc");
+            dB[0] = __builtin_amdgcn_readlane(v0, rc);
+            dB[1] = __builtin_amdgcn_readlane(v1, rc);
+            dB[2] = __builtin_amdgcn_readlane(v2, rc);
+            dB[3] = 0x00020000;
             cur_end = __builtin_amdgcn_readlane(vend, rc);
         }
-        asm volatile("s_nop 4" ::: "memory");   // VALU-written SGPRs (v_readlane) -> buffer descriptor of the asm pieces
+        // VALU-written SGPRs (v_readlane) must be 5 wait states old before a VMEM instruction reads them as a descriptor;
+        // the pieces are inline asm the hazard recogniser cannot see into. The operands tie the pad to the descriptors.
+        asm volatile("s_nop 4" : "+s"(dA[0]), "+s"(dA[1]), "+s"(dA[2]), "+s"(dB[0]), "+s"(dB[1]), "+s"(dB[2]));
         // a diagonal tile loads its panel into both LDS panels (vB == vA): the loop below never branches
         const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
         const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
@@ -288,15 +297,14 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) sA[q] = sB[q] = (uint32_t)q * slab;
             // piece d of the stage in ring slot SL: d = 0..3 A-panel KiB-block (d*4 + wv), d = 4..7 the same of B;
-            // CUR: the stage belongs to the current group (else to the next one)
-            auto piece = [&](auto slc, auto dc, auto curc) {
+            // `rs`: the descriptor of the sample the stage's group lies in
+            auto piece = [&](auto slc, auto dc, const i32x4& rs) {
                 constexpr int SL = decltype(slc)::value;
                 constexpr int d = decltype(dc)::value;
-                constexpr bool CUR = decltype(curc)::value;
                 if constexpr (DMA) {
                     constexpr int DSTB = SL * S4_STAGE + (d >> 2) * S4_PANEL + (d & 3) * 4 * 1024;
-                    if constexpr (d < 4) dma16w<DSTB, LOAD, ADV>(CUR ? rsrcC : rsrcN, vA, sA[d & 3], stage_bytes, wvoff);
-                    else dma16w<DSTB, LOAD, ADV>(CUR ? rsrcC : rsrcN, vB, sB[d & 3], stage_bytes, wvoff);
+                    if constexpr (d < 4) dma16w<DSTB, LOAD, ADV>(rs, vA, sA[d & 3], stage_bytes, wvoff);
+                    else dma16w<DSTB, LOAD, ADV>(rs, vB, sB[d & 3], stage_bytes, wvoff);
                 }
             };
             s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
@@ -337,27 +345,26 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             };
             // one burst: 16 MFMAs on (fa, fb). Behind MFMA i: i in {0,1,2,4,5,6,8,9} -> the next fragment of slice kk
             // of slot RSL into (na, nb) (all eight are back six MFMAs before the burst ends); i in {3,7,11,15} ->
-            // LDS-DMA piece D0 + i/4 of slot DSL (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread)
+            // LDS-DMA piece D0 + i/4 of slot DSL (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread);
+            // i in {10,12,13,14} -> `extra(i)`: scalar bookkeeping that must not cost an issue slot of its own
             auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, int rd_kk,
-                             auto dslc, auto d0c, auto curc) {
+                             auto dslc, auto d0c, const i32x4& rs, auto&& extra) {
                 constexpr int D0 = decltype(d0c)::value;
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     // serpentine walk of the 4x4 accumulator block: one operand changes per step
                     constexpr int mi = i >> 2, ni = (mi & 1) ? 3 - (i & 3) : (i & 3);
                     acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
-                    if constexpr ((i & 3) == 3) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{}, curc);
+                    if constexpr ((i & 3) == 3) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{}, rs);
                     else if constexpr (i < 10) frag(rslc, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
+                    else extra(ic);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
-            // prologue: stages 0 .. NSLOT-2 and the A half of stage NSLOT-1 (all of group 0) requested, stage 0 published
-            static_for<0, NSLOT - 1>([&](auto slc) { static_for<0, 8>([&](auto dc) { piece(slc, dc, std::true_type{}); }); });
-            static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, NSLOT - 1>{}, dc, std::true_type{}); });
-            dma_wait_upto<(NSLOT - 2) * PER + PER / 2>();
-            __builtin_amdgcn_s_barrier();
-            static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, 0, fc, fa0, fb0); });
-            for (int g = 0; g < ngroups; ++g) {
+            auto nothing = [](auto) {};
+            // one group (ring turn) g: `cur` = descriptor of group g, `nxt` = of group g + 1; `cur` is rebuilt for group
+            // g + 2 behind the second burst of the group's first stage
+            auto group = [&](i32x4& cur, const i32x4& nxt, int g) {
                 static_for<0, NSLOT>([&](auto jc) {
                     constexpr int J = decltype(jc)::value;              // stage st = g*NSLOT + J sits in slot J
                     constexpr int JN = (J + 1) % NSLOT;                 // slot of stage st+1
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                     // slice 0 of stage st; fetches slice 1; requests the B half of stage st+NSLOT-1 (J = 0: the last
                     // stage of this group, otherwise a stage of the next group)
                     burst(fa0, fb0, fa1, fb1, jc, 1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{},
-                          std::integral_constant<bool, J == 0>{});
+                          J == 0 ? cur : nxt, nothing);
                     // this wave's pieces of stage st+1 have landed (NSLOT-2 later stages may still be in flight);
                     // every wave has read the whole of stage st once its lgkmcnt(0) is behind the barrier
                     dma_wait_upto<(NSLOT - 2) * PER>();
@@ -374,18 +381,39 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     // slice 1; fetches slice 0 of stage st+1; requests the A half of stage st+NSLOT (next group) into slot J
-                    burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{},
-                          std::false_type{});
+                    if constexpr (J == 0) {
+                        int rc = 0;
+                        burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{}, nxt,
+                              [&](auto ic) {
+                                  constexpr int i = decltype(ic)::value;
+                                  if constexpr (i == 10) {      // group g + 2 starts a new sample iff it lies at or past the end
+                                      const int g2 = g + 2;     // of the sample group g + 1 is in. Three SALU instructions
+                                      asm volatile("s_cmp_ge_i32 %2, %3\n\ts_addc_u32 %0, %0, 0\n\ts_min_i32 %1, %0, 63"
+                                                   : "+s"(rel), "=s"(rc) : "s"(g2), "s"(cur_end) : "scc");
+                                  } else if constexpr (i == 12) {
+                                      cur[0] = __builtin_amdgcn_readlane(v0, rc);
+                                      cur[1] = __builtin_amdgcn_readlane(v1, rc);
+                                  } else if constexpr (i == 13) {
+                                      cur[2] = __builtin_amdgcn_readlane(v2, rc);
+                                      cur_end = __builtin_amdgcn_readlane(vend, rc);
+                                  }
+                              });
+                    } else {
+                        burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{}, nxt,
+                              nothing);
+                    }
                 });
-                // rotate the descriptors: group g+1 becomes current, group g+2 next (it starts a new sample iff it
-                // lies at or past the end of the sample group g+1 is in)
-                rel += (g + 2 >= cur_end) ? 1 : 0;
-                const int rc = rel < SYRK_UNIT_SAMPLES ? rel : SYRK_UNIT_SAMPLES - 1;
-                rsrcC = rsrcN;
-                rsrcN[0] = __builtin_amdgcn_readlane(v0, rc);
-                rsrcN[1] = __builtin_amdgcn_readlane(v1, rc);
-                rsrcN[2] = __builtin_amdgcn_readlane(v2, rc);
-                cur_end = __builtin_amdgcn_readlane(vend, rc);
+            };
+            // prologue: stages 0 .. NSLOT-2 and the A half of stage NSLOT-1 (all of group 0) requested, stage 0 published
+            static_for<0, NSLOT - 1>([&](auto slc) { static_for<0, 8>([&](auto dc) { piece(slc, dc, dA); }); });
+            static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, NSLOT - 1>{}, dc, dA); });
+            dma_wait_upto<(NSLOT - 2) * PER + PER / 2>();
+            __builtin_amdgcn_s_barrier();
+            static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, 0, fc, fa0, fb0); });
+            // groups in pairs (the descriptor sets swap roles); an odd chunk gets one padding group of zeros
+            for (int g = 0; g < ngroups; g += 2) {
+                group(dA, dB, g);
+                group(dB, dA, g + 1);
             }
             lds_wait_all();                  // the trailing fragment reads
             __builtin_amdgcn_s_barrier();    // ... of every wave, before the next unit's prologue overwrites the ring
@@ -503,14 +531,14 @@ static int syrk_plan(const int64_t* T_list, int n, int64_t K, int64_t ldx, SyrkA
 #ifdef LLMC_LAB
     if (const char* e = getenv("LLMC_SYRK_S")) S = atoi(e);   // lab: force the token-chunk count
 #endif
-    if (S > G) S = (int)G;
+    if (S > G / 2) S = (int)(G / 2);     // every chunk at least one group pair
     if (S < 1) S = 1;
     for (;; ++S) {
-        LLMC_REQUIRE(S <= SYRK_MAX_CHUNKS && S <= G, "hessian_accum: samples too short for one call (stage them into fewer, longer ones)");
+        LLMC_REQUIRE(S <= SYRK_MAX_CHUNKS && (S <= G / 2 || S == 1), "hessian_accum: samples too short for one call (stage them into fewer, longer ones)");
         int i = 0;
         bool fits = true;
         for (int s = 0; s <= S; ++s) {
-            const int64_t g = s * G / S;
+            const int64_t g = s == S ? G : (s * G / S) & ~(int64_t)1;   // interior boundaries even: the kernel walks group pairs
             a->cb[s] = (uint32_t)g;
             while (i + 1 < n && (int64_t)a->smp[i + 1].g0 <= g) ++i;
             a->ci[s] = (uint32_t)i;

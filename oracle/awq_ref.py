@@ -98,7 +98,7 @@ def search_scale(weights, x, dt, sym, qmin, qmax, group_size, version='v2', n_gr
 
 # ---- AutoClipper (llmc/compression/quantization/auto_clip.py:84-191, clip_version v1, w_only) ------------
 def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid=20, max_shrink=0.5,
-                    n_sample_token=512):
+                    n_sample_token=512, errs_out=None):
     """w [R,K], x [tokens,K] (values of dtype dt) or a LIST of such batches (auto_clip.py:130-184: the error is averaged
     over the list in dt). Returns (best_max [R, ng, 1], best_min [R, ng, 1]).
     Per (row, group), for i_s in range(int(max_shrink * n_grid)):
@@ -146,6 +146,8 @@ def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid
             err = rnd(sq.sum(axis=1, dtype=np.float32) / np.float32(sq.shape[1]), dt).reshape(R, ng, 1)
             err_mean = err if err_mean is None else rnd(err_mean + err, dt)      # err_mean = 0; err_mean += err
         err_mean = rnd(err_mean / np.float32(len(xgs)), dt)                      # err_mean /= len(inputs)
+        if errs_out is not None:
+            errs_out.append(err_mean.reshape(R, ng).copy())
         better = err_mean < min_errs
         min_errs = np.where(better, err_mean, min_errs)
         best_max = np.where(better, max_val, best_max)

@@ -22,3 +22,13 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+def report(test, **vals):
+    """Statistical parity checks record the value they measured next to the bound they assert (LLMC_TEST_ACTUALS=<file>):
+    the bounds of the end-to-end tests are derived from these records and from profiles/r03_parity_envelope.txt, not guessed."""
+    path = os.environ.get('LLMC_TEST_ACTUALS')
+    if path:
+        import json
+        with open(path, 'a') as f:
+            f.write(json.dumps({'test': test, **{k: (float(v) if hasattr(v, '__float__') else v) for k, v in vals.items()}}) + '\n')

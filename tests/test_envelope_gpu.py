@@ -1,0 +1,60 @@
+"""End-to-end GPTQ parity at a Llama input width against the REFERENCE'S OWN CLASS METHODS run on the host cores
+(oracle/_ref = llmc after its own CI rewrite; driven by tools/parity_arm.py exactly as tools/parity_envelope.py does).
+The bounds come from the measured envelope, profiles/r03_parity_envelope.txt: at K = 4096 with the full 128 x 2048
+calibration set the reference on the host and the unmodified reference on this GPU (PyTorch-ROCm) agree with each other
+on 99.999 % of the INT4 codes, and llmc_amd agrees with either of them on the same 99.999 %; with fewer samples per
+channel (this test: 24 x 2048 tokens for 4096 channels, to stay in seconds) the Hessian is worse conditioned and every
+pair drops together. Asserted here: what north_star states for the pieces that are comparable across implementations —
+static-group scales identical, dynamic-group scales within 1e-4 (relative) on >= 99.9 % of the groups, INT4 codes identical on
+>= 99.9 % of the weights, identical actorder permutation up to tied diagonals, the same layer-output error."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'llmc')),
+                    reason='oracle/_ref (the reference, built by __graft_entry__.build() in the build container) is absent')
+def test_gptq_layer_matches_the_reference_class_within_the_measured_envelope(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import parity_envelope as PE
+    from conftest import report
+    dev = torch.device('cuda', 0)
+    R, K, n_seq, seq = 512, 4096, 24, 2048
+    W, X = PE.synth(R, K, n_seq, seq, 5, dev)
+    data = str(tmp_path / 'data.pt')
+    torch.save({'W': W.cpu(), 'X': X.cpu()}, data)
+    res = {}
+    for arm, extra in (('ref_cpu', ['--threads', '16']), ('ours', [])):
+        out = str(tmp_path / f'{arm}.npz')
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'parity_arm.py'), '--arm', arm, '--data', data, '--out', out] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (arm, r.stderr[-800:])
+        res[arm] = dict(np.load(out))
+    Xs = X[:4].reshape(-1, K).float()
+    Y0 = Xs @ W.float().T
+    for v in ('w_only', 'vllm'):
+        qa, sa, za, wa = PE.codes_of(res['ref_cpu'], v, K)
+        qb, sb, zb, wb = PE.codes_of(res['ours'], v, K)
+        codes = float((qa == qb).float().mean())
+        rel_s = (sa - sb).abs() / sb.abs().clamp_min(1e-30)
+        s_ok = float((rel_s <= 1e-4).float().mean())
+        z_eq = float((za == zb).float().mean())
+        perm = float((torch.from_numpy(res['ref_cpu'][v + '/perm']) == torch.from_numpy(res['ours'][v + '/perm'])).float().mean())
+        ea = float(((Xs @ (wa.to(dev) - W.float()).T).double() ** 2).sum() / (Y0.double() ** 2).sum())
+        eb = float(((Xs @ (wb.to(dev) - W.float()).T).double() ** 2).sum() / (Y0.double() ** 2).sum())
+        la, lb = float(res['ref_cpu'][v + '/loss']), float(res['ours'][v + '/loss'])
+        report('envelope_llama_width/' + v, codes_equal=codes, scales_within_1e4=s_ok, zeros_equal=z_eq, perm_equal=perm,
+               out_err_ref=ea, out_err_ours=eb, loss_ref=la, loss_ours=lb)
+        assert codes >= 0.999, (v, codes)
+        assert s_ok >= 0.999 and z_eq >= 0.999, (v, s_ok, z_eq)
+        if v == 'vllm':
+            assert float(rel_s.max()) == 0.0                       # static groups: RTN scales of the original weights
+        assert perm >= 0.99, (v, perm)
+        assert abs(ea - eb) <= 1e-3 * ea and abs(la - lb) <= 1e-4 * abs(la), (v, ea, eb, la, lb)

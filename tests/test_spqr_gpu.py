@@ -139,6 +139,8 @@ def test_spqr_class_matches_reference_class():
         assert m.weight.dtype == torch.float32 and got.shape == ref.shape
         first = n.startswith('0.gate') or n.startswith('0.up')
         close = np.mean(np.abs(got - ref) < 2e-2 * np.abs(ref).max())
+        from conftest import report
+        report(f'spqr_vs_reference_class/{n}', w_close_2e2=close, w_close_1e3=np.mean(np.abs(got - ref) < 1e-3 * np.abs(ref).max()))
         assert close > (0.97 if first else 0.80), (n, close)
         assert m.buf_scales.shape == (ref.shape[0] * ref.shape[1] // 16, 1) and m.buf_scales.dtype == torch.float32
         assert m.buf_zeros.shape == m.buf_scales.shape and m.buf_mask.is_sparse
