@@ -15,8 +15,9 @@ def _strip_cache_kwargs(kwargs_list):
     """the first-block kwargs captured by the model adapter may carry a KV cache; it must not be reused"""
     for kw in kwargs_list:
         kw.pop('use_cache', None)
-        if 'past_key_value' in kw:
-            kw['past_key_value'] = None
+        for name in ('past_key_value', 'past_key_values'):      # the keyword was renamed between transformers releases
+            if name in kw:
+                kw[name] = None
 
 
 class BlockwiseOpt(ABC):

@@ -1,0 +1,165 @@
+"""Model adapters for REAL Hugging Face blocks (random init, no checkpoint), with the methods llmc's algorithms call on
+`BaseModel` (llmc/models/base_model.py:22-481) and the subset tables of llmc/models/llama.py:52-91 and
+llmc/models/opt.py:53-90: fused attention kwargs, GQA shapes, biases (OPT), rotary position embeddings.
+The first block's inputs are captured the way the reference does it (base_model.py:171-189: a Catcher in place of
+block 0 that records its arguments and raises). Test infrastructure."""
+import inspect
+
+import torch
+import torch.nn as nn
+
+
+def _linear_types():
+    from llmc_amd.compression.quantization.module_utils import _LLMC_LINEAR_TYPES_, _TRANSFORMERS_LINEAR_TYPES_
+    return tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)
+
+
+class _HFAdapter:
+    def __init__(self, model, dtype):
+        self.model = model.to(dtype)
+        self.torch_dtype = dtype
+        self.model_config = model.config
+        self.tokenizer = None
+        self.mm_model = None
+        self.kvcache_buffer = []
+        self.find_blocks()
+
+    def get_blocks(self):
+        return self.blocks
+
+    def get_model(self):
+        return self.model
+
+    def get_block_linears(self, block):
+        return {n: m for n, m in block.named_modules() if isinstance(m, _linear_types())}
+
+    def get_extra_modules(self, block):
+        return {}
+
+    def replace_module_subset(self, cls, block, subset, block_idx, params):
+        for name, m in subset['layers'].items():
+            if not isinstance(m, _linear_types()):
+                continue
+            parent_name, _, child = name.rpartition('.')
+            parent = block.get_submodule(parent_name) if parent_name else block
+            setattr(parent, child, cls.new(m, **params))
+
+    def replace_module_block(self, cls, block, block_idx, params):
+        self.replace_module_subset(cls, block, {'layers': self.get_block_linears(block)}, block_idx, params)
+
+    def replace_language_module_all(self, cls, params, keep_device=False):
+        for i, b in enumerate(self.blocks):
+            if not keep_device:
+                b.cuda()
+            self.replace_module_block(cls, b, i, params)
+            if not keep_device:
+                b.cpu()
+
+    def convert_dtype(self, dtype):
+        for i in range(len(self.blocks)):
+            self.blocks[i] = self.blocks[i].to(dtype)
+
+    @torch.no_grad()
+    def collect_first_block_input(self, input_ids_list):
+        """base_model.py:171-189, 228-290: run the model up to block 0 and keep what block 0 was called with."""
+        first = {'data': [], 'kwargs': []}
+
+        class Catcher(nn.Module):
+            def __init__(self, module):
+                super().__init__()
+                self.module = module
+                self.signature = inspect.signature(module.forward)
+
+            def forward(self, *args, **kwargs):
+                params = list(self.signature.parameters.keys())
+                for i, arg in enumerate(args):
+                    if i > 0:
+                        kwargs[params[i]] = arg
+                first['data'].append(args[0])
+                first['kwargs'].append(kwargs)
+                raise ValueError
+
+        self.model.cuda()
+        layers = self.layer_list()
+        layers[0] = Catcher(layers[0])
+        for ids in input_ids_list:
+            try:
+                self.model(ids.cuda())
+            except ValueError:
+                pass
+        layers[0] = layers[0].module
+        self.model.cpu()
+        self.blocks = self.layer_list()
+        return first
+
+
+class HFLlama(_HFAdapter):
+    block_name_prefix = 'model.layers'
+
+    def find_blocks(self):
+        self.blocks = self.model.model.layers
+
+    def layer_list(self):
+        return self.model.model.layers
+
+    def get_subsets_in_block(self, block):      # llmc/models/llama.py:52-91
+        return [
+            {'layers': {'self_attn.q_proj': block.self_attn.q_proj, 'self_attn.k_proj': block.self_attn.k_proj,
+                        'self_attn.v_proj': block.self_attn.v_proj},
+             'prev_op': [block.input_layernorm], 'input': ['self_attn.q_proj'], 'inspect': block.self_attn, 'has_kwargs': True},
+            {'layers': {'self_attn.o_proj': block.self_attn.o_proj}, 'prev_op': [block.self_attn.v_proj],
+             'input': ['self_attn.o_proj'], 'inspect': block.self_attn.o_proj, 'has_kwargs': False},
+            {'layers': {'mlp.gate_proj': block.mlp.gate_proj, 'mlp.up_proj': block.mlp.up_proj},
+             'prev_op': [block.post_attention_layernorm], 'input': ['mlp.gate_proj'], 'inspect': block.mlp,
+             'has_kwargs': False, 'is_mlp': True},
+            {'layers': {'mlp.down_proj': block.mlp.down_proj}, 'prev_op': [block.mlp.up_proj], 'input': ['mlp.down_proj'],
+             'inspect': block.mlp.down_proj, 'has_kwargs': False, 'is_mlp': True},
+        ]
+
+
+class HFOpt(_HFAdapter):
+    block_name_prefix = 'model.decoder.layers'
+
+    def find_blocks(self):
+        self.blocks = self.model.model.decoder.layers
+
+    def layer_list(self):
+        return self.model.model.decoder.layers
+
+    def get_subsets_in_block(self, block):      # llmc/models/opt.py:53-90
+        return [
+            {'layers': {'self_attn.q_proj': block.self_attn.q_proj, 'self_attn.k_proj': block.self_attn.k_proj,
+                        'self_attn.v_proj': block.self_attn.v_proj},
+             'prev_op': [block.self_attn_layer_norm], 'input': ['self_attn.q_proj'], 'inspect': block.self_attn,
+             'has_kwargs': True},
+            {'layers': {'self_attn.out_proj': block.self_attn.out_proj}, 'prev_op': [block.self_attn.v_proj],
+             'input': ['self_attn.out_proj'], 'inspect': block.self_attn.out_proj, 'has_kwargs': False},
+            {'layers': {'fc1': block.fc1}, 'prev_op': [block.final_layer_norm], 'input': ['fc1'], 'inspect': block.fc1,
+             'has_kwargs': False, 'is_mlp': True},
+            {'layers': {'fc2': block.fc2}, 'prev_op': [block.fc1], 'input': ['fc2'], 'inspect': block.fc2,
+             'has_kwargs': False, 'is_mlp': True, 'do_trans': False},
+        ]
+
+
+def tiny_llama(dtype=torch.bfloat16, seed=0):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=160, max_position_embeddings=256, attn_implementation='eager')
+    cfg.use_cache = False
+    return HFLlama(LlamaForCausalLM(cfg), dtype)
+
+
+def opt_125m_shaped(dtype=torch.float16, seed=0, layers=12):
+    """OPT-125M's architecture (hidden 768, ffn 3072, 12 heads, biases), random init (BASELINE.json configs[0])."""
+    from transformers import OPTConfig, OPTForCausalLM
+    torch.manual_seed(seed)
+    cfg = OPTConfig(hidden_size=768, ffn_dim=3072, num_hidden_layers=layers, num_attention_heads=12, vocab_size=512,
+                    max_position_embeddings=256, word_embed_proj_dim=768, attn_implementation='eager')
+    cfg.use_cache = False
+    return HFOpt(OPTForCausalLM(cfg), dtype)
+
+
+def calib_ids(n, seq, vocab, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, vocab, (1, seq), generator=g) for _ in range(n)]

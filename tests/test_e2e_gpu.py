@@ -83,8 +83,11 @@ def test_gptq_block_loop_matches_oracle_pipeline(variant):
     close3 = np.mean(np.abs(got - ref_w) < 1e-3 * np.abs(ref_w).max())
     from conftest import report
     report('gptq_block_loop_vs_oracle/' + variant, rel_max=rel, close_1e3=close3)
-    assert rel < 0.3, rel
-    assert close3 > 0.9
+    # measured (gpurun_out/r03c/actuals.jsonl): dynamic groups 3.4e-6 / 1.0, static groups 0.144 / 0.9969 — with static
+    # groups a last-bit difference can flip one 4-bit code, which moves that weight by a quantisation step (rel_max) and
+    # a few of its row's later weights through the error feedback; nothing flips with dynamic groups on this layer
+    assert rel < (0.3 if static else 1e-4), rel
+    assert close3 > (0.99 if static else 0.9999), close3
     # the quantity GPTQ minimises: output error of the layer on the calibration activations
     X = h16.detach().reshape(-1, 256).float().cpu().numpy()
     e_got = np.linalg.norm(X @ (got - W).T) / np.linalg.norm(X @ W.T)
@@ -174,8 +177,20 @@ def test_gptq_matches_reference_classes(tag, sym, static):
         from conftest import report
         report(f'gptq_vs_reference_classes/{tag}/{n}', w_close_2e2=close, w_close_1e3=close3, s_close_2e2=s_close,
                s_close_1e4=s_close4)
-        assert close > (0.97 if first else 0.80), (n, close)
-        assert s_close > (0.97 if first else 0.80), n
+        # Bounds from the measured values (gpurun_out/r03c/actuals.jsonl) and the envelope (profiles/r03_parity_envelope.txt).
+        # Block 0 and every static-groups layer: all weights within 1e-3 and all scales within 1e-4 of the reference's
+        # (measured 1.0). Dynamic groups, block 1: its inputs come from block 0's quantised layers (quant_out +
+        # true_sequential), so one flipped code upstream changes the calibration data itself: gate / up measured
+        # 0.9968 / 0.9983 within 1e-3, down_proj (third generation, K = 256, 384 calibration tokens) 0.92 within 1e-3,
+        # 0.975 within 2e-2, scales 0.988 within 2e-2. The reference run twice (host vs ROCm) shows the same kind of
+        # spread at Llama width (envelope: codes 0.99912 at K = 14336 with 65536 tokens).
+        block0 = n.startswith('0.')
+        if block0 or static:
+            assert close3 >= 0.999 and s_close4 >= 0.999, (n, close3, s_close4)
+        elif n.endswith('down_proj'):
+            assert close >= 0.95 and close3 >= 0.85 and s_close >= 0.97, (n, close, close3, s_close)
+        else:
+            assert close3 >= 0.99 and s_close4 >= 0.999, (n, close3, s_close4)
     algo.deploy('fake_quant')
     fq = model.get_blocks()[0].down_proj.weight.data.float().cpu().numpy()
     ref = g[f'{tag}/fake/0.down_proj']

@@ -141,12 +141,15 @@ def test_spqr_class_matches_reference_class():
         close = np.mean(np.abs(got - ref) < 2e-2 * np.abs(ref).max())
         from conftest import report
         report(f'spqr_vs_reference_class/{n}', w_close_2e2=close, w_close_1e3=np.mean(np.abs(got - ref) < 1e-3 * np.abs(ref).max()))
-        assert close > (0.97 if first else 0.80), (n, close)
+        # measured 1.0 for every layer of both blocks, also within 1e-3 (gpurun_out/r03c/actuals.jsonl)
+        assert close >= 0.999 and np.mean(np.abs(got - ref) < 1e-3 * np.abs(ref).max()) >= 0.995, (n, close)
         assert m.buf_scales.shape == (ref.shape[0] * ref.shape[1] // 16, 1) and m.buf_scales.dtype == torch.float32
         assert m.buf_zeros.shape == m.buf_scales.shape and m.buf_mask.is_sparse
         s_ref = g[f'scales/{n}']
         sg = m.buf_scales.cpu().numpy().reshape(-1)
-        assert np.mean(np.abs(sg - s_ref) <= 2e-2 * np.abs(s_ref)) > (0.95 if first else 0.75), n
+        s_close = np.mean(np.abs(sg - s_ref) <= 2e-2 * np.abs(s_ref))
+        report(f'spqr_vs_reference_class/scales/{n}', s_close_2e2=s_close, s_close_1e4=np.mean(np.abs(sg - s_ref) <= 1e-4 * np.abs(s_ref)))
+        assert s_close > (0.95 if first else 0.75), n
         nout, nref = int(m.buf_mask.to_dense().sum().item()), int(g[f'nout/{n}'])
         assert abs(nout - nref) <= max(4, 0.3 * nref), (n, nout, nref)
     with pytest.raises(AssertionError):
