@@ -62,20 +62,75 @@ struct ClipArgs {
     void* errs;      // optional [n_shrink, R, ng] dt: the mean error of every shrink level (multi-batch callers)
 };
 
+// ---- ATen's summation orders (the reference's CPU path, the one the goldens come from) ------------------------------
+// The chosen clip level is an argmin over errors that are 16-bit numbers: one ulp of difference in one output flips it.
+// Sums of 16-bit values in fp32 are not order-independent in their last bits (measured on the goldens: a plain
+// sequential k-sum changes 1-2.4 % of the fp16 error entries), so both reductions follow ATen
+// (aten/src/ATen/native/cpu/SumKernel.cpp; sum_stub has no AVX-512 variant, so the AVX2 kernel runs on every x86 host:
+// V = 8 fp32 lanes; restated and pinned against torch itself in oracle/aten_sum.py):
+//  (1) `(x * w).sum(-1)` (auto_clip.py:150,166): vectorized_inner_sum with the reduced-precision load policy: a 16-element
+//      Vectorized<BFloat16 / Half> is loaded as lo(8) + hi(8) in fp32; row_sum over the row's vectors: four interleaved
+//      streams (vector i -> stream i % 4, the vectors past the last full four -> stream 0), ((s0 + s1) + s2) + s3 per
+//      lane; the 8 lane sums added sequentially, trailing elements (g % 16) first. One thread per output: independent
+//      of the host's thread count.
+//  (2) `.pow(2).mean(dim=1)` (auto_clip.py:170): 16-bit means are cast to fp32, summed and divided; the sum over tokens is
+//      cascade_sum's outer reduction for the serial iterator (what small inputs and the goldens take; large inputs are
+//      split across threads by TensorIterator, there the reference's own order depends on the thread count):
+//      multi_row_sum — 16-element chunks summed sequentially, chunk sums cascaded in levels of 16 — either directly
+//      (MODE_A) or on four interleaved streams i % 4 that are added at the end (row_sum, MODE_B); which one a column
+//      (= group index j of ng) gets is vectorized_outer_sum's / scalar_outer_sum's blocking by 32 / 8 / 4 columns.
+// oracle/awq_ref.py pins the resulting levels 100 % to the reference on tests/golden/clip.npz and clip_mb.npz.
+__device__ __forceinline__ bool aten_outer_mode_b(int ng, int j) {
+    if (ng >= 8) return j >= (ng / 32) * 32;       // 4 vectors of 8 columns at a time: multi_row_sum; the rest: row_sum
+    return j >= (ng / 4) * 4;                      // scalar_outer_sum: 4 columns at a time, the rest row_sum
+}
+
+// fp32 sum of v[0 .. n) (LDS, n <= 512) in ATen's cascade order, by one wave; every lane returns the result.
+// stride 1 / 4: the elements i, i + stride, ... of one interleaved stream (MODE_B calls it with stride 4 per stream).
+__device__ __forceinline__ float aten_cascade_sum(const float* v, int first, int stride, int count, int lane) {
+    // chunk sums: lane c sums elements [16 c, 16 c + 16) of the stream sequentially from 0
+    const int nch = count >> 4;
+    float cs = 0.f;
+    if (lane < nch) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cs += v[first + (16 * lane + m) * stride];
+    }
+    // cascade over the chunk sums (level_step 16: acc1 takes 16 chunk sums, then moves on to acc2), remainder into acc0
+    float acc1 = 0.f, acc2 = 0.f;
+    for (int c = 0; c < nch; ++c) {
+        acc1 += __shfl(cs, c, 64);
+        if (((c + 1) & 15) == 0) {
+            acc2 += acc1;
+            acc1 = 0.f;
+        }
+    }
+    float acc0 = 0.f;
+    for (int i = nch * 16; i < count; ++i) acc0 += v[first + i * stride];
+    acc0 += acc1;
+    acc0 += acc2;
+    return acc0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
     constexpr int DT = dt_of<T>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xt = (T*)smem;                                                  // [g][CTOK]
-    float* tab = (float*)(smem + (size_t)CG * CTOK * sizeof(T));       // [4 waves][CMAXS][CG]
-    float* esum_all = tab + 4 * CMAXS * CG;                            // [CROWS][CMAXS]
+    T* tab = (T*)(smem + (size_t)CG * CTOK * sizeof(T));               // [4 waves][CMAXS][CG] candidate weights (dt values)
+    float* esum_all = (float*)(tab + 4 * CMAXS * CG);                  // [CROWS][CMAXS]
+    float* sqbuf = esum_all + CROWS * CMAXS;                           // [4 waves][CTOK] squared errors of one (row, level)
     const int gi = blockIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * CROWS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = a.g;
-    float* mytab = tab + wv * CMAXS * CG;
+    T* mytab = tab + wv * CMAXS * CG;
+    float* mysq = sqbuf + wv * CTOK;
     const int ns = a.n_shrink;
     const bool v0 = lane < g, v1 = lane + 64 < g;
+    const bool exact_tok = a.n_tok <= CTOK;           // one tile: the token sum follows ATen's serial cascade
+    const bool mode_b = aten_outer_mode_b(a.ng, gi);
+    const int nv = g >> 4;                            // 16-element vectors of the k-sum (<= 8)
+    const int nv4 = nv & ~3;                          // vectors dealt to the four streams; the rest go to stream 0
 
     for (int e = tid; e < CROWS * CMAXS; e += 256) esum_all[e] = 0.f;
 
@@ -99,8 +154,8 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
                                     v1 ? (a.clip_sym ? fabsf(w1) : w1) : -INFINITY);
             const float amn = fminf(v0 ? w0 : INFINITY, v1 ? w1 : INFINITY);
             const float org_max = wave_max(amx, 64), org_min = wave_min(amn, 64);
-            mytab[lane] = w0;
-            mytab[lane + 64] = w1;
+            mytab[lane] = from_f32<T>(w0);
+            mytab[lane + 64] = from_f32<T>(w1);
             for (int s = 0; s < ns; ++s) {
                 const float f = (float)(1.0 - (double)s / (double)a.n_grid);   // python scalar: fp32 opmath in ATen's mul
                 const float mx = rndc<DT>(org_max * f);
@@ -111,57 +166,99 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
                 const QParams q = qparams_from_minmax(gmn, gmx, DT, a.sym, 1, a.qmin, a.qmax);
                 const float q0 = dequant_code(quant_code(c0, q.s, q.z, DT, DT, a.qmin, a.qmax), q.s, q.z, DT);
                 const float q1 = dequant_code(quant_code(c1, q.s, q.z, DT, DT, a.qmin, a.qmax), q.s, q.z, DT);
-                mytab[(s + 1) * CG + lane] = v0 ? q0 : 0.f;
-                mytab[(s + 1) * CG + lane + 64] = v1 ? q1 : 0.f;
+                mytab[(s + 1) * CG + lane] = from_f32<T>(v0 ? q0 : 0.f);
+                mytab[(s + 1) * CG + lane + 64] = from_f32<T>(v1 ? q1 : 0.f);
             }
-            // ---- outputs of every candidate for this tile's tokens, 4 tokens per lane, 256 per pass
-            // every loop over candidates is fully unrolled with a uniform guard: indexing acc / esum with a runtime
-            // candidate index put them in scratch memory (5x slower)
-            float esum[CMAXS];
+            // ---- outputs of every candidate for this tile's tokens: 4 tokens per lane, 256 per pass; candidate by
+            // candidate (runtime loop: its 4 x 16 lane-partials of the ATen k-sum stay in registers)
+            float o0[CTOK / 256][4];                 // the original weights' outputs (candidate 0)
+            for (int s = 0; s <= ns; ++s) {
+                const T* tw = mytab + s * CG;
+                float es_lane = 0.f;                 // more than one tile: plain per-lane partial sums
 #pragma unroll
-            for (int s = 0; s < CMAXS; ++s) esum[s] = 0.f;
-            for (int tb = 0; tb < nt; tb += 256) {
-                float acc[CMAXS][4];
+                for (int pass = 0; pass < CTOK / 256; ++pass) {
+                    const int tb = pass * 256;
+                    if (tb >= nt) continue;
+                    const int tl = tb + lane * 4;
+                    float part[4][4][8];             // [stream][token][lane of the fp32 vector]
 #pragma unroll
-                for (int s = 0; s < CMAXS; ++s)
+                    for (int st = 0; st < 4; ++st)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[s][j] = 0.f;
-                const int tl = tb + lane * 4;
-                for (int k = 0; k < g; ++k) {
-                    float xv[4];
+                        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[j] = to_f32<T>(xt[k * CTOK + tl + j]);
+                            for (int l = 0; l < 8; ++l) part[st][j][l] = 0.f;
 #pragma unroll
-                    for (int s = 0; s < CMAXS; ++s) {
-                        if (s <= ns) {
-                            const float wv_ = mytab[s * CG + k];
-                            float pr[4];
+                    for (int i = 0; i < CG / 16; ++i) {
+                        if (i < nv) {                                    // uniform
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) pr[j] = xv[j] * wv_;
-                            rfast4<DT>(pr);
+                            for (int l = 0; l < 8; ++l) {
+                                const int k1 = 16 * i + l, k2 = k1 + 8;
+                                const float wa = to_f32<T>(tw[k1]), wb = to_f32<T>(tw[k2]);
+                                float xa[4], xb[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[s][j] += pr[j];
+                                for (int j = 0; j < 4; ++j) {
+                                    xa[j] = to_f32<T>(xt[k1 * CTOK + tl + j]) * wa;
+                                    xb[j] = to_f32<T>(xt[k2 * CTOK + tl + j]) * wb;
+                                }
+                                rfast4<DT>(xa);
+                                rfast4<DT>(xb);
+                                if (i < nv4) {                           // lo + hi, then onto the stream's lane sum
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) part[i & 3][j][l] += xa[j] + xb[j];
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) part[0][j][l] += xa[j] + xb[j];
+                                }
+                            }
                         }
                     }
-                }
+                    float fin[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int k = nv * 16; k < g; ++k) {           // trailing elements first
+                        const float wk = to_f32<T>(tw[k]);
+                        float xk[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (tl + j < nt) {
-                        const float o0 = rfast<DT>(acc[0][j]);
+                        for (int j = 0; j < 4; ++j) xk[j] = to_f32<T>(xt[k * CTOK + tl + j]) * wk;
+                        rfast4<DT>(xk);
 #pragma unroll
-                        for (int s = 1; s < CMAXS; ++s) {
-                            if (s <= ns) {
-                                const float d = rfast<DT>(rfast<DT>(acc[s][j]) - o0);
-                                esum[s] += rfast<DT>(d * d);
+                        for (int j = 0; j < 4; ++j) fin[j] += xk[j];
+                    }
+#pragma unroll
+                    for (int l = 0; l < 8; ++l)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            fin[j] += ((part[0][j][l] + part[1][j][l]) + part[2][j][l]) + part[3][j][l];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float o = rfast<DT>(fin[j]);
+                        if (s == 0) {
+                            o0[pass][j] = o;
+                        } else {
+                            const float d = rfast<DT>(o - o0[pass][j]);
+                            const float sq = rfast<DT>(d * d);
+                            if (tl + j < nt) {
+                                mysq[tl + j] = sq;
+                                es_lane += sq;
                             }
                         }
                     }
                 }
-            }
+                if (s == 0) continue;
+                float tot;
+                if (exact_tok) {
+                    // the wave's own LDS writes are visible to its own later reads (in-order LDS queue per wave)
+                    if (!mode_b) {
+                        tot = aten_cascade_sum(mysq, 0, 1, nt, lane);
+                    } else {                                   // row_sum: 4 interleaved streams + the n % 4 tail
+                        const int rows4 = nt >> 2;
+                        float part[4];
 #pragma unroll
-            for (int s = 1; s < CMAXS; ++s) {
-                if (s <= ns) {
-                    const float tot = wave_sum(esum[s], 64);
+                        for (int k4 = 0; k4 < 4; ++k4) part[k4] = aten_cascade_sum(mysq, k4, 4, rows4, lane);
+                        for (int i = rows4 * 4; i < nt; ++i) part[0] += mysq[i];
+                        tot = ((part[0] + part[1]) + part[2]) + part[3];
+                    }
+                    if (lane == 0) esum_all[rr * CMAXS + s] = tot;
+                } else {
+                    tot = wave_sum(es_lane, 64);
                     if (lane == 0) esum_all[rr * CMAXS + s] += tot;
                 }
             }
@@ -239,7 +336,7 @@ static int clip_launch(const void* W, const void* X, int dt, int64_t R, int64_t 
     a.W = W; a.X = X; a.R = R; a.K = K; a.g = (int)g; a.ng = (int)(K / g); a.n_tok = (int)n_tok;
     a.n_grid = n_grid; a.n_shrink = n_shrink; a.clip_sym = clip_sym; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
     a.best_max = best_max; a.best_min = best_min; a.errs = errs;
-    const size_t lds = (size_t)CG * CTOK * 2 + (size_t)(4 * CMAXS * CG + CROWS * CMAXS) * sizeof(float);
+    const size_t lds = (size_t)CG * CTOK * 2 + (size_t)4 * CMAXS * CG * 2 + (size_t)(CROWS * CMAXS + 4 * CTOK) * sizeof(float);
     dim3 grid((unsigned)a.ng, (unsigned)ceil_div64(R, CROWS));
     if (dt == LLMC_F16) {
         if (int rc = ensure_dynamic_lds((const void*)k_clip_search<f16_t>, (int)lds)) return rc;

@@ -14,6 +14,8 @@ bit-equal after the rounding to 16 bit), the elementwise chains bit-exactly.
 """
 import numpy as np
 
+from . import aten_sum
+
 from . import quant_ref as Q
 from .quant_ref import rnd
 
@@ -125,7 +127,9 @@ def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid
         o = np.empty((R, xg.shape[0], ng), dtype=np.float32)
         for r in range(R):
             prod = rnd(xg * wq[r][None], dt)         # [tok, ng, g]
-            o[r] = rnd(prod.sum(axis=-1, dtype=np.float32), dt)
+            # the k-sum in ATen's order (vectorized_inner_sum of a 16-bit tensor); shorter groups: plain fp32 sum
+            ks = aten_sum.inner_sum_16bit(prod) if g >= 16 else prod.sum(axis=-1, dtype=np.float32)
+            o[r] = rnd(ks, dt)
         return o
 
     org_outs = [out_of(xg, wg) for xg in xgs]
@@ -143,7 +147,8 @@ def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid
             cur_out = out_of(xg, qw.reshape(R, ng, g))
             d = rnd(cur_out - org_out, dt)
             sq = rnd(d * d, dt)
-            err = rnd(sq.sum(axis=1, dtype=np.float32) / np.float32(sq.shape[1]), dt).reshape(R, ng, 1)
+            # 16-bit mean: cast to fp32, sum over tokens in the serial iterator's order, divide, one rounding
+            err = rnd(aten_sum.outer_sum_fp32(sq) / np.float32(sq.shape[1]), dt).reshape(R, ng, 1)
             err_mean = err if err_mean is None else rnd(err_mean + err, dt)      # err_mean = 0; err_mean += err
         err_mean = rnd(err_mean / np.float32(len(xgs)), dt)                      # err_mean /= len(inputs)
         if errs_out is not None:

@@ -412,3 +412,27 @@ def test_fp8_block_restatement_pinned_to_the_reference_triton_kernels():
         c = _from16(g[p + 'c_bf16_16'], 'bf16')
         err = np.abs(Q.rnd(ref, 'bf16') - c)
         assert (err <= 2.0 ** -7 * np.abs(ref) + 1e-4 * np.abs(ref).max()).all()      # one bf16 rounding apart at most
+
+
+def test_aten_summation_orders_restated_exactly():
+    """oracle/aten_sum.py against torch itself (AVX-512 builds, the capability the goldens were produced with): the
+    contiguous 16-bit inner sum bit for bit in fp32-before-rounding terms (checked through the rounded result on 2e5
+    rows), and the serial outer sum in fp32 bit for bit."""
+    import torch
+    from oracle import aten_sum as AS
+    if torch.backends.cpu.get_cpu_capability() not in ('AVX512', 'AVX2'):
+        pytest.skip('ATen vector width differs on this host')     # sum_stub has no AVX-512 variant: AVX2 code on both
+    torch.manual_seed(0)
+    for dt in (torch.bfloat16, torch.float16):
+        for n in (128, 64, 96, 32, 16):
+            x = (torch.randn(50000, n) * torch.exp(torch.randn(n))).to(dt)
+            mine = torch.from_numpy(AS.inner_sum_16bit(x.float().numpy())).to(dt)
+            assert torch.equal(x.sum(-1), mine), (dt, n)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)                 # the serial iterator: what small inputs take at any thread count
+    try:
+        for (oc, tok, ng) in [(64, 32, 2), (64, 32, 4), (64, 100, 7), (64, 37, 16), (64, 37, 80), (32, 512, 32), (16, 300, 112)]:
+            t = (torch.randn(oc, tok, ng) ** 2 * torch.exp(torch.randn(ng))).to(torch.bfloat16).float()
+            assert torch.equal(t.sum(dim=1), torch.from_numpy(AS.outer_sum_fp32(t.numpy()))), (oc, tok, ng)
+    finally:
+        torch.set_num_threads(nthr)

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=${1:-gpurun_out/pmc_bench}
 mkdir -p $OUT
-CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/f -o f -- $CMD > $OUT/f.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum --output-format csv -d $OUT/w -o w -- $CMD > $OUT/w.log 2>&1
 python - "$OUT" <<'PY'
