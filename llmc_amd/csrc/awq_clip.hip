@@ -22,7 +22,7 @@ static constexpr int CMAXS = 12;      // 1 + max shrink steps (n_shrink <= 11)
 
 template <int DT> __device__ __forceinline__ float rfast(float v) {
     if constexpr (DT == LLMC_F16) {
-        return (float)(_Float16)v;
+        return f16_bits_to_f32(f32_to_f16_bits(v));     // through the fp32 value (no v_fma_mixlo_f16 fusion, common.h)
     } else if constexpr (DT == LLMC_BF16) {
         uint32_t x = __float_as_uint(v);
         x += 0x7fffu + ((x >> 16) & 1u);

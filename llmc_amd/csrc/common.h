@@ -64,6 +64,11 @@ __device__ __forceinline__ float f16_bits_to_f32(uint16_t u) {
     return (float)h;
 }
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float v) {
+    // ATen evaluates an fp16 op in fp32 and THEN converts: two roundings. hipcc would fuse `(f16)(a * b)` / `(f16)(a + b)`
+    // into v_fma_mixlo_f16, which rounds the exact result once — different on the rare values where the fp32 rounding
+    // lands on an fp16 tie (round 3: `org_max * 0.95f` in the AWQ clip search chose another clip level than the reference
+    // for 1-2 % of the groups). The barrier materialises the fp32 value first. (bf16 has no fused form.)
+    asm volatile("" : "+v"(v));
     _Float16 h = (_Float16)v;  // RNE
     uint16_t u;
     __builtin_memcpy(&u, &h, 2);

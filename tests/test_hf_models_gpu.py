@@ -92,7 +92,14 @@ def test_awq_on_llama_blocks_inspecting_the_attention_module():
     its Linear calls on the k-tiled HIP GEMM with the shared activation packed once per grid point."""
     import llmc_amd.compression.quantization as Q
     from llmc_amd.compression.quantization import awq_ops
-    model, inp = _llama_with_inputs()
+    import hf_adapters as H
+    model = H.tiny_llama(torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    for blk in model.get_blocks():      # outlier channels (random-init norms are all ones: the search would return s = 1)
+        for ln in (blk.input_layernorm, blk.post_attention_layernorm):
+            ln.weight.data *= torch.exp(0.7 * torch.randn(256, generator=g)).to(torch.bfloat16)
+            ln.weight.data[torch.randperm(256, generator=g)[:4]] *= 30
+    inp = model.collect_first_block_input(H.calib_ids(4, 128, 160))
     ref_blocks = copy.deepcopy(model.get_blocks())
     inp1 = {'data': [torch.cat(inp['data'], dim=0)], 'kwargs': [inp['kwargs'][0]]}     # calib.bs = -1: one batch
     qc = Cfg(weight=Cfg(bit=4, symmetric=True, granularity='per_group', group_size=128),
