@@ -71,8 +71,12 @@ class AutoClipper:
         best_max, best_min = org_max.clone(), org_min.clone()
         min_errs = torch.ones_like(org_max) * 1e9
         for i_s in range(errs.shape[0]):
-            max_val = org_max * (1 - i_s / n_grid)
-            min_val = -max_val if self.clip_sym else org_min * (1 - i_s / n_grid)
+            # `tensor * python_float` as ATen's CPU kernels evaluate it: the product in fp32 (rounded), THEN the cast — two
+            # separate device ops here, because a fused fp16 multiply rounds the exact product once and lands on the
+            # other side of a tie now and then (llmc_amd/csrc/common.h, f32_to_f16_bits)
+            f = 1 - i_s / n_grid
+            max_val = (org_max.float() * f).to(org_max.dtype)
+            min_val = -max_val if self.clip_sym else (org_min.float() * f).to(org_min.dtype)
             err = errs[i_s].unsqueeze(-1)
             better = err < min_errs
             min_errs = torch.where(better, err, min_errs)
