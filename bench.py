@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
                          'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch')
     ap.add_argument('--mode', default='independent', choices=['independent', 'cooperative'])
-    ap.add_argument('--wide-helper', type=int, default=1, help='--order shadow: the widest chain, alone by then, keeps its helper stream')
+    ap.add_argument('--wide-helper', type=int, default=1, help='the widest chain (down_proj) keeps its internal helper stream (0: every chain on one stream)')
     ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
     ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
                     help='subset schedule when --overlap > 1 (see step_independent)')
@@ -582,7 +582,10 @@ def main():
                 name, K = groups[gi][0], groups[gi][1]
                 if args.order != 'k1first':
                     Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-                chain(si, gi)
+                # the widest chain (down_proj: K3 + K4 at K = 14336) is the step's critical path once the Hessians are
+                # done: it keeps its internal helper stream (the far panel work of every factor step and the far column
+                # updates run beside its latency-bound diagonal chain); the three narrow chains stay on one stream each
+                chain(si, gi, helper=bool(args.wide_helper) and si == 0)
         for st in set(evs):
             cur.wait_stream(st)
         return outs

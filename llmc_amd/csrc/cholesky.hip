@@ -555,9 +555,39 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     // the fp32 MFMA path.
     const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
     const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
+    // Inside an outer block the columns split into NEAR (the block's own, which the next factor step needs) and FAR (all
+    // the columns to its right, needed by the later far panel solves and by the block's far update). The near panel solve
+    // and near update stay on the caller's stream between the diagonal factorisations — three small latency-bound
+    // kernels per step; the far panel solve and far in-block update of the same step (128 x nfar products: the bulk of a
+    // step's work) run on the helper stream behind an event, concurrently with the next steps' chain. Same kernels, same
+    // arithmetic per element and the same order of the updates an element receives (all of step c before step c + 1 on
+    // either stream), so the factor is bit-identical with or without the helper stream.
+    auto panel_solve = [&](const float* Vb, int c0, int nb, int col0, int ncols, hipStream_t s_) -> int {
+        if (ncols <= 0) return LLMC_OK;
+        float* P = Wk + (size_t)c0 * K + col0;     // rows c0..c0+nb, cols col0..col0+ncols
+        SgemmArgs g{};
+        // P = V^T P  (op(A)[i][k] = V[k][i], lower triangular)
+        g.A = Vb; g.lda = NB; g.B = P; g.ldb = K; g.C = P; g.ldc = K;
+        g.M = g.M_last = nb; g.N = g.N_last = ncols; g.Kd = g.Kd_last = nb;
+        g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
+        return sgemm_launch(g, true, false, s_);
+    };
+    // rows c0+nb .. oend of the trailing matrix, columns col0 .. col0+ncols:  C -= P[:, rows]^T P[:, cols]
+    auto inblock_update = [&](int c0, int nb, int oend, int col0, int ncols, hipStream_t s_) -> int {
+        const int mrows = oend - (c0 + nb);
+        if (mrows <= 0 || ncols <= 0) return LLMC_OK;
+        SgemmArgs u{};
+        u.A = Wk + (size_t)c0 * K + c0 + nb; u.lda = K;
+        u.B = Wk + (size_t)c0 * K + col0; u.ldb = K;
+        u.C = Wk + (size_t)(c0 + nb) * K + col0; u.ldc = K;
+        u.M = u.M_last = mrows; u.N = u.N_last = ncols; u.Kd = u.Kd_last = nb;
+        u.epilogue = SG_SUB; u.c_upper_only = col0 == c0 + nb ? 1 : 0; u.batch = 1;   // the far columns lie right of every row
+        return sgemm_launch(u, true, false, s_);
+    };
     for (int k0 = 0; k0 < K; k0 += NBO) {
         const int nbo = K - k0 < NBO ? K - k0 : NBO;
         const int oend = k0 + nbo;
+        const int nfar = K - oend;
         for (int c0 = k0; c0 < oend; c0 += NB) {
             const int b = c0 / NB;
             const int nb = K - c0 < NB ? K - c0 : NB;
@@ -565,36 +595,33 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
             hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (NB * PLD + 32 * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
                                nb, Vb, info_dev);
             LLMC_LAUNCH_CHECK();
-            const int nrem = K - c0 - nb;
-            if (nrem <= 0) break;
-            float* P = Wk + (size_t)c0 * K + c0 + nb;  // panel rows c0..c0+nb, cols c0+nb..K
-            SgemmArgs g{};
-            // panel solve: P = V^T P  (op(A)[i][k] = V[k][i], lower triangular)
-            g.A = Vb; g.lda = NB; g.B = P; g.ldb = K; g.C = P; g.ldc = K;
-            g.M = g.M_last = nb; g.N = g.N_last = nrem; g.Kd = g.Kd_last = nb;
-            g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
-            int rc = sgemm_launch(g, true, false, st);
+            if (K - c0 - nb <= 0) break;
+            const int nnear = oend - (c0 + nb);
+            int rc = panel_solve(Vb, c0, nb, c0 + nb, nnear, st);
             if (rc) return rc;
-            // in-block trailing update: rows c0+nb .. oend only
-            const int mrows = oend - (c0 + nb);
-            if (mrows > 0) {
-                SgemmArgs u{};
-                u.A = P; u.lda = K; u.B = P; u.ldb = K;
-                u.C = Wk + (size_t)(c0 + nb) * K + c0 + nb; u.ldc = K;
-                u.M = u.M_last = mrows; u.N = u.N_last = nrem; u.Kd = u.Kd_last = nb;
-                u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
-                    rc = sgemm_launch(u, true, false, st);
+            if (nfar > 0) {
+                hipStream_t fs = st;
+                if (side) {           // the far part of this step: behind the near panel, beside the rest of the chain
+                    rc = fork_to_side(side, st);
+                    if (rc) return rc;
+                    fs = side->side;
+                    pending_side = true;
+                }
+                rc = panel_solve(Vb, c0, nb, oend, nfar, fs);
+                if (rc) return rc;
+                rc = inblock_update(c0, nb, oend, oend, nfar, fs);
                 if (rc) return rc;
             }
+            rc = inblock_update(c0, nb, oend, c0 + nb, nnear, st);
+            if (rc) return rc;
         }
-        const int nfar = K - oend;
         if (nfar > 0) {
             // far trailing update T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo), in two parts: the rows
             // of the NEXT outer block on the main stream (its factor steps need them), the rows below on the side
             // stream, overlapped with the next outer block's latency-bound diagonal / panel kernels.
             float* P = Wk + (size_t)k0 * K + oend;
             const int m1 = nfar < NBO ? nfar : NBO;
-            if (side && pending_side) {          // rows oend.. were last written by the previous side update
+            if (side && pending_side) {          // the block's far panels (and the previous block's side update) are complete
                 int rc = join_from_side(side, st);
                 if (rc) return rc;
                 pending_side = false;
