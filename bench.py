@@ -8,8 +8,11 @@ inverse -> blocked column loop -> scales/zeros/compensated weights.  Synthetic i
   python bench.py --gpus N --steps K --warmup W
 N > 1 without a launcher: bench.py re-executes itself under `python -m torch.distributed.run` with N ranks (one per
 GPU, RCCL); under a launcher (WORLD_SIZE set) it is a rank.
-  --mode independent (default, weak scaling): every rank quantizes its own blocks, no data-path collective;
-          value = layers of all ranks / max-over-ranks time.
+  --mode handoff (default for N > 1, weak scaling): every rank quantizes its own blocks; the calibration activations
+          entering a block ([n_seq, seq, K], 2 GiB) arrive from the ring predecessor over RCCL send/recv on a side
+          stream, overlapped with compute. value = layers of all ranks / max-over-ranks time; `independent_value` = the
+          same without the hand-off (a few extra steps after the timed region).
+  --mode independent (weak scaling): every rank quantizes its own blocks, no data-path traffic at all.
   --mode cooperative (strong scaling): all ranks work on ONE block per step (llmc_amd/dist/layer_shard.py):
           subsets with K <= 8192 — rank 0 broadcasts the Hessian (layers sharing an input) or the activations over
           RCCL and the subset's layers are dealt round-robin; wider subsets (down_proj) — every rank accumulates the
@@ -67,7 +70,11 @@ def parse_args(argv=None):
     ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq'],
                     help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
                          'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch')
-    ap.add_argument('--mode', default='independent', choices=['independent', 'cooperative'])
+    ap.add_argument('--mode', default=None, choices=['independent', 'handoff', 'cooperative'],
+                    help='N > 1 (default handoff): independent = every rank quantizes its own blocks, no data-path traffic; '
+                         'handoff = the same ownership, and the calibration activations entering a block arrive from the '
+                         'rank that owns the previous block over RCCL send/recv (xGMI), overlapped with compute; '
+                         'cooperative = all ranks share ONE block (broadcast / sample-sharded all_reduce, strong scaling)')
     ap.add_argument('--wide-helper', type=int, default=1, help='the widest chain (down_proj) keeps its internal helper stream (0: every chain on one stream)')
     ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
     ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
@@ -485,13 +492,17 @@ def main():
             raise SystemExit(f'rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
+    if args.mode is None:
+        args.mode = 'handoff' if world > 1 else 'independent'
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # a bounded collective timeout: a wedged transfer aborts the run instead of hanging the node
         if args.dry:
-            dist.init_process_group('gloo')
+            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=180))
 
     from llmc_amd.compression.quantization.gptq_pipeline import GptqConfig
     from llmc_amd.dist import layer_shard as LS
@@ -522,7 +533,11 @@ def main():
             acts[name] = synth_acts(args.n_seq, args.seq_len, K, gi, dev, dtype) if rank == 0 else None
         else:
             acts[name] = synth_acts(args.n_seq, args.seq_len, K, seed_r * 64 + gi, dev, dtype)
-            if args.calib_bs < args.n_seq and not args.dry:
+            if args.mode == 'handoff' and world > 1 and gi == 0:
+                continue_split = False      # the block's first input arrives as ONE tensor from the previous owner
+            else:
+                continue_split = True
+            if continue_split and args.calib_bs < args.n_seq and not args.dry:
                 # the hook calls' tensors: one allocation per call (calib.bs sequences each), nothing contiguous across calls
                 x = acts[name]
                 acts[name] = [x[i:i + args.calib_bs].clone() for i in range(0, args.n_seq, args.calib_bs)]
@@ -612,7 +627,50 @@ def main():
                     hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=0, to_cpu=False))
         return outs
 
-    step = step_cooperative if coop else step_independent
+    # ---- handoff: block-sharded ownership with the activations of a block's first input handed from owner to owner.
+    # In a model run with quant_out off the inputs of block b are the float outputs of block b - 1
+    # (base_blockwise_quantization.py:367-402): whoever owns block b - 1 produces them and sends them on. Here every rank
+    # sends the [n_seq, seq, K] tensor it has just consumed to its ring successor and receives the one its NEXT step
+    # consumes from its predecessor: the transfer of step t + 1's input runs on its own stream under step t's kernels.
+    handoff = args.mode == 'handoff' and world > 1
+    hand = {}
+    if handoff:
+        name0 = groups[0][0]
+        hand['cur'] = acts[name0]
+        hand['nxt'] = torch.empty_like(acts[name0])
+        hand['bytes'] = acts[name0].numel() * acts[name0].element_size()
+        hand['stream'] = None if args.dry else torch.cuda.Stream(device=dev)
+
+    def handoff_start():
+        import torch.distributed as dist
+        nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+        p2p = [dist.P2POp(dist.isend, hand['cur'], nxt_rank), dist.P2POp(dist.irecv, hand['nxt'], prv_rank)]
+        if hand['stream'] is None:
+            hand['reqs'] = dist.batch_isend_irecv(p2p)
+            return
+        hand['stream'].wait_stream(torch.cuda.current_stream())      # the buffers are ready
+        with torch.cuda.stream(hand['stream']):
+            hand['reqs'] = dist.batch_isend_irecv(p2p)
+
+    def handoff_finish():
+        if hand['stream'] is None:
+            for r in hand['reqs']:
+                r.wait()
+        else:
+            with torch.cuda.stream(hand['stream']):
+                for r in hand['reqs']:
+                    r.wait()
+            torch.cuda.current_stream().wait_stream(hand['stream'])   # the next step reads what arrived
+        hand['cur'], hand['nxt'] = hand['nxt'], hand['cur']
+        acts[groups[0][0]] = hand['cur']
+
+    def step_handoff(record):
+        handoff_start()
+        out = step_independent(record)
+        handoff_finish()
+        return out
+
+    step = step_cooperative if coop else (step_handoff if handoff else step_independent)
 
     def barrier():
         if world > 1:
@@ -628,6 +686,19 @@ def main():
         last = step(True)
     barrier()
     dt = time.perf_counter() - t0
+    independent_value = None
+    if handoff:
+        # the same ownership without the hand-off, a few steps outside the contract's timed region, for comparison
+        k2 = max(2, min(4, args.steps))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step_independent(False)
+        barrier()
+        dt2 = time.perf_counter() - t1
+        t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        independent_value = n_layers_block * world * k2 / float(t.item())
     # deferred positive-definiteness check of the factorisations (the classes check once per subset; here after timing)
     def _infos(o):
         if isinstance(o, dict):
@@ -693,7 +764,11 @@ def main():
                 'subset_overlap_streams': 0 if (args.dry or coop) else args.overlap,
                 'parallelism': ('single GPU' if world == 1 else
                                 (f'cooperative x{world}: Hessian/activation broadcast + sample-sharded all_reduce, '
-                                 'row-sharded column loop' if coop else f'layer-sharded x{world}')),
+                                 'row-sharded column loop' if coop else
+                                 (f'block-sharded x{world}, calibration activations of every block\'s first input '
+                                  f'({hand["bytes"] / 2**30:.2f} GiB per step and rank) handed owner-to-owner over RCCL '
+                                  'send/recv (xGMI ring), overlapped with compute' if handoff else
+                                  f'layer-sharded x{world}, no data-path traffic'))),
             },
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
@@ -704,6 +779,8 @@ def main():
                 'achieved_incl_fixup': achieved_fix, 'avg_fixup_ms': ms_fix / max(1, n_launch),
             },
         }
+        if independent_value is not None:
+            out['independent_value'] = independent_value      # layers/s of the same ownership without the hand-off
         if world == 1 and not args.no_extras and not args.dry and args.model == 'llama3-8b' and args.variant == 'w_only':
             # free this run's tensors first: the secondary workloads are child processes on the same GPU
             acts.clear(); weights.clear(); ops.accs.clear(); ops.hwork.clear(); last = None

@@ -1,5 +1,5 @@
-"""bench.py's multi-rank plumbing without a GPU: `--gpus 2 --dry` self-spawns two ranks (gloo), runs the independent and
-the cooperative step with CPU stand-ins, and prints the contract's JSON line with n_gpus = 2."""
+"""bench.py's multi-rank plumbing without a GPU: `--gpus 2 --dry` self-spawns two ranks (gloo), runs the independent, hand-off and
+cooperative steps with CPU stand-ins, and prints the contract's JSON line with n_gpus = 2."""
 import json
 import os
 import subprocess
@@ -21,9 +21,9 @@ def run(extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize('mode', ['independent', 'cooperative'])
+@pytest.mark.parametrize('mode', ['independent', 'cooperative', 'handoff', None])
 def test_self_spawn_two_ranks_dry(mode):
-    j = run(['--mode', mode])
+    j = run(['--mode', mode] if mode else [])            # no flag: the N > 1 default = handoff
     assert j['n_gpus'] == 2 and j['steps'] == 2 and j['warmup'] == 1
     assert j['unit'] == 'layers/s' and j['value'] > 0 and j['higher_is_better'] is True
     assert j['scaling'] == ('strong' if mode == 'cooperative' else 'weak')
@@ -32,6 +32,12 @@ def test_self_spawn_two_ranks_dry(mode):
         assert k in j
     if mode == 'cooperative':
         assert 'cooperative x2' in j['config']['parallelism']
+    if mode in ('handoff', None):
+        # block-sharded with the owner-to-owner hand-off of the calibration activations over send/recv, plus the same
+        # ownership without the hand-off measured after the timed region
+        assert 'handed owner-to-owner' in j['config']['parallelism'] and j['independent_value'] > 0
+    if mode == 'independent':
+        assert 'independent_value' not in j
 
 
 def test_single_rank_needs_a_gpu_or_dry():
