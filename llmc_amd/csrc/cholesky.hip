@@ -597,21 +597,24 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
             LLMC_LAUNCH_CHECK();
             if (K - c0 - nb <= 0) break;
             const int nnear = oend - (c0 + nb);
+            if (!side || nfar <= 0) {
+                // one stream: near and far columns in ONE panel solve and ONE update per step (the split costs two more
+                // launches per step, 1.3 ms over a K = 14336 factorisation, and buys nothing without a second stream)
+                int rc = panel_solve(Vb, c0, nb, c0 + nb, K - c0 - nb, st);
+                if (rc) return rc;
+                rc = inblock_update(c0, nb, oend, c0 + nb, K - c0 - nb, st);
+                if (rc) return rc;
+                continue;
+            }
             int rc = panel_solve(Vb, c0, nb, c0 + nb, nnear, st);
             if (rc) return rc;
-            if (nfar > 0) {
-                hipStream_t fs = st;
-                if (side) {           // the far part of this step: behind the near panel, beside the rest of the chain
-                    rc = fork_to_side(side, st);
-                    if (rc) return rc;
-                    fs = side->side;
-                    pending_side = true;
-                }
-                rc = panel_solve(Vb, c0, nb, oend, nfar, fs);
-                if (rc) return rc;
-                rc = inblock_update(c0, nb, oend, oend, nfar, fs);
-                if (rc) return rc;
-            }
+            rc = fork_to_side(side, st);      // the far part of this step: behind the near panel, beside the rest of the chain
+            if (rc) return rc;
+            pending_side = true;
+            rc = panel_solve(Vb, c0, nb, oend, nfar, side->side);
+            if (rc) return rc;
+            rc = inblock_update(c0, nb, oend, oend, nfar, side->side);
+            if (rc) return rc;
             rc = inblock_update(c0, nb, oend, c0 + nb, nnear, st);
             if (rc) return rc;
         }
