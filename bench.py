@@ -623,7 +623,7 @@ def main():
                         n + str(li), [weights[n][li]],
                         shared if sh == 'hessian' else ops.hessian(n, k, shared, args.calib_bs)),
                     (shape, dtype, dev), share=share,
-                    hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=0, to_cpu=False))
+                    hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=None, to_cpu=False))   # results stay with their owners: the gather for saving is not on the step's path
         return outs
 
     # ---- handoff: block-sharded ownership with the activations of a block's first input handed from owner to owner.

@@ -57,10 +57,10 @@ def run_independent(n_units, fn, gather_to=0, to_cpu=True):
     (other ranks get their own). `fn` returns a payload: tensors / None / numbers nested in dicts, lists, tuples.
     to_cpu=True: payloads travel as pickled CPU objects (gather_object; any backend, what the Gloo tests use).
     to_cpu=False: tensors stay on their device and travel point-to-point (RCCL send/recv over xGMI); only their
-    shapes / dtypes are exchanged as objects."""
+    shapes / dtypes are exchanged as objects. gather_to=None: no gather at all, every rank keeps what it computed."""
     rank, world = world_info()
     mine = [ShardedResult(u, fn(u)) for u in units_of(rank, n_units, world)]
-    if world == 1:
+    if world == 1 or gather_to is None:      # gather_to=None: results stay with their owners (saved / gathered later)
         return [r.payload for r in mine]
     if not to_cpu:
         return _gather_p2p(mine, n_units, gather_to)

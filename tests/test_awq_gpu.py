@@ -78,7 +78,11 @@ def test_search_matches_reference_golden():
         for w, w0 in zip(ws, w_before):
             assert torch.equal(w, w0)
         ref = g[p + 'losses']
-        np.testing.assert_allclose(losses.cpu().numpy(), ref, rtol=2e-2, err_msg=name)
+        from conftest import report
+        report('awq_search_losses/' + name, max_rel=float((np.abs(losses.cpu().numpy() - ref) / ref).max()))
+        # measured on the GPU: <= 3e-4 (the products' fp32 sums are taken in another order than the CPU GEMM's and a few bf16
+        # outputs round the other way); the argmin gaps of these goldens are 2-8 %
+        np.testing.assert_allclose(losses.cpu().numpy(), ref, rtol=2e-3, err_msg=name)
         assert n == int(np.argmin(ref)), name
         u = ulps(host(best), g[p + 'best_scales'], dt)
         assert u.max() <= 2, (name, u.max())
@@ -287,7 +291,9 @@ def test_search_with_inspected_mlp_two_batches_and_mask_matches_reference_golden
         ours = np.array([float(v) for v in rec])
         ref = g[p + 'losses']
         assert ours.shape == ref.shape == (40,), name
-        np.testing.assert_allclose(ours, ref, rtol=3e-2, err_msg=name)
+        from conftest import report
+        report('awq_inspect_losses/' + name, max_rel=float((np.abs(ours - ref) / ref).max()))
+        np.testing.assert_allclose(ours, ref, rtol=5e-3, err_msg=name)
         u = ulps(host(best), g[p + 'best_scales'], dt)
         assert u.max() <= 2, (name, u.max())
 
@@ -359,3 +365,27 @@ def test_search_in_output_row_chunks_matches_unchunked(monkeypatch):
     s1, l1, b1 = search_scale_stacked(ws, x, wq, 'v2', return_losses=True)
     assert b0 == b1 and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
     np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5)
+
+
+def test_search_with_two_near_equal_minima_picks_the_reference_grid_point():
+    """tests/golden/awq_flat.npz: the reference's second-best loss is 3.7e-4 above its best; the HIP search must land on
+    the same grid point through loss values, not through a tolerance."""
+    from conftest import report
+    from llmc_amd.compression.quantization.awq_pipeline import search_scale_stacked
+    g = load_golden('awq_flat')
+    name = str(g['names'][0])
+    p = name + '/'
+    sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+    dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
+    ws = [dev(g[p + f'w{i}'], dt) for i in range(nl)]
+    best, losses, n = search_scale_stacked(ws, dev(g[p + 'x'], dt), make_q(sym, gs), ver, return_losses=True)
+    ref = g[p + 'losses']
+    srt = np.sort(ref)
+    gap = (srt[1] - srt[0]) / srt[0]
+    err = float(np.abs(losses.cpu().numpy() - ref).max() / ref.min())
+    report('awq_flat_minima', gap=float(gap), max_err_over_min=err, argmin=int(n), ref_argmin=int(np.argmin(ref)))
+    if err < gap / 2:
+        assert n == int(np.argmin(ref))
+    else:       # the loss noise reaches the gap: then the chosen point must be one of the two near-equal minima
+        assert ref[n] <= srt[1] * (1 + 1e-9)
+    assert n in (int(np.argsort(ref)[0]), int(np.argsort(ref)[1]))

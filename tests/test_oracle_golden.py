@@ -215,7 +215,9 @@ def test_awq_reductions_and_search_match_reference():
         best, losses, n = A.search_scale(ws, g[p + 'x'], dt, bool(sym), qmin, qmax, gs, ver)
         ref_losses = g[p + 'losses']
         assert len(ref_losses) == 20
-        np.testing.assert_allclose(losses, ref_losses, rtol=2e-2, err_msg=name)
+        # the 20 losses agree with the reference's to 1e-4 (measured: 2e-7 typical, 4.5e-5 worst: summation order of the
+        # CPU GEMM behind F.linear); the argmin gaps of these goldens are 2-8 %
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-4, err_msg=name)
         assert n == int(np.argmin(ref_losses)), name
         # a 1-ulp difference of the token mean at the max/min channel moves the normaliser sqrt(max*min) and
         # with it every scale by one unit in the last place: same grid point, scales within 2 ulp of the dtype
@@ -436,3 +438,23 @@ def test_aten_summation_orders_restated_exactly():
             assert torch.equal(t.sum(dim=1), torch.from_numpy(AS.outer_sum_fp32(t.numpy()))), (oc, tok, ng)
     finally:
         torch.set_num_threads(nthr)
+
+
+def test_awq_search_with_two_near_equal_minima_picks_the_reference_grid_point():
+    """tests/golden/awq_flat.npz: the reference's second-best loss is 3.7e-4 above its best. The restatement's losses agree
+    to 1e-5, so the same grid point wins — nothing here relies on a percent-level tolerance."""
+    g = load_golden('awq_flat')
+    name = str(g['names'][0])
+    p = name + '/'
+    sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+    dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
+    ws = [g[p + f'w{i}'] for i in range(nl)]
+    qmin, qmax = Q.int_range(4, bool(sym))
+    best, losses, n = A.search_scale(ws, g[p + 'x'], dt, bool(sym), qmin, qmax, gs, ver)
+    ref = g[p + 'losses']
+    srt = np.sort(ref)
+    gap = (srt[1] - srt[0]) / srt[0]
+    assert 1e-4 < gap < 2e-3
+    assert np.abs(losses - ref).max() / ref.min() < gap / 10
+    assert n == int(np.argmin(ref))
+    assert _ulp_close(best, g[p + 'best_scales'], dt, max_frac_diff=0.01, max_ulps=1)
