@@ -46,9 +46,10 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
 
     # ---- quantizer callbacks handed to the Linear wrappers (base_…:46-83) ---------------------------
     def w_qdq(self, module, wquantizer):
-        args = {}
+        args = {}                                 # base_blockwise_quantization.py:46-52: clip v2's learnable bounds ride along
         if getattr(module, 'buf_upbound_factor', None) is not None:
-            raise NotImplementedError('clip_version v2 (learnable bounds) is outside the hot path')
+            args['upbound_factor'] = module.buf_upbound_factor
+            args['lowbound_factor'] = getattr(module, 'buf_lowbound_factor', None)
         return wquantizer.fake_quant_weight_dynamic(module.weight, args)
 
     def w_q(self, module, wquantizer):
@@ -117,6 +118,8 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             if self.save_clip:
                 self.clip_path = special['clip_path']
             self.clip_version = special.get('clip_version', 'v1')
+            if self.clip_version == 'v2':
+                assert self.wquantizer.calib_algo == 'learnable'      # base_blockwise_quantization.py:229-230
             self.auto_clipper = AutoClipper(
                 w_only=self.w_only, wquantizer=self.wquantizer, aquantizer=self.aquantizer,
                 clip_version=self.clip_version, clip_sym=special.get('clip_sym', self.wquantizer.sym),

@@ -6,7 +6,8 @@ FloatQuantizer :963-1229).  In scope: calib_algo 'minmax' (the algorithm of ever
 named in BASELINE.json); granularity per_group / per_channel / per_token / per_tensor / per_head;
 FloatQuantizer e4m3 with the qtorch path pinned to torch.float8_e4m3fn's RNE cast.
 Also in scope: calib_algo 'mse' (get_mse_range, quant.py:145-203).
-Out of scope (raise NotImplementedError): learnable / hist / hqq range search, W48, per_block.
+Also in scope: calib_algo 'learnable' (get_learnable_range, quant.py:205-224: the range AutoClipper's clip v2 factors scale).
+Out of scope (raise NotImplementedError): hqq range search, W48.
 
 Tensors must live on the GPU; there is no CPU fallback (see llmc_amd/_ffi.py).
 """
@@ -29,9 +30,8 @@ class BaseQuantizer(object):
         self.kwargs = kwargs
 
         self.calib_algo = self.kwargs.get('calib_algo', 'minmax')
-        if self.calib_algo not in ('minmax', 'static_minmax', 'static_moving_minmax', 'static_hist', 'mse'):
-            raise NotImplementedError(
-                f'calib_algo={self.calib_algo}: learnable / hqq ranges are outside the hot path')
+        if self.calib_algo not in ('minmax', 'static_minmax', 'static_moving_minmax', 'static_hist', 'mse', 'learnable'):
+            raise NotImplementedError(f'calib_algo={self.calib_algo}: hqq ranges are outside the hot path')
         # hist config (quant.py:81-86)
         self.bins = self.kwargs.get('bins', 2048)
         self.upsample_rate = self.kwargs.get('upsample_rate', 16)
@@ -119,8 +119,47 @@ class BaseQuantizer(object):
             return scales, zeros, mn.reshape(shp), mx.reshape(shp)
         return scales, zeros
 
+    # ---- calib_algo 'learnable' (quant.py:205-224, 545-559): the range is min / max scaled by sigmoid(bound factors) — the
+    # factors AutoClipper's clip_version v2 stores as buf_upbound_factor / buf_lowbound_factor (auto_clip.py:213-256). With
+    # no factors it is the plain min/max range. Products are formed in fp32 and then cast (ATen's CPU kernels round twice;
+    # a fused fp16 multiply on the GPU rounds once: csrc/common.h).
+    @staticmethod
+    def _mul16(a, b):
+        return (a.float() * b.float()).to(torch.promote_types(a.dtype, b.dtype))
+
+    def get_learnable_range(self, tensor, lowbound_factor=None, upbound_factor=None):
+        min_val, max_val = tensor.amin(dim=-1, keepdim=True), tensor.amax(dim=-1, keepdim=True)
+        if self.granularity == 'per_tensor':
+            min_val, max_val = torch.min(tensor), torch.max(tensor)
+        if self.sym:
+            if upbound_factor is not None:
+                abs_max = torch.max(max_val.abs(), min_val.abs()).clamp(min=1e-5)
+                abs_max = self._mul16(torch.sigmoid(upbound_factor), abs_max)
+                min_val, max_val = -abs_max, abs_max
+        elif upbound_factor is not None and lowbound_factor is not None:
+            min_val = self._mul16(torch.sigmoid(lowbound_factor), min_val)
+            max_val = self._mul16(torch.sigmoid(upbound_factor), max_val)
+        return min_val, max_val
+
+    def get_qparams(self, tensor_range, device):
+        """quant.py:545-559 on a given (min, max) range."""
+        min_val, max_val = tensor_range
+        qmin, qmax = self.qmin.to(device), self.qmax.to(device)
+        if self.sym:
+            abs_max = torch.max(max_val.abs(), min_val.abs()).clamp(min=1e-5)
+            scales = abs_max / qmax
+            zeros = torch.tensor(0.0)
+        else:
+            scales = (max_val - min_val).clamp(min=1e-5) / (qmax - qmin)
+            zeros = (qmin - torch.round(min_val / scales)).clamp(qmin, qmax)
+            if not self.round_zp:
+                zeros = qmin - (min_val / scales)
+        return scales, zeros, qmax, qmin
+
     def get_tensor_range(self, tensor, args={}):
         """quant.py:122-130 for the algorithms on the accelerated path: (min_val, max_val)."""
+        if self.calib_algo == 'learnable':
+            return self.get_learnable_range(tensor, **{k: v for k, v in args.items() if k in ('lowbound_factor', 'upbound_factor')})
         if self.calib_algo == 'mse':
             _, _, mn, mx = self._mse_qparams(tensor, want_range=True)
             return mn, mx
@@ -190,6 +229,9 @@ class IntegerQuantizer(BaseQuantizer):
     def get_tensor_qparams(self, tensor, args={}):
         """quant.py:690-697 -> (reshaped tensor, scales, zeros, qmax, qmin)."""
         tensor = self.reshape_tensor(tensor)
+        if self.calib_algo == 'learnable' and (args.get('upbound_factor') is not None):
+            scales, zeros, qmax, qmin = self.get_qparams(self.get_tensor_range(tensor, args), tensor.device)
+            return tensor, scales, zeros, qmax, qmin
         scales, zeros = self._minmax_qparams(tensor)
         return tensor, scales, zeros, self.qmax.to(tensor.device), self.qmin.to(tensor.device)
 
@@ -298,8 +340,13 @@ class IntegerQuantizer(BaseQuantizer):
         transpose = 'dim' in args and 'ic' in args['dim']
         q_weight = weight.T if transpose else weight
         org_w_shape = q_weight.shape
-        q_weight = self.reshape_tensor(q_weight)
-        q_weight, _, _ = self._dynamic(q_weight, _ffi.OUT_FAKE, False)
+        if self.calib_algo == 'learnable' and args.get('upbound_factor') is not None:
+            # quant.py:833-869 with the learnable range: qparams from the factor-scaled range, static arithmetic
+            q_weight, scales, zeros, qmax, qmin = self.get_tensor_qparams(q_weight, args)
+            q_weight = self.quant_dequant(q_weight.contiguous(), scales, zeros, qmax, qmin)
+        else:
+            q_weight = self.reshape_tensor(q_weight)
+            q_weight, _, _ = self._dynamic(q_weight, _ffi.OUT_FAKE, False)
         q_weight = self.restore_tensor(q_weight, org_w_shape)
         return q_weight.T if transpose else q_weight
 

@@ -709,6 +709,51 @@ def suite_clip_mb():
     save('clip_mb', **out)
 
 
+def suite_clip_v2():
+    """What AutoClipper clip_version v2 leaves behind (auto_clip.py:213-256) with a `calib_algo: learnable` weight
+    quantizer (quant.py:205-224): apply_clip stores a range as logit factors, the quantizer scales its min / max range by
+    their sigmoid. The v2 SEARCH itself only runs per_channel in the reference (per_group raises inside quant.py:701), so the
+    ranges here come from the v1 search on the same data; goldens: the factors and the fake-quantized weights."""
+    from llmc.compression.quantization.auto_clip import AutoClipper
+    out = {}
+    gen = torch.Generator().manual_seed(321)
+    cfgs = [('bf16_sym_pc_clipsym', 'bf16', True, 'per_channel', None, True), ('f16_asym_pc_noclipsym', 'f16', False, 'per_channel', None, False),
+            ('bf16_asym_g128', 'bf16', False, 'per_group', 128, False)]
+    for name, dt, sym, gran, gs, clip_sym in cfgs:
+        R, K = 64, 256
+        kw = dict(group_size=gs) if gs else {}
+        wq = IntegerQuantizer(4, sym, gran, calib_algo='learnable', **kw)
+        ac = AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v2', clip_sym=clip_sym,
+                         save_clip=False, padding_mask=None)
+        wt = torch.randn(R, K, generator=gen) * 0.02
+        wt[torch.rand(R, K, generator=gen) < 0.01] *= 8
+        w = wt.to(DT[dt])
+        g = gs or K
+        wg = w.reshape(R, K // g, g)
+        org_max = (wg.abs() if clip_sym else wg).amax(dim=-1, keepdim=True)
+        org_min = wg.amin(dim=-1, keepdim=True)
+        lev = torch.randint(0, 10, (R, K // g, 1), generator=gen)
+        mx = org_max * (1 - lev / 20)
+        mn = -mx if clip_sym else org_min * (1 - lev / 20)
+        mx, mn = mx.to(DT[dt]), mn.to(DT[dt])
+        layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+        layer.weight.data = w.clone()
+        ac.apply_clip(0, layer, mn, mx, 'fc')
+        args = {'upbound_factor': layer.buf_upbound_factor, 'lowbound_factor': layer.buf_lowbound_factor}
+        fq = wq.fake_quant_weight_dynamic(layer.weight, args)
+        fq0 = wq.fake_quant_weight_dynamic(layer.weight, {'upbound_factor': None, 'lowbound_factor': None})
+        p = name + '/'
+        out[p + 'w'] = f32(w)
+        out[p + 'max'], out[p + 'min'] = f32(mx), f32(mn)
+        out[p + 'up_factor'] = f32(layer.buf_upbound_factor)
+        out[p + 'low_factor'] = f32(layer.buf_lowbound_factor) if layer.buf_lowbound_factor is not None else np.zeros(0, np.float32)
+        out[p + 'w_qdq'], out[p + 'w_qdq_nofactor'] = f32(fq), f32(fq0)
+        out[p + 'meta'] = np.array([int(sym), gs or 0, int(clip_sym)], dtype=np.int64)
+        out[p + 'dt'] = np.array(dt)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('clip_v2', **out)
+
+
 def suite_fp8():
     """FloatQuantizer e4m3 weight path. qtorch is not installed/vendored: float_quantize is bound to torch's own
     float8_e4m3fn round trip (the cast the reference's real-quant path ends in), which is what the oracle pins."""
@@ -1032,7 +1077,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':
