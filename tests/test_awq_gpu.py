@@ -80,9 +80,10 @@ def test_search_matches_reference_golden():
         ref = g[p + 'losses']
         from conftest import report
         report('awq_search_losses/' + name, max_rel=float((np.abs(losses.cpu().numpy() - ref) / ref).max()))
-        # measured on the GPU: <= 3e-4 (the products' fp32 sums are taken in another order than the CPU GEMM's and a few bf16
-        # outputs round the other way); the argmin gaps of these goldens are 2-8 %
-        np.testing.assert_allclose(losses.cpu().numpy(), ref, rtol=2e-3, err_msg=name)
+        # measured on an MI355X: max 2.0e-5 (profiles/r03_e2e_measured_values.jsonl; the products' fp32 sums are taken in
+        # another order than the CPU GEMM's and a few bf16 outputs round the other way); bound = 10x that. The argmin gaps of
+        # these goldens are 2-8 %; awq_flat.npz holds the 3.7e-4 case
+        np.testing.assert_allclose(losses.cpu().numpy(), ref, rtol=2e-4, err_msg=name)
         assert n == int(np.argmin(ref)), name
         u = ulps(host(best), g[p + 'best_scales'], dt)
         assert u.max() <= 2, (name, u.max())
@@ -293,7 +294,7 @@ def test_search_with_inspected_mlp_two_batches_and_mask_matches_reference_golden
         assert ours.shape == ref.shape == (40,), name
         from conftest import report
         report('awq_inspect_losses/' + name, max_rel=float((np.abs(ours - ref) / ref).max()))
-        np.testing.assert_allclose(ours, ref, rtol=5e-3, err_msg=name)
+        np.testing.assert_allclose(ours, ref, rtol=3e-4, err_msg=name)      # measured: max 2.4e-5 (same record)
         u = ulps(host(best), g[p + 'best_scales'], dt)
         assert u.max() <= 2, (name, u.max())
 

@@ -79,7 +79,7 @@ def test_apply_clip_v2_and_learnable_w_qdq_gpu(name):
     fq = wq.fake_quant_weight_dynamic(layer.weight.data, args)
     ref = t('w_qdq')
     agree = (fq.float() == ref.float()).float().mean().item()
-    report(f'clip_v2/{name}/w_qdq_agree', agree)
+    report(f'clip_v2/{name}', w_qdq_agree=agree, up_factor_rel=du)
     assert agree >= 0.999, agree
     # and with no factors a learnable quantizer is the plain min/max one
     fq0 = wq.fake_quant_weight_dynamic(layer.weight.data, {'upbound_factor': None, 'lowbound_factor': None})

@@ -93,6 +93,42 @@ def test_fp8_block_gemm_and_forward_vs_restatement(shape):
         assert rel < 0.06, rel
 
 
+@pytest.mark.parametrize('shape,dtype,with_bias', [
+    ((512, 768, 1024), torch.bfloat16, False),      # whole 256 x 256 tiles, even number of K blocks
+    ((384, 256, 640), torch.float16, False),        # ragged m tile, odd number of K blocks
+    ((1000, 520, 384), torch.float32, True),        # ragged both ways, three K blocks, bias, fp32 output
+    ((128, 130, 128), torch.bfloat16, True),        # the smallest shape the K = 64 kernel takes, N % 4 != 0
+    ((2048, 2304, 256), torch.bfloat16, False),     # 72 tiles: several rounds of the persistent grid's XCD order
+])
+def test_fp8_block_gemm_k64_kernel(shape, dtype, with_bias):
+    """The 256 x 256-tile kernel on v_mfma_f32_32x32x64_f8f6f4 (K % 128 == 0, M, N >= 128) against the fp64 restatement of
+    kernel.py:213-242, for every output dtype, edge tiles, bias; operands with an asymmetric pattern so that a swapped or
+    transposed tile cannot pass."""
+    from llmc_amd.compression.quantization import kernel as KN
+    M, N, K = shape
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    a8 = (torch.randn(M, K, generator=gen) * 2 * (1 + torch.arange(M).remainder(7)[:, None] / 7)).to(torch.float8_e4m3fn).cuda()
+    w8 = (torch.randn(N, K, generator=gen) * (1 + torch.arange(N).remainder(5)[:, None] / 5)).to(torch.float8_e4m3fn).cuda()
+    nkb = K // 128
+    a_s = (torch.rand(M, nkb, generator=gen) + 0.5).cuda()
+    w_s = (torch.rand(-(-N // 128), nkb, generator=gen) * 0.1 + 0.01).cuda()
+    bias = torch.randn(N, generator=gen).to(dtype).cuda() if with_bias else None
+    c = KN.fp8_gemm(a8, a_s, w8, w_s, dtype=dtype, bias=bias)
+    assert c.dtype == dtype and c.shape == (M, N)
+    ref = Q.fp8_block_gemm_ref(a8.view(torch.uint8).cpu().numpy(), a_s.cpu().numpy(), w8.view(torch.uint8).cpu().numpy(),
+                               w_s.cpu().numpy())
+    eps = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 2.0 ** -20}[dtype]
+    want = torch.from_numpy(ref).to(dtype)
+    if with_bias:
+        want = (want + bias.cpu()).to(dtype)
+    err = (c.cpu().double() - want.double()).abs().numpy()
+    # one output rounding of fp32 sums taken in another order (in-block: the MFMA's; fp32 output: 128 terms of rounding noise)
+    tol = eps * np.abs(want.double().numpy()) + (3e-5 if dtype == torch.float32 else 1e-4) * np.abs(ref).max()
+    if with_bias:
+        tol = tol + eps * np.abs(ref)          # the product is rounded to the output dtype before the bias is added
+    assert (err <= tol).all(), (float((err - tol).max()), np.unravel_index(np.argmax(err - tol), err.shape))
+
+
 def test_llmc_fp8_linear_forward():
     """LlmcFp8Linear (module_utils.py:130-191) loaded with a block-scaled FP8 weight: forward = act_quant + fp8 GEMM."""
     from llmc_amd.compression.quantization import LlmcFp8Linear

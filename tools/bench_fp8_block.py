@@ -23,7 +23,8 @@ def timed(fn, reps=5):
 def main():
     g = torch.Generator(device='cuda').manual_seed(0)
     M = 16384
-    for N, K in ((14336, 4096), (4096, 14336)):
+    shapes = ((14336, 4096), (4096, 14336)) + (((7168, 7168),) if '--more' in sys.argv else ())
+    for N, K in shapes:
         x = (torch.randn(M, K, generator=g, device='cuda') * torch.exp(0.5 * torch.randn(K, generator=g, device='cuda'))).to(torch.bfloat16)
         w = (torch.randn(N, K, generator=g, device='cuda') * 0.02).to(torch.bfloat16)
         t_a = timed(lambda: KN.act_quant(x, 128))
