@@ -19,6 +19,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
 
 
+# per-file additions. fp8_block.hip: the accumulator update of the K = 64 GEMM is written as scalar fp32 ops on purpose (packed
+# fp32 VALU beside MFMAs costs extra issue time on gfx950); keep the SLP vectoriser from re-packing it.
+FILE_FLAGS = {'fp8_block.hip': ['-fno-slp-vectorize']}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 
@@ -28,7 +33,7 @@ def _digest(path, deps):
     for p in [path] + deps:
         with open(p, 'rb') as f:
             h.update(f.read())
-    h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(FLAGS + FILE_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
 
 
@@ -41,7 +46,7 @@ def _compile(src, verbose):
     dg = _digest(path, deps)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ['-c', path, '-o', obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ['-c', path, '-o', obj]
     if verbose:
         print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -9,6 +9,7 @@
 // e4m3 rounding is pinned to torch.float8_e4m3fn's cast (RNE) like fp8_pack.hip; products of two e4m3 values are
 // exact in fp32, the 128-deep partial sums accumulate in fp32 inside the MFMA.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include "mfma_common.h"
 
@@ -370,8 +371,8 @@ __global__ __launch_bounds__(256) void k_fp8_block_gemm(const uint8_t* __restric
 //   every ds_read_b128 lane group touches 16 distinct 16-B bank slots.
 //   The MFMA runs transposed (D = B_tile . A_tile^T: n on the accumulator registers, m on the lanes), so a lane needs ONE
 //   activation scale a_s[m, kb] per 32 x 32 accumulator and K block, and b_s[n / 128, kb] is wave-uniform (a scalar load).
-//   Per K block and accumulator: part = 2 MFMAs from a zero C, then acc += (part * a_s) * b_s as packed fp32 VALU (the
-//   order of kernel.py:226, no contraction) — the second wave of the SIMD keeps the matrix pipe busy meanwhile.
+//   Per K block and accumulator: part = 2 MFMAs from a zero C, then acc = fma(part * a_s, b_s, acc) on the fp32 VALU
+//   (kernel.py:226 as Triton compiles it with fp fusion) — the second wave of the SIMD keeps the matrix pipe busy meanwhile.
 //   Which k a lane's 32 operand bytes stand for does not matter as long as both operands use the same bytes: lane l takes
 //   bytes 32 * (l >> 5) .. + 31 of its row's 64-B half, for A and for B.
 // ---------------------------------------------------------------------------------------------------------------
@@ -390,6 +391,9 @@ struct Fp8GemmArgs {
     int64_t M, N, K;
     const void* bias; void* C;
     int ntm, ntn, sbm, sbn, nsn, nrounds;
+#ifdef LLMC_LAB
+    int abl;      // tools/probes/fp8_gemm_lab.hip: 1 no accumulator update, 2 no DMA after a tile's first stage, 4 no MFMA
+#endif
 };
 
 template <int DST>
@@ -506,20 +510,20 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
 
         stage_dma(0u, 0);
 
-        // One K block out of ring slot `st`. n-tile outer (its two operand fragments stay in registers), m-tile inner (fragments
-        // streamed): 16 + 16 fragment registers next to the 128 accumulator registers of a wave that has 256 in all.
-        auto kblock = [&](auto morec, uint32_t st, int kb) {
-            constexpr bool more = decltype(morec)::value;        // another K block follows: request it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            float as_cur[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) as_cur[j] = *(LDS_AS const float*)(lds + asrd + (kb & 1) * 1024 + j * 128);
-            const float bs = bsc[bsrow + kb];
-            const f32x2 bs2 = {bs, bs};
-            // read addresses of this slot; formed here (not hoisted: eight loop-invariant registers less)
-            int adA[2][2], adB[2][2];
+        // Fragment state carried from K block to K block: the first fragments of block k + 1 are read at the END of block k (after
+        // its last MFMAs have issued and the barrier that publishes slot k + 1), under the two accumulator updates still pending,
+        // so a block starts with its operands in registers instead of with a barrier, address arithmetic and an LDS round trip.
+        i32x8 fb[2][2], fa[2][2];
+        int adA[2][2];
+        auto frag = [&](const int (&ad)[2][2], int imm, int kh) -> i32x8 {
+            const i32x4 lo = *(LDS_AS const i32x4*)(lds + ad[kh][0] + imm);
+            const i32x4 hi = *(LDS_AS const i32x4*)(lds + ad[kh][1] + imm);
+            return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        // slot st has landed for every wave: read addresses (formed here, not hoisted: loop-invariant registers are scarce), both
+        // n-tile operands and the first m-tile operand
+        auto first_frags = [&](uint32_t st) {
+            int adB[2][2];
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -527,27 +531,59 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                     asm volatile("v_add_u32 %0, %1, %2" : "=v"(adA[kh][e]) : "s"((int)st + baseA), "v"(choff[kh][e]));
                     asm volatile("v_add_u32 %0, %1, %2" : "=v"(adB[kh][e]) : "s"((int)st + baseB), "v"(choff[kh][e]));
                 }
-            auto frag = [&](const int (&ad)[2][2], int imm, int kh) -> i32x8 {
-                const i32x4 lo = *(LDS_AS const i32x4*)(lds + ad[kh][0] + imm);
-                const i32x4 hi = *(LDS_AS const i32x4*)(lds + ad[kh][1] + imm);
-                return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            };
-            // Eight accumulators t = 4 i + j in a row, software-pipelined inside the wave: the MFMAs of t are issued, then the
-            // fragment reads of t + 1, then the packed-fp32 update of accumulator t - 1 runs under those MFMAs.
-            i32x8 fb[2], fa[2][2];
-            f32x16 pp[2];
-            fb[0] = frag(adB, 0, 0);
-            fb[1] = frag(adB, 0, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) fb[i][kh] = frag(adB, i * 4096, kh);
             fa[0][0] = frag(adA, 0, 0);
             fa[0][1] = frag(adA, 0, 1);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        first_frags(0u);
+
+        // One K block out of ring slot `st`: eight accumulators t = 2 j + i in a row (both n tiles' operand fragments stay in
+        // registers, the m tile's are read once per K block), software-pipelined inside the wave: the MFMAs of t are issued, then
+        // a DMA piece of the next K block, (t even) the fragment reads of the next m tile, then the fp32 update of accumulator
+        // t - 1 runs under those MFMAs.
+        auto kblock = [&](auto morec, uint32_t st, int kb) {
+            constexpr bool more = decltype(morec)::value;        // another K block follows: request it
+            float as_cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) as_cur[j] = *(LDS_AS const float*)(lds + asrd + (kb & 1) * 1024 + j * 128);
+            const float bs = bsc[bsrow + kb];
+            f32x16 pp[2];
             auto update = [&](auto tc) {
-                constexpr int t = decltype(tc)::value, i = t >> 2, j = t & 3;
-                const f32x2 as2 = {as_cur[j], as_cur[j]};
+                constexpr int t = decltype(tc)::value, j = t >> 1, i = t & 1;
+                // acc += part * a_s * b_s the way the reference's Triton kernel is compiled (fp fusion on: the second product
+                // and the sum contract into one fma); scalar fp32 ops: packed ones cost twice the issue time
+#ifdef LLMC_LAB
+                if (a.abl & 1) return;
+                if (a.abl & 16) {        // one op per element (not the reference's rounding)
+                    const float sc = as_cur[j] * bs;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        acc[i][j][r] = f32x2{__builtin_fmaf(pp[t & 1][2 * r], sc, acc[i][j][r][0]), __builtin_fmaf(pp[t & 1][2 * r + 1], sc, acc[i][j][r][1])};
+                    asm volatile("" : "+v"(acc[i][j][0]), "+v"(acc[i][j][1]), "+v"(acc[i][j][2]), "+v"(acc[i][j][3]),
+                                 "+v"(acc[i][j][4]), "+v"(acc[i][j][5]), "+v"(acc[i][j][6]), "+v"(acc[i][j][7]));
+                    return;
+                }
+                if (a.abl & 32) {        // the same op count, not reading the MFMA results
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float v0 = acc[i][j][r][1] * as_cur[j], v1 = acc[i][j][r][0] * as_cur[j];
+                        acc[i][j][r] = f32x2{__builtin_fmaf(v0, bs, acc[i][j][r][0]), __builtin_fmaf(v1, bs, acc[i][j][r][1])};
+                    }
+                    asm volatile("" : "+v"(acc[i][j][0]), "+v"(acc[i][j][1]), "+v"(acc[i][j][2]), "+v"(acc[i][j][3]),
+                                 "+v"(acc[i][j][4]), "+v"(acc[i][j][5]), "+v"(acc[i][j][6]), "+v"(acc[i][j][7]));
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    f32x2 v = f32x2{pp[t & 1][2 * r], pp[t & 1][2 * r + 1]} * as2;
-                    v = v * bs2;
-                    acc[i][j][r] = acc[i][j][r] + v;
+                    const float v0 = pp[t & 1][2 * r] * as_cur[j], v1 = pp[t & 1][2 * r + 1] * as_cur[j];
+                    acc[i][j][r] = f32x2{__builtin_fmaf(v0, bs, acc[i][j][r][0]), __builtin_fmaf(v1, bs, acc[i][j][r][1])};
                 }
                 // the sums are formed HERE (an IR pass otherwise sinks them past the next barrier and keeps the partial
                 // tiles alive)
@@ -555,25 +591,49 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                              "+v"(acc[i][j][4]), "+v"(acc[i][j][5]), "+v"(acc[i][j][6]), "+v"(acc[i][j][7]));
             };
             g2_for<0, 8>([&](auto tc) {
-                constexpr int t = decltype(tc)::value, j = t & 3;
+                constexpr int t = decltype(tc)::value, j = t >> 1, i = t & 1;
                 f32x16 pz;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pz[r] = 0.0f;
-                pp[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[0], fa[j & 1][0], pz, 0, 0, 0, 0, 0, 0);
-                pp[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[1], fa[j & 1][1], pp[t & 1], 0, 0, 0, 0, 0, 0);
+#ifdef LLMC_LAB
+                if (a.abl & 4) {
+                    pp[t & 1] = pz;
+                    pp[t & 1][0] = __builtin_bit_cast(float, fb[i][0][0] ^ fa[j & 1][0][1] ^ fb[i][1][2] ^ fa[j & 1][1][3]);
+                } else
+#endif
+                {
+                // the wave that has MFMAs to issue goes first: the other wave of the SIMD is in its update and can fill the gaps,
+                // the matrix pipe cannot catch up on a late issue
+                __builtin_amdgcn_s_setprio(3);
+                pp[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[i][0], fa[j & 1][0], pz, 0, 0, 0, 0, 0, 0);
+                pp[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[i][1], fa[j & 1][1], pp[t & 1], 0, 0, 0, 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                // the next K block's pieces ride behind the MFMAs, one (the first time two) per accumulator
+                // the next K block's nine pieces ride behind the MFMAs of the first six accumulators
                 if constexpr (more) {
-                    dma_piece(tc, st ^ (uint32_t)G2_STAGE, kb + 1);
-                    if constexpr (t == 0) dma_piece(std::integral_constant<int, 8>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+#ifdef LLMC_LAB
+                    if (a.abl & 2) {
+                    } else
+#endif
+                    {
+                    if constexpr (t < 3) {
+                        dma_piece(std::integral_constant<int, 2 * t>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                        dma_piece(std::integral_constant<int, 2 * t + 1>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                    } else if constexpr (t < 6) dma_piece(std::integral_constant<int, t + 3>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                    }
                 }
-                if constexpr (t == 3) {           // the second n tile's operand (its registers are free once t = 3 has issued)
-                    fb[0] = frag(adB, 4096, 0);
-                    fb[1] = frag(adB, 4096, 1);
+                if constexpr (i == 0 && j < 3) {
+                    fa[(j + 1) & 1][0] = frag(adA, (j + 1) * 4096, 0);
+                    fa[(j + 1) & 1][1] = frag(adA, (j + 1) * 4096, 1);
                 }
-                if constexpr (t < 7) {
-                    fa[(j + 1) & 1][0] = frag(adA, ((j + 1) & 3) * 4096, 0);
-                    fa[(j + 1) & 1][1] = frag(adA, ((j + 1) & 3) * 4096, 1);
+                if constexpr (more && t == 7) {
+                    // every fragment of this slot is in registers: publish the next slot (my pieces landed, then everybody's)
+                    // and fetch its first fragments while updates 6 and 7 are still to run
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    first_frags(st ^ (uint32_t)G2_STAGE);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (t > 0) update(std::integral_constant<int, t - 1>{});
@@ -593,31 +653,42 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
 
         // epilogue: lane = row m, four consecutive n per register group (lanes 0-31 and 32-63 together: 16 B (8 B) runs of fp32
         // (16-bit) outputs per row and store)
-        const bool full = m0 + G2_T <= a.M && n0 + G2_T <= a.N && (a.N & 3) == 0 && a.bias == nullptr;   // block-uniform
+        const bool full = m0 + G2_T <= a.M && n0 + G2_T <= a.N && (a.N & 7) == 0 && a.bias == nullptr;   // block-uniform
         if (full) {
             constexpr int ES = DT == LLMC_F32 ? 4 : 2;
             g2_for<0, 4>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                char* crow = (char*)a.C + ((m0 + wm * 128 + j * 32 + (lane & 31)) * a.N + n0 + wn * 64 + 4 * h) * ES;
+                if constexpr (DT == LLMC_F32) {
+                    char* crow = (char*)a.C + ((m0 + wm * 128 + j * 32 + (lane & 31)) * a.N + n0 + wn * 64 + 4 * h) * ES;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x2 v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
-                        if constexpr (DT == LLMC_F32) {
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x2 v0 = acc[i][j][2 * q], v1 = acc[i][j][2 * q + 1];
                             *reinterpret_cast<float4*>(crow + (i * 32 + 8 * q) * ES) = float4{v0[0], v0[1], v1[0], v1[1]};
-                        } else {
-                            uint2 ov;
-                            if constexpr (DT == LLMC_BF16) {
-                                ov.x = (uint32_t)f32_to_bf16_bits(v0[0]) | ((uint32_t)f32_to_bf16_bits(v0[1]) << 16);
-                                ov.y = (uint32_t)f32_to_bf16_bits(v1[0]) | ((uint32_t)f32_to_bf16_bits(v1[1]) << 16);
-                            } else {
-                                ov.x = (uint32_t)f32_to_f16_bits(v0[0]) | ((uint32_t)f32_to_f16_bits(v0[1]) << 16);
-                                ov.y = (uint32_t)f32_to_f16_bits(v1[0]) | ((uint32_t)f32_to_f16_bits(v1[1]) << 16);
-                            }
-                            *reinterpret_cast<uint2*>(crow + (i * 32 + 8 * q) * ES) = ov;
                         }
-                    }
+                } else {
+                    // 16-bit outputs: a lane's run of four is 8 B. The two halves of the wave trade (v_permlane32_swap) the odd
+                    // group of the lower lanes for the even group of the upper lanes: every lane then owns eight consecutive
+                    // outputs = one 16-B store (half the store instructions: the epilogue is store-issue bound)
+                    char* crow = (char*)a.C + ((m0 + wm * 128 + j * 32 + (lane & 31)) * a.N + n0 + wn * 64 + 8 * h) * ES;
+                    auto pack = [&](f32x2 v) -> uint32_t {
+                        if constexpr (DT == LLMC_BF16) return (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+                        else return (uint32_t)f32_to_f16_bits(v[0]) | ((uint32_t)f32_to_f16_bits(v[1]) << 16);
+                    };
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int qp = 0; qp < 2; ++qp) {
+                            const uint32_t x0 = pack(acc[i][j][4 * qp]), x1 = pack(acc[i][j][4 * qp + 1]);          // group 2 qp
+                            const uint32_t y0 = pack(acc[i][j][4 * qp + 2]), y1 = pack(acc[i][j][4 * qp + 3]);      // group 2 qp + 1
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                            // lanes 0-31: own x (n + 0..3), the partner's x (n + 4..7); lanes 32-63: the partner's y, own y
+                            const uint4 ov = uint4{s0[0], s1[0], s0[1], s1[1]};
+                            *reinterpret_cast<uint4*>(crow + (i * 32 + 16 * qp) * ES) = ov;
+                        }
+                }
             });
         } else {
             g2_for<0, 4>([&](auto jc) {
@@ -763,6 +834,9 @@ extern "C" int llmc_fp8_block_gemm(const void* A8, const float* a_s, const void*
         a.M = M; a.N = N; a.K = K; a.bias = bias; a.C = C;
         a.ntm = (int)ceil_div64(M, G2_T); a.ntn = (int)ceil_div64(N, G2_T);
         g2_tile_order(a, cus);
+#ifdef LLMC_LAB
+        a.abl = getenv("LLMC_FP8_ABL") ? atoi(getenv("LLMC_FP8_ABL")) : 0;
+#endif
         const void* fn = out_dt == LLMC_F16 ? (const void*)k_fp8_block_gemm256<LLMC_F16>
                        : out_dt == LLMC_BF16 ? (const void*)k_fp8_block_gemm256<LLMC_BF16> : (const void*)k_fp8_block_gemm256<LLMC_F32>;
         if (int rc = ensure_dynamic_lds(fn, G2_LDS)) return rc;
