@@ -626,7 +626,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                 __builtin_amdgcn_s_setprio(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // the next K block's nine pieces ride behind the MFMAs of the first six accumulators
+                // the next K block's nine pieces ride behind the MFMAs of the first three accumulators
                 if constexpr (more) {
 #ifdef LLMC_LAB
                     if (a.abl & 2) {
@@ -634,9 +634,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
 #endif
                     {
                     if constexpr (t < 3) {
-                        dma_piece(std::integral_constant<int, 2 * t>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
-                        dma_piece(std::integral_constant<int, 2 * t + 1>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
-                    } else if constexpr (t < 6) dma_piece(std::integral_constant<int, t + 3>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                        dma_piece(std::integral_constant<int, 3 * t>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                        dma_piece(std::integral_constant<int, 3 * t + 1>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                        dma_piece(std::integral_constant<int, 3 * t + 2>{}, st ^ (uint32_t)G2_STAGE, kb + 1);
+                    }
                     }
                 }
                 if constexpr (i == 0 && j < 3) {
