@@ -154,8 +154,8 @@ def _from16(bits, dt):
 
 def test_triton_only_ops_match_goldens_of_the_reference_triton_kernels():
     """kernel.py:7-242 as executed by the reference itself (Triton on ROCm, this GPU model): our HIP act_quant and
-    weight_cast_to_fp8 give the same fp8 codes and fp32 scales bit for bit (the 0 / 0 block included); the block-scaled
-    GEMM gives the same bf16 output up to one rounding of fp32 sums taken in a different order."""
+    weight_cast_to_fp8 give the same fp8 codes and fp32 scales bit for bit (the 0 / 0 block included); so does the block-scaled
+    GEMM's bf16 output."""
     from llmc_amd.compression.quantization import kernel as KN
     g = load_golden('fp8_triton')
     for dt in ('bf16', 'f16'):
@@ -177,4 +177,6 @@ def test_triton_only_ops_match_goldens_of_the_reference_triton_kernels():
         assert (np.abs(c - cref) <= 2.0 ** -7 * np.abs(cref) + 1e-4 * np.abs(cref).max()).all()
         from conftest import report
         report(f'fp8_triton_gemm/{i}', equal_fraction=float((c == cref).mean()))
-        assert (c == cref).mean() > 0.97        # the single bf16 rounding hides almost every fp32-order difference
+        # the K = 64 MFMA and fma(part * a_s, b_s, acc) are what the Triton kernel compiles to on this GPU: every output equal
+        # (measured 1.0 on both golden products; 0.97-0.99 with the K = 16 MFMA and an uncontracted update)
+        assert (c == cref).all(), float((c == cref).mean())
