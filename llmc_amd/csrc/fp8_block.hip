@@ -11,40 +11,15 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include "fp8_math.h"
 #include "mfma_common.h"
 
 namespace llmc {
 
-// fp32 <-> e4m3fn with torch's semantics (same arithmetic as fp8_pack.hip)
-__device__ __forceinline__ uint8_t fb_f32_to_e4m3fn(float x) {
-    const uint32_t b = __float_as_uint(x);
-    const uint32_t sign = (b >> 24) & 0x80u;
-    const uint32_t ab = b & 0x7fffffffu;
-    if (ab > 0x7f800000u) return (uint8_t)(sign | 0x7f);
-    const float ax = __uint_as_float(ab);
-    if (ax < 0.015625f) return (uint8_t)(sign | (uint32_t)rintf(ax * 512.0f));
-    uint32_t r = ab + 0x7ffffu + ((ab >> 20) & 1u);
-    r &= 0xfff00000u;
-    if (r > 0x43e00000u) return (uint8_t)(sign | 0x7f);
-    return (uint8_t)(sign | (((r >> 23) - 120u) << 3) | ((r >> 20) & 7u));
-}
-// Two values at once on v_cvt_pk_fp8_f32 (gfx950: OCP e4m3fn, round to nearest even). Measured against the routine above over
-// 4 M bit patterns (tools/probes/fp8_mfma_probe.hip): identical for every finite |x| <= 464 (= everything that rounds to a finite
-// e4m3 value, subnormals included); NaN and overflow differ (sign of the NaN code), so those take the routine above.
-__device__ __forceinline__ uint32_t fb_f32x2_to_e4m3fn(float x, float y) {
-    if (__builtin_expect(!(fabsf(x) <= 464.0f) || !(fabsf(y) <= 464.0f), 0))
-        return (uint32_t)fb_f32_to_e4m3fn(x) | ((uint32_t)fb_f32_to_e4m3fn(y) << 8);
-    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(x, y, 0, false) & 0xffffu;
-}
-__device__ __forceinline__ float fb_e4m3fn_to_f32(uint8_t v) {
-    const uint32_t e = (v >> 3) & 0xf, m = v & 7;
-    float r;
-    if ((v & 0x7f) == 0x7f) r = __uint_as_float(0x7fc00000u);
-    else if (e == 0) r = (float)m * 0.001953125f;
-    else r = __uint_as_float(((e + 120u) << 23) | (m << 20));
-    // sign by bit: a negative zero must stay negative ((q - 0) * s = -0.0 in the reference)
-    return __uint_as_float(__float_as_uint(r) | ((uint32_t)(v & 0x80) << 24));
-}
+// fp32 <-> e4m3fn: fp8_math.h (torch's semantics; the pair form uses the hardware conversion for in-range values)
+__device__ __forceinline__ uint8_t fb_f32_to_e4m3fn(float x) { return f32_to_e4m3fn(x); }
+__device__ __forceinline__ uint32_t fb_f32x2_to_e4m3fn(float x, float y) { return f32x2_to_e4m3fn(x, y); }
+__device__ __forceinline__ float fb_e4m3fn_to_f32(uint8_t v) { return e4m3fn_to_f32(v); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // One workgroup per b x b block (b <= 128): absmax, scale = max(absmax, clamp_min) / 448 in fp32, then

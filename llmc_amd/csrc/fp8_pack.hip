@@ -4,39 +4,11 @@
 //                       rounding is pinned to torch.float8_e4m3fn's cast (RNE, no saturation: > 464 -> NaN).
 //   llmc_pack_awq_gemm  module_utils.py:1004-1065.
 #include "common.h"
+#include "fp8_math.h"
 
 namespace llmc {
 
 static constexpr int FB = 256;
-
-// fp32 -> e4m3fn bits with torch's semantics
-__device__ __forceinline__ uint8_t f32_to_e4m3fn(float x) {
-    const uint32_t b = __float_as_uint(x);
-    const uint32_t sign = (b >> 24) & 0x80u;
-    const uint32_t ab = b & 0x7fffffffu;
-    if (ab > 0x7f800000u) return (uint8_t)(sign | 0x7f);  // NaN
-    const float ax = __uint_as_float(ab);
-    if (ax < 0.015625f) {  // below 2^-6: subnormal grid 2^-9 (rint = RNE); 8 -> smallest normal
-        const uint32_t m = (uint32_t)rintf(ax * 512.0f);
-        return (uint8_t)(sign | m);
-    }
-    // round the fp32 mantissa to 3 bits, RNE, carry propagates into the exponent
-    uint32_t r = ab + 0x7ffffu + ((ab >> 20) & 1u);
-    r &= 0xfff00000u;
-    if (r > 0x43e00000u) return (uint8_t)(sign | 0x7f);  // > 448 after rounding (incl. inf) -> NaN
-    const uint32_t e = (r >> 23) - 127 + 7;
-    const uint32_t m = (r >> 20) & 7u;
-    return (uint8_t)(sign | (e << 3) | m);
-}
-__device__ __forceinline__ float e4m3fn_to_f32(uint8_t v) {
-    const uint32_t e = (v >> 3) & 0xf, m = v & 7;
-    float r;
-    if ((v & 0x7f) == 0x7f) r = __uint_as_float(0x7fc00000u);
-    else if (e == 0) r = (float)m * 0.001953125f;
-    else r = __uint_as_float(((e - 7 + 127) << 23) | (m << 20));
-    // sign by bit: a negative zero must stay negative ((q - 0) * s = -0.0 in the reference)
-    return __uint_as_float(__float_as_uint(r) | ((uint32_t)(v & 0x80) << 24));
-}
 
 // amax[row] = clamp(absmax, 1e-5) in dt (from llmc_minmax_qparams with qmax = 1). scale = amax / 448 in the
 // scales' dtype sdt: ATen promotes the 0-dim per-tensor absmax (dt) / 0-dim fp32 qmax to fp32, but keeps dt for
@@ -47,6 +19,20 @@ __device__ __forceinline__ void fp8_one(float w, float s, int tdt, int fake, int
     const uint8_t q = f32_to_e4m3fn(t);
     if (fake) *of = from_f32<T>(opaque_f32(e4m3fn_to_f32(q) * s));   // fp32 product, one rounding to dt
     else *ob = q;
+}
+// two elements: one hardware conversion (fp8_math.h)
+template <typename T>
+__device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, int fake, T* of, uint8_t* ob) {
+    const float t0 = rnd(rnd(w0 / s, tdt) + 0.0f, tdt), t1 = rnd(rnd(w1 / s, tdt) + 0.0f, tdt);
+    const uint32_t c = f32x2_to_e4m3fn(t0, t1);
+    const uint8_t q0 = (uint8_t)c, q1 = (uint8_t)(c >> 8);
+    if (fake) {
+        of[0] = from_f32<T>(opaque_f32(e4m3fn_to_f32(q0) * s));
+        of[1] = from_f32<T>(opaque_f32(e4m3fn_to_f32(q1) * s));
+    } else {
+        ob[0] = q0;
+        ob[1] = q1;
+    }
 }
 
 template <typename T>
@@ -78,7 +64,7 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
             T of[V];
             uint8_t ob[V];
 #pragma unroll
-            for (int k = 0; k < V; ++k) fp8_one<T>(to_f32<T>(wv[k]), s, tdt, fake, DT, &of[k], &ob[k]);
+            for (int k = 0; k < V; k += 2) fp8_two<T>(to_f32<T>(wv[k]), to_f32<T>(wv[k + 1]), s, tdt, fake, &of[k], &ob[k]);
             if (fake) {
                 uint4 o;
                 __builtin_memcpy(&o, of, 16);
