@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_fp8_act_quant(const T* __restrict__ X, 
 // 64 x 64 = 2 x 2 MFMA 32x32x16 accumulators. Per K block of 128: both 128 x 128-byte panels are staged in LDS
 // (rows padded to 144 B: the 8-byte fragment reads of a 32-lane half then touch every bank pair once), eight
 // fp8 MFMAs per accumulator build the block's partial sum, which enters the result as
-//     acc += (partial * a_s[row]) * b_s          (the order of kernel.py:226; no contraction)
+//     acc = fma(partial * a_s[row], b_s, acc)    (kernel.py:226 with Triton's fp fusion, like k_fp8_block_gemm256 below)
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr int FG_T = 128;
 static constexpr int FG_LD = 144;
@@ -328,9 +328,7 @@ __global__ __launch_bounds__(256) void k_fp8_block_gemm(const uint8_t* __restric
                 const float as = row < M ? As[row * nkb + kb] : 0.0f;
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    float t = part[m][n][r] * as;
-                    t = t * bs;
-                    acc[m][n][r] = acc[m][n][r] + t;
+                    acc[m][n][r] = __builtin_fmaf(part[m][n][r] * as, bs, acc[m][n][r]);   // as the Triton kernel compiles it
                 }
             }
     }
@@ -645,6 +643,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
 
         // epilogue: lane = row m, four consecutive n per register group (lanes 0-31 and 32-63 together: 16 B (8 B) runs of fp32
         // (16-bit) outputs per row and store)
+        {
+        // the output addresses are formed AFTER the K loop (opaque tile indices: hipcc otherwise computes them before the loop
+        // and spills them across it)
+        int tme = tm, tne = tn;
+        asm volatile("" : "+s"(tme), "+s"(tne));
+        const int64_t m0 = (int64_t)tme * G2_T, n0 = (int64_t)tne * G2_T;
         const bool full = m0 + G2_T <= a.M && n0 + G2_T <= a.N && (a.N & 7) == 0 && a.bias == nullptr;   // block-uniform
         if (full) {
             constexpr int ES = DT == LLMC_F32 ? 4 : 2;
@@ -702,6 +706,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                             }
                 }
             });
+        }
         }
     }
 }

@@ -16,3 +16,4 @@ timeout 100 python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline -
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 python tools/kernel_stats_csv.py $O/kt/kt_kernel_trace.csv 32 > $O/kernel_stats.txt 2>&1; rm -rf $O/kt; head -8 $O/kernel_stats.txt
 timeout 200 python tools/bench_stages.py > $O/stage_times.txt 2>&1; tail -4 $O/stage_times.txt
+timeout 200 python tools/bench_fp8_block.py --more > $O/fp8_block_rates.txt 2>&1; tail -3 $O/fp8_block_rates.txt
