@@ -85,7 +85,10 @@ class Awq(BaseBlockwiseQuantization):
     @torch.no_grad()
     def get_scales(self, prev_op, x, w_max, is_gqa, ratio):
         if is_gqa:
-            raise NotImplementedError('GQA v-proj -> o-proj transformation is outside the hot path')
+            # awq.py:89-91, 104-105: the scales of a GQA v_proj -> o_proj subset come from v_proj's OUTPUT (one per key/value
+            # channel), always in the v2 form
+            x = awq_ops.linear_auto(x, prev_op.weight.data, getattr(prev_op, 'bias', None))
+            return awq_ops.awq_scales(self._act_scale_batched(x), None, ratio, 'v2')
         return awq_ops.awq_scales(self.get_act_scale(x), w_max, ratio, self.trans_version)
 
     # ---- the reference's helper surface (awq.py:110-145), used by the general route ---------------------------
@@ -133,10 +136,11 @@ class Awq(BaseBlockwiseQuantization):
 
     @torch.no_grad()
     def search_scale_subset(self, prev_op, layers_dict, input, inspect_module, is_gqa, subset_kwargs):
-        if is_gqa:
-            raise NotImplementedError('GQA v-proj -> o-proj transformation is outside the hot path')
         self._bs = input[0].shape[0] if self.awq_bs is None else self.awq_bs
-        if self._fused_route_ok(layers_dict, input, inspect_module, subset_kwargs):
+        if is_gqa:
+            best_scales, best_error = self._search_scale_general(layers_dict, input, inspect_module, subset_kwargs,
+                                                                 prev_op=prev_op, is_gqa=True)
+        elif self._fused_route_ok(layers_dict, input, inspect_module, subset_kwargs):
             x = input[0]
             weights = [fc.weight.data for fc in layers_dict.values()]
             best_scales, losses, n = search_scale_stacked(weights, x, self.wquantizer, self.trans_version,
@@ -155,9 +159,11 @@ class Awq(BaseBlockwiseQuantization):
         return best_scales
 
     @torch.no_grad()
-    def _search_scale_general(self, layers_dict, input, inspect_module, subset_kwargs, n_grid=20):
+    def _search_scale_general(self, layers_dict, input, inspect_module, subset_kwargs, n_grid=20, prev_op=None, is_gqa=False):
         """awq.py:189-253 with the module kept on the device: weights are restored from a device copy after every
-        evaluation (the reference reloads a CPU state dict), everything else in the reference's order."""
+        evaluation (the reference reloads a CPU state dict), everything else in the reference's order. is_gqa (do_gqa_trans):
+        the scales are per key/value channel of `prev_op` (v_proj) and reach the layer and its input repeated per query-head
+        group (repeat_gqa_scales)."""
         layers = list(layers_dict.values())
         w_max = self.get_weight_scale(layers_dict)
         org_w = [fc.weight.data.clone() for fc in layers]
@@ -174,10 +180,15 @@ class Awq(BaseBlockwiseQuantization):
                         org_out_dict[i] = self.get_original_out(x, inspect_module, kwargs)
                     org_out = org_out_dict[i]
                     ratio = n * 1 / n_grid
-                    scales = awq_ops.awq_scales(self._act_scale_batched(x), w_max, ratio, self.trans_version)
+                    if is_gqa:
+                        scales = self.get_scales(prev_op, x, w_max, True, ratio)
+                        cols = self.repeat_gqa_scales(scales).reshape(-1).contiguous()
+                    else:
+                        scales = awq_ops.awq_scales(self._act_scale_batched(x), w_max, ratio, self.trans_version)
+                        cols = scales
                     for fc, w0 in zip(layers, org_w):      # fake_quantize_weight (awq.py:147-164)
-                        fc.weight.data = awq_ops.scale_fakequant(w0, scales, self.wquantizer)
-                    x_tmp = awq_ops.div_cols(x, scales)   # scaling_input (base_blockwise_quantization.py:877-889)
+                        fc.weight.data = awq_ops.scale_fakequant(w0, cols, self.wquantizer)
+                    x_tmp = awq_ops.div_cols(x, cols)     # scaling_input (base_blockwise_quantization.py:877-889)
                     out = self.inspect_module_forward(x_tmp, inspect_module, kwargs)
                     if self.padding_mask and org_out.shape[1] == self.padding_mask[i].shape[-1]:
                         m = self.padding_mask[i].unsqueeze(dim=-1).to(org_out.device)
@@ -229,20 +240,22 @@ class Awq(BaseBlockwiseQuantization):
         if not isinstance(prev_op[0], ln_types + lin_types) and not hasattr(prev_op[0], 'weight'):
             return
         layers = list(layers_dict.values())
+        is_gqa = False
         if isinstance(prev_op[0], (nn.Linear, FakeQuantLinear)):
             of, inf = prev_op[0].out_features, layers[0].in_features
             if of not in (inf * 3, inf * 2, inf):
                 if getattr(self, 'has_gqa', False) and getattr(self, 'do_gqa_trans', False):
-                    # awq.py:338-343 transforms v_proj -> o_proj with repeated scales here; not built: refuse loudly
-                    # instead of silently leaving the subset untransformed
-                    raise NotImplementedError('Awq: do_gqa_trans (GQA v_proj -> o_proj scale folding, awq.py:338-343) '
-                                              'is outside the hot path; set special.do_gqa_trans: False')
-                return                                                      # awq.py:344-346: "Cannot apply scale"
+                    # awq.py:338-343: v_proj -> o_proj of a GQA attention; the search runs on the inputs of the previous subset
+                    is_gqa = True
+                    input_keys = list(input_feat.keys())
+                    input_name = input_keys[input_keys.index(input_name) - 1]
+                else:
+                    return                                                  # awq.py:344-346: "Cannot apply scale"
 
-        scale = self.search_scale_subset(prev_op[0], layers_dict, input_feat[input_name], subset['inspect'], False,
+        scale = self.search_scale_subset(prev_op[0], layers_dict, input_feat[input_name], subset['inspect'], is_gqa,
                                          subset_kwargs)
         self.apply_scale(scale, prev_op, layers)
-        self.update_input_feat(scale, input_feat, layers_dict, False)
+        self.update_input_feat(scale, input_feat, layers_dict, is_gqa)
         if self.save_scale:
             for n in layers_dict:
                 self.act_scales[f'{self.model.block_name_prefix}.{self.block_idx}.{n}'] = scale

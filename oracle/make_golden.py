@@ -650,6 +650,67 @@ def suite_awq_inspect():
     save('awq_inspect', **out)
 
 
+def suite_awq_gqa():
+    """special.do_gqa_trans (awq.py:88-108, 338-365; base_blockwise_quantization.py:591-595, 678-685, 877-897): the v_proj -> o_proj
+    subset of a GQA attention (fewer key/value heads than query heads). The scales live on v_proj's output channels and are
+    repeated per query-head group for o_proj; the search runs on the inputs of the PREVIOUS subset (q/k/v's), as the reference
+    does. Goldens: the 20 x batches losses, the best scales, both weights after apply_scale, o_proj's inputs after
+    update_input_feat."""
+    import torch.distributed as dist
+    from llmc.compression.quantization.awq import Awq
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29594', rank=0, world_size=1)
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()
+    out = {}
+    gen = torch.Generator().manual_seed(4242)
+    cfgs = [('bf16_sym_g128', 'bf16', True, 128, True), ('f16_asym_g64_2batch', 'f16', False, 64, False)]
+    for name, dt, sym, gs, one_batch in cfgs:
+        H, NH, NKV, HD, B, S = 256, 8, 2, 32, 2, 40
+        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.aquantizer, a.w_only, a.awq_bs, a.save_mem = wq, None, True, None, False
+        a.trans_version, a.has_gqa, a.do_gqa_trans, a.padding_mask = 'v2', True, True, None
+        a.num_key_value_heads, a.head_dim, a.num_key_value_groups = NKV, HD, NH // NKV
+        a.fp8_block_size = 128
+        nb = 1 if one_batch else 2
+        a.n_samples = nb * B
+        v_proj = torch.nn.Linear(H, NKV * HD, bias=True).to(DT[dt])
+        o_proj = torch.nn.Linear(NH * HD, H, bias=False).to(DT[dt])
+        v_proj.weight.data = (torch.randn(NKV * HD, H, generator=gen) * 0.05 * torch.exp(0.7 * torch.randn(NKV * HD, 1, generator=gen))).to(DT[dt])
+        v_proj.bias.data = (torch.randn(NKV * HD, generator=gen) * 0.02).to(DT[dt])
+        wo = torch.randn(H, NH * HD, generator=gen) * 0.05
+        wo[:, torch.randperm(NH * HD, generator=gen)[:6]] *= 8
+        o_proj.weight.data = wo.to(DT[dt])
+        c = torch.exp(0.5 * torch.randn(H, generator=gen))
+        xs = [(torch.randn(B, S, H, generator=gen) * c).to(DT[dt]) for _ in range(nb)]                 # q/k/v's input
+        xo = [(torch.randn(B, S, NH * HD, generator=gen)).to(DT[dt]) for _ in range(nb)]             # o_proj's input
+        losses = []
+        orig = a.calculate_loss
+
+        def rec(org_out, o, _orig=orig):
+            v = _orig(org_out, o)
+            losses.append(v)
+            return v
+        a.calculate_loss = rec
+        p = name + '/'
+        out[p + 'v_w'], out[p + 'v_b'], out[p + 'o_w'] = f32(v_proj.weight.data), f32(v_proj.bias.data), f32(o_proj.weight.data)
+        for i in range(nb):
+            out[p + f'x{i}'], out[p + f'xo{i}'] = f32(xs[i]), f32(xo[i])
+        scale = a.search_scale_subset(v_proj, {'o_proj': o_proj}, [x.clone() for x in xs], o_proj, True, {})
+        a.apply_scale(scale, [v_proj], [o_proj])
+        feat = {'o_proj': [x.clone() for x in xo]}
+        a.update_input_feat(scale, feat, {'o_proj': o_proj}, True)
+        out[p + 'best_scales'] = f32(scale)
+        out[p + 'losses'] = np.array(losses, dtype=np.float64)
+        out[p + 'v_w_after'], out[p + 'v_b_after'], out[p + 'o_w_after'] = f32(v_proj.weight.data), f32(v_proj.bias.data), f32(o_proj.weight.data)
+        for i in range(nb):
+            out[p + f'xo{i}_after'] = f32(feat['o_proj'][i])
+        out[p + 'meta'] = np.array([int(sym), gs, H, NH, NKV, HD, nb], dtype=np.int64)
+        out[p + 'dt'] = np.array(dt)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('awq_gqa', **out)
+
+
 def suite_clip():
     """AutoClipper.auto_clip_layer / apply_clip (clip_version v1, w_only)."""
     from llmc.compression.quantization.auto_clip import AutoClipper
@@ -1077,7 +1138,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

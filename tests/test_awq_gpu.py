@@ -299,6 +299,49 @@ def test_search_with_inspected_mlp_two_batches_and_mask_matches_reference_golden
         assert u.max() <= 2, (name, u.max())
 
 
+def test_gqa_v_to_o_transformation_matches_reference_golden():
+    """special.do_gqa_trans (awq.py:88-108, 338-365): the v_proj -> o_proj subset of a GQA attention. Scales per key/value channel
+    from v_proj's output, repeated per query-head group for o_proj's weight and input; same loss curve and winner as the
+    reference, v_proj / o_proj after apply_scale and o_proj's inputs after update_input_feat within an ulp of the scales'
+    difference (tests/golden/awq_gqa.npz, the reference's own classes)."""
+    from llmc_amd.compression.quantization.awq import Awq
+    g = load_golden('awq_gqa')
+    from conftest import report
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        sym, gs, H, NH, NKV, HD, nb = [int(v) for v in g[p + 'meta']]
+        dt = str(g[p + 'dt'])
+        v_proj = torch.nn.Linear(H, NKV * HD, bias=True).to(TD[dt]).cuda()
+        o_proj = torch.nn.Linear(NH * HD, H, bias=False).to(TD[dt]).cuda()
+        v_proj.weight.data, v_proj.bias.data, o_proj.weight.data = dev(g[p + 'v_w'], dt), dev(g[p + 'v_b'], dt), dev(g[p + 'o_w'], dt)
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.w_only, a.awq_bs, a.save_mem, a.padding_mask = make_q(sym, gs), True, None, False, None
+        a.trans_version, a.n_samples, a.has_gqa, a.do_gqa_trans, a.save_scale = 'v2', nb * 2, True, True, False
+        a.num_key_value_heads, a.head_dim, a.num_key_value_groups = NKV, HD, NH // NKV
+        rec = []
+        orig = Awq.calculate_loss
+        a.calculate_loss = lambda org_out, out, _a=a: rec.append(orig(_a, org_out, out)) or rec[-1]
+        # through subset_transform: the search must pick the inputs of the PREVIOUS subset (q/k/v's), like the reference
+        feat = {'self_attn.q_proj': [dev(g[p + f'x{i}'], dt) for i in range(nb)],
+                'self_attn.o_proj': [dev(g[p + f'xo{i}'], dt) for i in range(nb)]}
+        subset = {'layers': {'self_attn.o_proj': o_proj}, 'prev_op': [v_proj], 'input': ['self_attn.o_proj'], 'inspect': o_proj,
+                  'has_kwargs': False}
+        Awq.subset_transform(a, subset, feat, {})
+        ours = np.array([float(v) for v in rec])
+        ref = g[p + 'losses']
+        assert ours.shape == ref.shape == (20 * nb,), name
+        report('awq_gqa_losses/' + name, max_rel=float((np.abs(ours - ref) / ref).max()))
+        np.testing.assert_allclose(ours, ref, rtol=1e-4, err_msg=name)       # measured: max 4.8e-6
+        # the folded weights: v_proj / scales, o_proj * repeat(scales); inputs / repeat(scales)
+        for ours_t, key in ((v_proj.weight.data, 'v_w_after'), (v_proj.bias.data, 'v_b_after'), (o_proj.weight.data, 'o_w_after')):
+            u = ulps(host(ours_t), g[p + key], dt)
+            assert u.max() <= 4, (name, key, u.max())
+        for i in range(nb):
+            u = ulps(host(feat['self_attn.o_proj'][i]), g[p + f'xo{i}_after'], dt)
+            assert u.max() <= 4, (name, i, u.max())
+        assert 'forward' not in o_proj.__dict__
+
+
 def test_fused_route_only_for_single_inspected_linear():
     from llmc_amd.compression.quantization.awq import Awq
     a = Awq.__new__(Awq)
