@@ -67,9 +67,11 @@ def parse_args(argv=None):
     ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
                     help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
                          'vllm: sym g128 static groups + INT4 pack (configs/quantization/backend/vllm/gptq_w4a16.yml)')
-    ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq'],
+    ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq', 'fp8'],
                     help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
-                         'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch')
+                         'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch; fp8: configs[4], FP8 '
+                         '(e4m3) per-tensor weight quantization + static per-tensor activation ranges on the Linear shapes of one '
+                         'Mixtral-8x7B block (8 experts)')
     ap.add_argument('--mode', default=None, choices=['independent', 'handoff', 'cooperative'],
                     help='N > 1 (default handoff): independent = every rank quantizes its own blocks, no data-path traffic; '
                          'handoff = the same ownership, and the calibration activations entering a block arrive from the '
@@ -86,7 +88,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary workloads reported under "extra" (N = 1 only): AWQ (BASELINE configs[2]), the '
-                         'vLLM-exportable GPTQ variant with INT4 packing, Llama-3-70B shapes')
+                         'vLLM-exportable GPTQ variant with INT4 packing, Llama-3-70B shapes, FP8 on Mixtral shapes (configs[4])')
     return ap.parse_args(argv)
 
 
@@ -442,6 +444,103 @@ def run_awq(args):
         torch.distributed.destroy_process_group()
 
 
+PEAK_HBM = 8.0e12   # spec, /opt/skills/guides/MI355X_MICROARCH.md (about 6.3e12 measured)
+
+
+def run_fp8(args):
+    """BASELINE configs[4]: FP8 (e4m3) per-tensor weight + activation quantization on Mixtral-8x7B expert Linear shapes
+    (configs/quantization/backend/vllm/fp8/*.yml with per_tensor granularity). Quantization time, per block: every Linear's
+    weight -> absmax -> scale -> e4m3 codes (FloatQuantizer.real_quant_weight_dynamic: llmc_minmax_qparams + llmc_fp8_quant),
+    and the static per-tensor range of every Linear input over the calibration tokens (mean of per-sample min / max,
+    base_blockwise_quantization.py:253-263: llmc_minmax_samples, one launch pair per input)."""
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback in llmc_amd)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    from llmc_amd.compression.quantization import FloatQuantizer
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
+    h, kv, ffn, n_exp = 4096, 1024, 14336, 8              # Mixtral-8x7B: llmc/models/mixtral.py:43-86
+    layers = [('q_proj', h, h), ('k_proj', kv, h), ('v_proj', kv, h), ('o_proj', h, h)]
+    for e in range(n_exp):
+        layers += [(f'experts.{e}.w1', ffn, h), (f'experts.{e}.w3', ffn, h), (f'experts.{e}.w2', h, ffn)]
+    n_seq, seq = 128, 512
+    wq = FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True)
+    weights = [synth_weight(R, K, rank * 64 + i, dev, dtype) for i, (_, R, K) in enumerate(layers)]
+    # inputs: attention in, o_proj in (all tokens); an expert sees top-2 of 8 = a quarter of the tokens on average
+    acts = {'attn_in': synth_acts(n_seq, seq, h, rank * 64 + 1, dev, dtype), 'o_in': synth_acts(n_seq, seq, h, rank * 64 + 2, dev, dtype)}
+    for e in range(n_exp):
+        acts[f'e{e}_in'] = synth_acts(n_seq // 4, seq, h, rank * 64 + 8 + e, dev, dtype)
+        acts[f'e{e}_mid'] = synth_acts(n_seq // 4, seq, ffn, rank * 64 + 24 + e, dev, dtype)
+
+    from llmc_amd.compression.quantization.hist_range import sample_minmax
+    samples = {k: [x[i] for i in range(x.shape[0])] for k, x in acts.items()}      # what the hooks deliver: one tensor per sample
+
+    def step():
+        out = [wq.real_quant_weight_dynamic(w) for w in weights]
+        for k in acts:                # static_minmax: mean over samples of the per-sample range (register_act_qparams)
+            mn, mx = sample_minmax(samples[k])
+            out.append(torch.max(mx.mean().abs(), mn.mean().abs()).clamp(min=1e-5) / 448.0)
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    # the dominant kernel alone: the cast of one 14336 x 4096 weight, HIP events on the current stream
+    w = weights[4]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    wq.real_quant_weight_dynamic(w)
+    e0.record()
+    for _ in range(reps):
+        wq.real_quant_weight_dynamic(w)
+    e1.record()
+    torch.cuda.synchronize()
+    t_w = e0.elapsed_time(e1) * 1e-3 / reps
+    wbytes = 5.0 * w.numel()          # 2 B min/max pass + 2 B cast pass + 1 B codes
+    if rank == 0:
+        elems = sum(R * K for _, R, K in layers)
+        abytes = sum(2.0 * x.numel() for x in acts.values())
+        print(json.dumps({
+            'metric': 'layers/sec (FP8 e4m3 per-tensor weight quantization + static activation ranges, Mixtral-8x7B block shapes)',
+            'value': len(layers) * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f8e4m3 codes from ' + args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'FP8 e4m3 symmetric per-tensor RTN: 28 Linear weights of one Mixtral-8x7B block (4 attention + 8 experts '
+                                   'x 3) -> absmax, scale, codes; static per-tensor ranges of their 18 inputs (128 x 512 calibration '
+                                   'tokens, experts a quarter each), 1 block per step per GPU',
+                       'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'block-sharded x{world}' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'hbm', 'achieved': wbytes / t_w / 1e9, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
+                         'frac': wbytes / t_w / PEAK_HBM, 'traffic': None,
+                         'kernel': 'k_minmax_partial + k_fp8_cast on a 14336 x 4096 weight (5 B per element: two 16-bit reads, one code '
+                                   'written); the Python call, events on the launch stream',
+                         'launches': reps, 'algorithmic_bytes_per_launch': wbytes, 'avg_launch_ms': t_w * 1e3,
+                         'whole_step_gbps': (5.0 * elems + abytes) * args.steps / dt / 1e9},
+            'cpu_baseline': None,
+        }), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def run_extras(args):
     """The secondary workloads, a few steps each, as child runs of this script (same code path as their own bench
     lines): value / ms_per_step / roofline of each go under "extra" of the one JSON line."""
@@ -449,6 +548,7 @@ def run_extras(args):
         'awq_llama3_8b': ['--workload', 'awq', '--steps', '2', '--warmup', '1'],
         'gptq_vllm_variant_packed': ['--variant', 'vllm', '--steps', '3', '--warmup', '1'],
         'gptq_llama3_70b_shapes': ['--model', 'llama3-70b', '--steps', '2', '--warmup', '1'],
+        'fp8_mixtral_8x7b_shapes': ['--workload', 'fp8', '--steps', '3', '--warmup', '1'],
     }
     out = {}
     for key, flags in runs.items():
@@ -475,6 +575,8 @@ def main():
         sys.exit(rc)
     if args.workload == 'awq':
         return run_awq(args)
+    if args.workload == 'fp8':
+        return run_fp8(args)
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))

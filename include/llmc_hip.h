@@ -85,6 +85,17 @@ int llmc_minmax_qparams(const void* W, int dt, int64_t G, int64_t g, int sym, in
  * counts; bin = int((x - min) * bins / (max - min)) in fp32, the right edge belongs to the last bin, values outside the
  * range are dropped, min == max widens the range by one on both sides (ATen). ws: llmc_histc_ws_bytes(bins). The merge
  * of the per-sample histograms and the range search (quant.py:279-460) work on `bins` numbers and stay host code. */
+/* Per-sample min / max of n <= llmc_minmax_samples_max() calibration samples in one launch pair: what `sample.min()`,
+ * `sample.max()` give for every sample in get_minmax_stats / get_moving_minmax / the first pass of the histogram observer
+ * (quant.py:253-263, 524-543, 462-475). X_list_host[i]: device address of sample i (16-B aligned, its own allocation),
+ * len_list_host[i] its element count; both arrays live on the HOST (they travel in the kernel arguments). mn / mx: fp32 [n]
+ * on the device (the values are elements of the samples, exact in fp32); a NaN in a sample makes both of its results NaN,
+ * like torch. ws: llmc_minmax_samples_ws_bytes(len_list_host, n). */
+int llmc_minmax_samples_max(void);
+size_t llmc_minmax_samples_ws_bytes(const int64_t* len_list_host, int n);
+int llmc_minmax_samples(const void* const* X_list_host, const int64_t* len_list_host, int n, int dt, float* mn, float* mx,
+                        void* ws, llmc_stream_t stream);
+
 size_t llmc_histc_ws_bytes(int bins);
 int llmc_histc(const void* x, int dt, int64_t n, int bins, float min, float max, float* out, void* ws,
                llmc_stream_t stream);

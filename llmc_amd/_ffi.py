@@ -27,6 +27,9 @@ SIGNATURES = {
     'llmc_hip_set_cu_reserve': (_i32, [_i32]),
     'llmc_minmax_qparams_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_minmax_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    'llmc_minmax_samples_max': (_i32, []),
+    'llmc_minmax_samples_ws_bytes': (_sz, [_vp, _i32]),
+    'llmc_minmax_samples': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'llmc_histc_ws_bytes': (_sz, [_i32]),
     'llmc_histc': (_i32, [_vp, _i32, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),
     'llmc_mse_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),

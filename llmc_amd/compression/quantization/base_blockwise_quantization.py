@@ -259,16 +259,22 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
         algo = getattr(aq, 'calib_algo', 'static_minmax')
         if algo == 'static_moving_minmax':
             # quant.py:524-543: exponential moving average of the per-sample ranges (alpha = 0.01, the default of
-            # get_batch_tensors_qparams), in the sample dtype like the reference
+            # get_batch_tensors_qparams), in the sample dtype like the reference. The per-sample min / max come from one
+            # kernel pass (hist_range.sample_minmax); the recurrence runs on the host on 0-dim tensors of the sample dtype —
+            # the arithmetic the reference performs on its (CPU) scalars
+            from .hist_range import sample_minmax
             alpha = 0.01
+            smn, smx = sample_minmax(samples)
+            smn, smx = smn.cpu().to(samples[0].dtype), smx.cpu().to(samples[0].dtype)
             mn = mx = None
-            for smp in samples:
-                a, b = smp.min(), smp.max()
+            for a, b in zip(smn, smx):
                 mn, mx = (a, b) if mn is None else (mn + alpha * (a - mn), mx + alpha * (b - mx))
+            mn, mx = mn.to(samples[0].device), mx.to(samples[0].device)
         elif algo in ('static_minmax', 'minmax'):
             # quant.py:253-263: mean over samples of per-sample min / max (fp32), then get_qparams on the means
-            mx = torch.stack([s.max().float() for s in samples]).mean()
-            mn = torch.stack([s.min().float() for s in samples]).mean()
+            from .hist_range import sample_minmax
+            smn, smx = sample_minmax(samples)
+            mx, mn = smx.mean(), smn.mean()
         elif algo == 'static_hist':
             # quant.py:462-512 (+ get_batch_tensors_qparams' assert, :564-568): histogram-observer range, data pass in HIP
             assert aq.sym is True and aq.granularity == 'per_tensor', \

@@ -15,6 +15,30 @@ from llmc_amd import _ffi
 F = np.float32
 
 
+def sample_minmax(samples):
+    """fp32 (min, max) of every calibration sample, [n] each on the device: `sample.min()`, `sample.max()` of quant.py:253-263,
+    524-543 for all samples in one launch pair per 160 samples (`llmc_minmax_samples`: the samples are separate allocations,
+    their addresses travel in the kernel arguments). The values are elements of the samples, so fp32 holds them exactly."""
+    import ctypes
+    _ffi.require_gpu(*samples)
+    L = _ffi.lib()
+    xs = [s if s.is_contiguous() else s.contiguous() for s in samples]
+    assert all(x.dtype == xs[0].dtype for x in xs), 'calibration samples of one input share a dtype'
+    dev = xs[0].device
+    mn = torch.empty(len(xs), dtype=torch.float32, device=dev)
+    mx = torch.empty(len(xs), dtype=torch.float32, device=dev)
+    cap = L.llmc_minmax_samples_max()
+    for i0 in range(0, len(xs), cap):
+        part = xs[i0:i0 + cap]
+        n = len(part)
+        ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in part])
+        lens = (ctypes.c_int64 * n)(*[x.numel() for x in part])
+        ws = _ffi.workspace(L.llmc_minmax_samples_ws_bytes(lens, n), dev)
+        _ffi.check(L.llmc_minmax_samples(ptrs, lens, n, _ffi.dt(part[0]), mn[i0:].data_ptr(), mx[i0:].data_ptr(), _ffi.ptr(ws),
+                                         _ffi.stream()), 'llmc_minmax_samples')
+    return mn, mx
+
+
 class HistRange:
     def __init__(self, bins=2048, upsample_rate=16, dst_nbins=256):
         self.bins, self.ups, self.dst = int(bins), int(upsample_rate), int(dst_nbins)
@@ -30,12 +54,15 @@ class HistRange:
                                 _ffi.ptr(ws), _ffi.stream()), 'llmc_histc')
         return out.cpu().numpy()
 
-    def add(self, sample):
-        """One calibration sample (quant.py:471-503)."""
+    def add(self, sample, minmax=None):
+        """One calibration sample (quant.py:471-503); minmax = its (min, max) when the caller already has them."""
         _ffi.require_gpu(sample)
         x = sample.contiguous().reshape(-1)
-        mm = torch.stack([x.min(), x.max()]).float().cpu().numpy()      # get_minmax_stats: fp32 copies of min / max
-        x_min, x_max = F(mm[0]), F(mm[1])
+        if minmax is None:
+            mm = torch.stack([x.min(), x.max()]).float().cpu().numpy()  # get_minmax_stats: fp32 copies of min / max
+            x_min, x_max = F(mm[0]), F(mm[1])
+        else:
+            x_min, x_max = F(minmax[0]), F(minmax[1])
         if self.hist is None:
             self.hist, self.lo, self.hi = self._histc(x, x_min, x_max), x_min, x_max
             return
@@ -136,7 +163,10 @@ class HistRange:
 def static_hist_range(samples, bins=2048, upsample_rate=16, bit=8):
     """samples: iterable of GPU tensors (one per calibration sample) -> (min, max) as Python floats (fp32 values)."""
     h = HistRange(bins, upsample_rate, 2 ** bit)
-    for s in samples:
-        h.add(s)
+    samples = list(samples)
+    mn, mx = sample_minmax(samples)                    # every sample's range in one pass, one host copy
+    mm = torch.stack([mn, mx], dim=1).cpu().numpy()
+    for s, (a, b) in zip(samples, mm):
+        h.add(s, minmax=(a, b))
     lo, hi = h.range()
     return float(lo), float(hi)

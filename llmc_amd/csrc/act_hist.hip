@@ -51,6 +51,93 @@ __global__ __launch_bounds__(HB) void k_hist_to_f32(const unsigned* __restrict__
     if (i < bins) out[i] = (float)cnt[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Per-sample min / max of up to MM_MAX_SAMPLES calibration samples in ONE launch pair (`static_minmax`,
+// `static_moving_minmax` and the first pass of `static_hist` take `sample.min()`, `sample.max()` of every sample:
+// quant.py:253-263, 524-543, 462-475). The samples are separate allocations (hook outputs); their addresses and lengths travel
+// in the kernel arguments like k_syrk4's sample table. HBM-bound: one read of every sample in 16-B pieces.
+// NaN: torch's min / max propagate it, fminf / fmaxf drop it, so a NaN anywhere in a sample sets both of its results to NaN.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int MM_MAX_SAMPLES = 160;
+static constexpr int MM_CHUNK = 65536;       // elements per workgroup pass
+
+struct MinmaxSamplesArgs {
+    int n, nch;              // samples, chunks per sample (of the longest)
+    float* part;             // [n][nch][3] min, max, nan flag
+    float* mn;               // [n]
+    float* mx;               // [n]
+    struct { uint64_t base; int64_t len; } smp[MM_MAX_SAMPLES];
+};
+
+template <typename T>
+__global__ __launch_bounds__(HB) void k_minmax_samples(MinmaxSamplesArgs a) {
+    __shared__ float red[3][HB / 64];
+    const int row = blockIdx.y, ch = blockIdx.x;
+    const T* x = (const T*)(uintptr_t)a.smp[row].base;
+    const int64_t n = a.smp[row].len;
+    const int64_t c0 = (int64_t)ch * MM_CHUNK, c1 = c0 + MM_CHUNK < n ? c0 + MM_CHUNK : n;
+    float mn = INFINITY, mx = -INFINITY, bad = 0.0f;
+    constexpr int V = 16 / sizeof(T);
+    if (c0 < n) {
+        const int64_t v1 = c0 + ((c1 - c0) / V) * V;      // c0 is a multiple of V (MM_CHUNK is), the base is 16-B aligned
+        for (int64_t i = c0 + (int64_t)threadIdx.x * V; i < v1; i += (int64_t)HB * V) {
+            const uint4 r = *reinterpret_cast<const uint4*>(x + i);
+            T v[V];
+            __builtin_memcpy(v, &r, 16);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float f = to_f32<T>(v[k]);
+                mn = fminf(mn, f);
+                mx = fmaxf(mx, f);
+                bad = f != f ? 1.0f : bad;
+            }
+        }
+        for (int64_t i = v1 + threadIdx.x; i < c1; i += HB) {      // ragged tail of the last chunk
+            const float f = to_f32<T>(x[i]);
+            mn = fminf(mn, f);
+            mx = fmaxf(mx, f);
+            bad = f != f ? 1.0f : bad;
+        }
+    }
+    mn = wave_min(mn, 64);
+    mx = wave_max(mx, 64);
+    bad = wave_max(bad, 64);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = mn;
+        red[1][threadIdx.x >> 6] = mx;
+        red[2][threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < HB / 64; ++i) {
+            mn = fminf(mn, red[0][i]);
+            mx = fmaxf(mx, red[1][i]);
+            bad = fmaxf(bad, red[2][i]);
+        }
+        float* o = a.part + ((int64_t)row * a.nch + ch) * 3;
+        o[0] = mn; o[1] = mx; o[2] = bad;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_minmax_samples_final(MinmaxSamplesArgs a) {
+    const int row = blockIdx.x;
+    float mn = INFINITY, mx = -INFINITY, bad = 0.0f;
+    for (int c = threadIdx.x; c < a.nch; c += 64) {
+        const float* o = a.part + ((int64_t)row * a.nch + c) * 3;
+        mn = fminf(mn, o[0]);
+        mx = fmaxf(mx, o[1]);
+        bad = fmaxf(bad, o[2]);
+    }
+    mn = wave_min(mn, 64);
+    mx = wave_max(mx, 64);
+    bad = wave_max(bad, 64);
+    if (threadIdx.x == 0) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+        a.mn[row] = bad != 0.0f ? nanv : mn;
+        a.mx[row] = bad != 0.0f ? nanv : mx;
+    }
+}
+
 }  // namespace llmc
 
 using namespace llmc;
@@ -79,6 +166,41 @@ extern "C" int llmc_histc(const void* x, int dt, int64_t n, int bins, float lo, 
                                        (const T*)x, n, bins, lo, hi, (unsigned*)ws));
     LLMC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_hist_to_f32, dim3((bins + HB - 1) / HB), dim3(HB), 0, st, (const unsigned*)ws, bins, out);
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+extern "C" int llmc_minmax_samples_max(void) { return MM_MAX_SAMPLES; }
+
+extern "C" size_t llmc_minmax_samples_ws_bytes(const int64_t* len_list_host, int n) {
+    if (!len_list_host || n <= 0) return 0;
+    int64_t longest = 0;
+    for (int i = 0; i < n; ++i) longest = len_list_host[i] > longest ? len_list_host[i] : longest;
+    return (size_t)n * (size_t)ceil_div64(longest, MM_CHUNK) * 3 * sizeof(float);
+}
+
+extern "C" int llmc_minmax_samples(const void* const* X_list_host, const int64_t* len_list_host, int n, int dt, float* mn,
+                                   float* mx, void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(dtype_ok(dt) && X_list_host && len_list_host && mn && mx && ws, "minmax_samples: bad argument");
+    LLMC_REQUIRE(n >= 1 && n <= MM_MAX_SAMPLES, "minmax_samples: 1 .. llmc_minmax_samples_max() samples per call");
+    MinmaxSamplesArgs a;
+    int64_t longest = 0;
+    for (int i = 0; i < n; ++i) {
+        LLMC_REQUIRE(X_list_host[i] && len_list_host[i] > 0 && ((uintptr_t)X_list_host[i] & 15) == 0,
+                     "minmax_samples: every sample must be non-empty and 16-B aligned");
+        a.smp[i].base = (uint64_t)(uintptr_t)X_list_host[i];
+        a.smp[i].len = len_list_host[i];
+        longest = len_list_host[i] > longest ? len_list_host[i] : longest;
+    }
+    a.n = n;
+    a.nch = (int)ceil_div64(longest, MM_CHUNK);
+    a.part = (float*)ws;
+    a.mn = mn;
+    a.mx = mx;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(dt, hipLaunchKernelGGL((k_minmax_samples<T>), dim3(a.nch, n), dim3(HB), 0, st, a));
+    LLMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_minmax_samples_final, dim3(n), dim3(64), 0, st, a);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }

@@ -283,3 +283,24 @@ def test_register_act_qparams_all_static_calibrations(algo):
             a, b = (lo, hi) if a is None else (a + 0.01 * (lo - a), b + 0.01 * (hi - b))
         assert abs(s - max(abs(a), abs(b)) / 127) <= 1e-2 * s
     assert float(layer.buf_act_qmax_0) == 127 and float(layer.buf_act_zeros_0) == 0
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16, torch.float32])
+def test_sample_minmax_equals_torch_min_max_per_sample(dt):
+    """llmc_minmax_samples (the data pass of static_minmax / static_moving_minmax / the histogram observer's first pass,
+    quant.py:253-263): every sample's min / max exactly what `sample.min()`, `sample.max()` give, for separately allocated
+    samples of different lengths (ragged tails, one shorter than a vector), more samples than one launch takes, NaN."""
+    from llmc_amd.compression.quantization.hist_range import sample_minmax
+    gen = torch.Generator().manual_seed(3)
+    lens = [1, 7, 8, 4099, 65536, 65537, 200003] + [1000 + 13 * i for i in range(170)]
+    xs = [(torch.randn(n, generator=gen) * (1 + i % 5)).to(dt).cuda() for i, n in enumerate(lens)]
+    xs[3][17] = float('nan')
+    xs[5] = xs[5].reshape(1, -1, 1)                  # any shape: the sample is its elements
+    mn, mx = sample_minmax(xs)
+    assert mn.dtype == torch.float32 and mn.shape == (len(xs),)
+    for i, x in enumerate(xs):
+        a, b = x.min().float(), x.max().float()
+        if i == 3:
+            assert torch.isnan(mn[i]) and torch.isnan(mx[i]) and torch.isnan(a)      # torch propagates the NaN too
+        else:
+            assert float(mn[i]) == float(a) and float(mx[i]) == float(b), i
