@@ -232,22 +232,40 @@ def _gptq_instance(wq, actorder, static_groups, percdamp=0.01, blocksize=128, dt
     return g
 
 
+GPTQ_CFGS = [
+    # (name, bit, sym, gran, gs, actorder, static_groups, dtype, R, K, dead)
+    ('asym_g128_act_dyn', 4, False, 'per_group', 128, True, False, 'bf16', 24, 384, True),
+    ('sym_g128_act_static', 4, True, 'per_group', 128, True, True, 'f16', 32, 256, False),
+    ('sym_pc_noact', 8, True, 'per_channel', None, False, False, 'f16', 32, 256, False),
+    ('asym_g64_act_dyn', 4, False, 'per_group', 64, True, False, 'f16', 32, 256, False),
+    ('asym_g128_noact_static', 4, False, 'per_group', 128, False, True, 'bf16', 32, 256, False),
+]
+# second file (round 3): other bit widths and group sizes, per-channel with actorder, 8-bit static groups
+GPTQ_MORE_CFGS = [
+    ('asym_g32_w3_act_dyn', 3, False, 'per_group', 32, True, False, 'bf16', 32, 256, False),
+    ('sym_g128_w2_noact_dyn', 2, True, 'per_group', 128, False, False, 'f16', 32, 256, False),
+    ('asym_pc_w4_act', 4, False, 'per_channel', None, True, False, 'bf16', 32, 384, True),
+    ('sym_g64_w8_act_static', 8, True, 'per_group', 64, True, True, 'f16', 24, 256, False),
+    ('asym_g16_w4_noact_dyn', 4, False, 'per_group', 16, False, False, 'bf16', 16, 256, False),
+]
+
+
 def suite_gptq():
+    _gptq_suite(GPTQ_CFGS, 2024, 'gptq', True)
+
+
+def suite_gptq_more():
+    _gptq_suite(GPTQ_MORE_CFGS, 4048, 'gptq_more', False)
+
+
+def _gptq_suite(cfgs, seed, fname, with_mm):
     """GPTQ.add_batch / process_hessian_and_weights / weight_transform / update_model_qparams / w_q / w_qdq
     on small seeded layers, several configurations."""
     import torch.distributed as dist
     if not dist.is_initialized():
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29591', rank=0, world_size=1)
     out = {}
-    cfgs = [
-        # (name, bit, sym, gran, gs, actorder, static_groups, dtype, R, K, dead)
-        ('asym_g128_act_dyn', 4, False, 'per_group', 128, True, False, 'bf16', 24, 384, True),
-        ('sym_g128_act_static', 4, True, 'per_group', 128, True, True, 'f16', 32, 256, False),
-        ('sym_pc_noact', 8, True, 'per_channel', None, False, False, 'f16', 32, 256, False),
-        ('asym_g64_act_dyn', 4, False, 'per_group', 64, True, False, 'f16', 32, 256, False),
-        ('asym_g128_noact_static', 4, False, 'per_group', 128, False, True, 'bf16', 32, 256, False),
-    ]
-    gen = torch.Generator().manual_seed(2024)
+    gen = torch.Generator().manual_seed(seed)
     for (name, bit, sym, gran, gs, actorder, static_groups, dt, R, K, dead) in cfgs:
         kw = dict(group_size=gs) if gs else {}
         wq = IntegerQuantizer(bit, sym, gran, **kw)
@@ -331,11 +349,12 @@ def suite_gptq():
         out[p + 'gran'] = np.array(gran)
     out['names'] = np.array([c[0] for c in cfgs])
 
-    # sgemm order pin: MKL result of Err1.matmul(Hinv[i1:i2, i2:]) on a realistic block
-    a = torch.randn(96, 128, generator=gen) * 0.01
-    b = torch.randn(128, 200, generator=gen)
-    out['mm_a'], out['mm_b'], out['mm_out'] = f32(a), f32(b), f32(a.matmul(b))
-    save('gptq', **out)
+    if with_mm:
+        # sgemm order pin: MKL result of Err1.matmul(Hinv[i1:i2, i2:]) on a realistic block
+        a = torch.randn(96, 128, generator=gen) * 0.01
+        b = torch.randn(128, 200, generator=gen)
+        out['mm_a'], out['mm_b'], out['mm_out'] = f32(a), f32(b), f32(a.matmul(b))
+    save(fname, **out)
 
 
 def suite_gptq_owq():
@@ -1138,7 +1157,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

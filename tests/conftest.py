@@ -15,7 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+class _Merged(dict):
+    """Several golden files whose keys carry their case name as a prefix, read as one; `names` is the concatenation."""
+    @property
+    def files(self):
+        return list(self.keys())
+
+
 def load_golden(name):
+    if name == 'gptq+more':          # the round-1 GPTQ cases and the round-3 ones (other bit widths / group sizes)
+        out, names = _Merged(), []
+        for f in ('gptq', 'gptq_more'):
+            g = np.load(os.path.join(GOLDEN, f + '.npz'), allow_pickle=False)
+            names += [str(n) for n in g['names']]
+            out.update({k: g[k] for k in g.files if k != 'names'})
+        out['names'] = np.array(names)
+        return out
     return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
 
 

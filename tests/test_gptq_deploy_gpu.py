@@ -39,7 +39,7 @@ def build_layer(g, p):
 def test_w_qdq_and_w_q_match_reference_goldens():
     from llmc_amd.compression.quantization import IntegerQuantizer
     from llmc_amd.compression.quantization.gptq import GPTQ
-    g = load_golden('gptq')
+    g = load_golden('gptq+more')
     checked_wq = 0
     for name in [str(n) for n in g['names']]:
         p = name + '/'

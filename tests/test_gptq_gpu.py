@@ -164,7 +164,7 @@ def test_sgemm_shortk_hints_do_not_change_bits():
 
 def test_column_loop_bit_exact_vs_reference_golden():
     from llmc_amd.compression.quantization.gptq_ops import gptq_quantize
-    g = load_golden('gptq')
+    g = load_golden('gptq+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
         bit, sym, gs, actorder, static_groups, R, K, qmin, qmax = g[p + 'meta']

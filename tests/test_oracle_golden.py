@@ -105,7 +105,7 @@ from oracle import gptq_ref as G  # noqa: E402
 
 
 def _gptq_cases():
-    g = load_golden('gptq')
+    g = load_golden('gptq+more')
     return g, [str(n) for n in g['names']]
 
 
