@@ -426,7 +426,22 @@ def suite_gptq_owq():
     save('gptq_owq', **out)
 
 
+AWQ_CFGS = [('bf16_sym_g128_v2', 'bf16', True, 128, 'v2', [64, 32], 4), ('f16_asym_g128_v2', 'f16', False, 128, 'v2', [48], 4),
+            ('bf16_sym_g64_v1', 'bf16', True, 64, 'v1', [32, 32], 4)]
+# second file (round 3): other bit widths, per-channel (gs = 0), three stacked layers
+AWQ_MORE_CFGS = [('f16_asym_g32_w3_v2', 'f16', False, 32, 'v2', [32, 32], 3), ('bf16_sym_pc_w8_v2', 'bf16', True, 0, 'v2', [64], 8),
+                 ('f16_sym_g128_w4_v1_3l', 'f16', True, 128, 'v1', [32, 16, 16], 4), ('bf16_asym_g64_w2_v2', 'bf16', False, 64, 'v2', [48], 2)]
+
+
 def suite_awq():
+    _awq_suite(AWQ_CFGS, 4242, 'awq')
+
+
+def suite_awq_more():
+    _awq_suite(AWQ_MORE_CFGS, 8484, 'awq_more')
+
+
+def _awq_suite(cfgs, seed, fname):
     """Awq.search_scale_subset (20-point grid, one batch) with inspect = the stacked Linear layers."""
     import torch.distributed as dist
     import types
@@ -448,12 +463,10 @@ def suite_awq():
     # Keep the GPU semantics the reference is written for: make .cpu() copy while this suite runs.
     torch.Tensor.cpu = lambda self, *a, **k: self.clone()
     out = {}
-    gen = torch.Generator().manual_seed(4242)
-    cfgs = [('bf16_sym_g128_v2', 'bf16', True, 128, 'v2', [64, 32]), ('f16_asym_g128_v2', 'f16', False, 128, 'v2', [48]),
-            ('bf16_sym_g64_v1', 'bf16', True, 64, 'v1', [32, 32])]
-    for (name, dt, sym, gs, ver, Rs) in cfgs:
+    gen = torch.Generator().manual_seed(seed)
+    for (name, dt, sym, gs, ver, Rs, bit) in cfgs:
         K, N = 256, 192
-        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+        wq = IntegerQuantizer(bit, sym, 'per_group', group_size=gs) if gs else IntegerQuantizer(bit, sym, 'per_channel')
         a = Awq.__new__(Awq)
         a.wquantizer = wq
         a.aquantizer = None
@@ -510,11 +523,11 @@ def suite_awq():
         out[p + 'scales_r035'] = f32(s)
         out[p + 'wq_r035'] = f32(wqs)
         out[p + 'xs_r035'] = f32(xs)
-        out[p + 'meta'] = np.array([int(sym), gs, len(Rs), K], dtype=np.int64)
+        out[p + 'meta'] = np.array([int(sym), gs, len(Rs), K] + ([bit] if fname != 'awq' else []), dtype=np.int64)
         out[p + 'dt'] = np.array(dt)
         out[p + 'ver'] = np.array(ver)
     out['names'] = np.array([c[0] for c in cfgs])
-    save('awq', **out)
+    save(fname, **out)
 
 
 def suite_awq_flat():
@@ -1157,7 +1170,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

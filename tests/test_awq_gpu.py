@@ -30,19 +30,21 @@ def ulps(a, b, dt):
     return np.abs(a - b)
 
 
-def make_q(sym, gs):
+def make_q(sym, gs, bit=4):
     from llmc_amd.compression.quantization import IntegerQuantizer
-    return IntegerQuantizer(4, bool(sym), 'per_group', group_size=gs)
+    if gs == 0:
+        return IntegerQuantizer(bit, bool(sym), 'per_channel')
+    return IntegerQuantizer(bit, bool(sym), 'per_group', group_size=gs)
 
 
 def test_elementwise_chain_vs_reference_golden():
     from llmc_amd.compression.quantization import awq_ops
-    g = load_golden('awq')
+    g = load_golden('awq+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
-        sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+        sym, gs, nl, K, bit = [int(v) for v in g[p + 'meta']]
         dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
-        q = make_q(sym, gs)
+        q = make_q(sym, gs, bit)
         s = dev(g[p + 'scales_r035'], dt)
         wcat = torch.cat([dev(g[p + f'w{i}'], dt) for i in range(nl)], dim=0)
         wq = awq_ops.scale_fakequant(wcat, s, q)
@@ -66,12 +68,12 @@ def test_elementwise_chain_vs_reference_golden():
 
 def test_search_matches_reference_golden():
     from llmc_amd.compression.quantization.awq_pipeline import search_scale_stacked
-    g = load_golden('awq')
+    g = load_golden('awq+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
-        sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+        sym, gs, nl, K, bit = [int(v) for v in g[p + 'meta']]
         dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
-        q = make_q(sym, gs)
+        q = make_q(sym, gs, bit)
         ws = [dev(g[p + f'w{i}'], dt) for i in range(nl)]
         w_before = [w.clone() for w in ws]
         best, losses, n = search_scale_stacked(ws, dev(g[p + 'x'], dt), q, ver, return_losses=True)
@@ -83,7 +85,7 @@ def test_search_matches_reference_golden():
         # measured on an MI355X: max 2.0e-5 (profiles/r03_e2e_measured_values.jsonl; the products' fp32 sums are taken in
         # another order than the CPU GEMM's and a few bf16 outputs round the other way); bound = 10x that. The argmin gaps of
         # these goldens are 2-8 %; awq_flat.npz holds the 3.7e-4 case
-        np.testing.assert_allclose(losses.cpu().numpy(), ref, rtol=2e-4, err_msg=name)
+        np.testing.assert_allclose(losses.cpu().numpy(), ref, rtol=2e-4 if bit < 8 else 1e-3, err_msg=name)   # W8: see test_oracle_golden
         assert n == int(np.argmin(ref)), name
         u = ulps(host(best), g[p + 'best_scales'], dt)
         assert u.max() <= 2, (name, u.max())

@@ -185,13 +185,13 @@ def _ulp_close(a, b, dt, max_frac_diff=0.0, max_ulps=1):
 
 
 def test_awq_elementwise_chain_bit_exact():
-    g = load_golden('awq')
+    g = load_golden('awq+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
-        sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+        sym, gs, nl, K, bit = [int(v) for v in g[p + 'meta']]
         dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
         ws = [g[p + f'w{i}'] for i in range(nl)]
-        qmin, qmax = Q.int_range(4, bool(sym))
+        qmin, qmax = Q.int_range(bit, bool(sym))
         s = g[p + 'scales_r035']
         wq = np.concatenate([A.fake_quantize_weight(w, s, dt, bool(sym), qmin, qmax, gs) for w in ws], axis=0)
         np.testing.assert_array_equal(wq.view(np.uint32), g[p + 'wq_r035'].view(np.uint32), err_msg=name)
@@ -203,21 +203,22 @@ def test_awq_elementwise_chain_bit_exact():
 
 
 def test_awq_reductions_and_search_match_reference():
-    g = load_golden('awq')
+    g = load_golden('awq+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
-        sym, gs, nl, K = [int(v) for v in g[p + 'meta']]
+        sym, gs, nl, K, bit = [int(v) for v in g[p + 'meta']]
         dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
         ws = [g[p + f'w{i}'] for i in range(nl)]
         assert _ulp_close(A.act_mean(g[p + 'x'], dt), g[p + 'x_mean'], dt, max_frac_diff=0.02), name
         assert _ulp_close(A.weight_scale(ws, dt, gs), g[p + 'w_max'], dt, max_frac_diff=0.05, max_ulps=2), name
-        qmin, qmax = Q.int_range(4, bool(sym))
+        qmin, qmax = Q.int_range(bit, bool(sym))
         best, losses, n = A.search_scale(ws, g[p + 'x'], dt, bool(sym), qmin, qmax, gs, ver)
         ref_losses = g[p + 'losses']
         assert len(ref_losses) == 20
         # the 20 losses agree with the reference's to 1e-4 (measured: 2e-7 typical, 4.5e-5 worst: summation order of the
-        # CPU GEMM behind F.linear); the argmin gaps of these goldens are 2-8 %
-        np.testing.assert_allclose(losses, ref_losses, rtol=1e-4, err_msg=name)
+        # CPU GEMM behind F.linear); the argmin gaps of these goldens are 1-8 %. W8: the quantization error is so small that
+        # the loss is a difference of nearly equal bf16 outputs, where one output rounding the other way shows (1.8e-4)
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-4 if bit < 8 else 5e-4, err_msg=name)
         assert n == int(np.argmin(ref_losses)), name
         # a 1-ulp difference of the token mean at the max/min channel moves the normaliser sqrt(max*min) and
         # with it every scale by one unit in the last place: same grid point, scales within 2 ulp of the dtype
