@@ -743,23 +743,37 @@ def suite_awq_gqa():
     save('awq_gqa', **out)
 
 
+CLIP_CFGS = [('bf16_sym_g128_clipsym', 'bf16', True, 128, True, 4, 96, 32), ('f16_asym_g128_noclipsym', 'f16', False, 128, False, 4, 96, 32),
+             ('f16_sym_g64_clipsym', 'f16', True, 64, True, 4, 96, 32)]
+# second file (round 3): other bit widths, group 32, more sampled tokens (several 16-token chunks of ATen's cascade sum),
+# an asymmetric quantizer with symmetric clipping
+CLIP_MORE_CFGS = [('bf16_asym_g32_w3_noclipsym', 'bf16', False, 32, False, 3, 96, 32), ('f16_sym_g128_w2_clipsym', 'f16', True, 128, True, 2, 96, 32),
+                  ('bf16_sym_g64_w8_clipsym_200tok', 'bf16', True, 64, True, 8, 400, 200), ('f16_asym_g128_w4_clipsym_77tok', 'f16', False, 128, True, 4, 154, 77)]
+
+
 def suite_clip():
+    _clip_suite(CLIP_CFGS, 99, 'clip')
+
+
+def suite_clip_more():
+    _clip_suite(CLIP_MORE_CFGS, 1999, 'clip_more')
+
+
+def _clip_suite(cfgs, seed, fname):
     """AutoClipper.auto_clip_layer / apply_clip (clip_version v1, w_only)."""
     from llmc.compression.quantization.auto_clip import AutoClipper
     out = {}
-    gen = torch.Generator().manual_seed(99)
-    cfgs = [('bf16_sym_g128_clipsym', 'bf16', True, 128, True), ('f16_asym_g128_noclipsym', 'f16', False, 128, False),
-            ('f16_sym_g64_clipsym', 'f16', True, 64, True)]
-    for name, dt, sym, gs, clip_sym in cfgs:
-        R, K, T = 64, 256, 96
-        wq = IntegerQuantizer(4, sym, 'per_group', group_size=gs)
+    gen = torch.Generator().manual_seed(seed)
+    for name, dt, sym, gs, clip_sym, bit, T, nst in cfgs:
+        R, K = 64, 256
+        wq = IntegerQuantizer(bit, sym, 'per_group', group_size=gs)
         ac = AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v1', clip_sym=clip_sym,
                          save_clip=False, padding_mask=None)
         wt = torch.randn(R, K, generator=gen) * 0.02
         wt[torch.rand(R, K, generator=gen) < 0.01] *= 8       # weight outliers make clipping worthwhile
         w = wt.to(DT[dt])
         x = (torch.randn(2, T // 2, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(DT[dt])
-        mx, mn = ac.auto_clip_layer(0, 'fc', w, [x.clone()], n_sample_token=32)
+        mx, mn = ac.auto_clip_layer(0, 'fc', w, [x.clone()], n_sample_token=nst)
         layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
         layer.weight.data = w.clone()
         ac.apply_clip(0, layer, mn, mx, 'fc')
@@ -767,10 +781,10 @@ def suite_clip():
         out[p + 'w'], out[p + 'x'] = f32(w), f32(x)
         out[p + 'best_max'], out[p + 'best_min'] = f32(mx), f32(mn)
         out[p + 'clipped'] = f32(layer.weight.data)
-        out[p + 'meta'] = np.array([int(sym), gs, int(clip_sym), 32], dtype=np.int64)
+        out[p + 'meta'] = np.array([int(sym), gs, int(clip_sym), nst] + ([bit] if fname != 'clip' else []), dtype=np.int64)
         out[p + 'dt'] = np.array(dt)
     out['names'] = np.array([c[0] for c in cfgs])
-    save('clip', **out)
+    save(fname, **out)
 
 
 def suite_clip_mb():
@@ -1170,7 +1184,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

@@ -31,6 +31,18 @@ def load_golden(name):
             out.update({k: g[k] for k in g.files if k != 'names'})
         out['names'] = np.array(names)
         return out
+    if name == 'clip+more':          # same for the AutoClipper cases (meta: sym, gs, clip_sym, n_sample_token[, bit])
+        out, names = _Merged(), []
+        for f in ('clip', 'clip_more'):
+            g = np.load(os.path.join(GOLDEN, f + '.npz'), allow_pickle=False)
+            names += [str(n) for n in g['names']]
+            out.update({k: g[k] for k in g.files if k != 'names'})
+        for n in names:
+            m = out[n + '/meta']
+            if m.size == 4:
+                out[n + '/meta'] = np.concatenate([m, [4]])
+        out['names'] = np.array(names)
+        return out
     if name == 'awq+more':           # round-1 AWQ cases (4 bit) and the round-3 ones (meta carries the bit width, gs 0 = per channel)
         out, names = _Merged(), []
         for f in ('awq', 'awq_more'):

@@ -158,12 +158,12 @@ def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape):
 def test_clip_search_matches_reference_golden():
     """Every (row, group) gets the reference's clip level (auto_clip.py:84-191); the clamped weights follow bit for bit."""
     from llmc_amd.compression.quantization import awq_ops
-    g = load_golden('clip')
+    g = load_golden('clip+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
-        sym, gs, clip_sym, nst = [int(v) for v in g[p + 'meta']]
+        sym, gs, clip_sym, nst, bit = [int(v) for v in g[p + 'meta']]
         dt = str(g[p + 'dt'])
-        q = make_q(sym, gs)
+        q = make_q(sym, gs, bit)
         x = g[p + 'x'].reshape(-1, g[p + 'x'].shape[-1])
         step = max(1, x.shape[0] // nst)
         xd = dev(x[0::step], dt)                                  # auto_clip.py:146-147

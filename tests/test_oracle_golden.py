@@ -244,12 +244,12 @@ def test_fp8_e4m3_bit_exact_vs_torch_cast_path():
 def test_auto_clip_matches_reference():
     """auto_clip_layer restated with the reference's roundings chooses the reference's clip level for EVERY (row, group)
     of the goldens: one batch (clip.npz) and the list form (clip_mb.npz, error averaged over the batches)."""
-    g = load_golden('clip')
+    g = load_golden('clip+more')
     for name in [str(n) for n in g['names']]:
         p = name + '/'
-        sym, gs, clip_sym, nst = [int(v) for v in g[p + 'meta']]
+        sym, gs, clip_sym, nst, bit = [int(v) for v in g[p + 'meta']]
         dt = str(g[p + 'dt'])
-        qmin, qmax = Q.int_range(4, bool(sym))
+        qmin, qmax = Q.int_range(bit, bool(sym))
         mx, mn = A.auto_clip_layer(g[p + 'w'], g[p + 'x'], dt, bool(sym), qmin, qmax, gs, bool(clip_sym),
                                    n_sample_token=nst)
         ref_mx, ref_mn = g[p + 'best_max'], g[p + 'best_min']
