@@ -180,3 +180,25 @@ def test_triton_only_ops_match_goldens_of_the_reference_triton_kernels():
         # the K = 64 MFMA and fma(part * a_s, b_s, acc) are what the Triton kernel compiles to on this GPU: every output equal
         # (measured 1.0 on both golden products; 0.97-0.99 with the K = 16 MFMA and an uncontracted update)
         assert (c == cref).all(), float((c == cref).mean())
+
+
+def test_fp8_gemm_bit_identical_to_the_reference_triton_kernel_more_shapes():
+    """fp8_triton_more.npz (tools/fp8_triton_golden_more.py: the reference's Triton fp8_gemm run unmodified on an MI355X):
+    several b_s column blocks, up to 12 K blocks, M below one tile (the K = 16 MFMA kernel), ragged M / N — bf16 AND fp32
+    outputs bit for bit (measured: 1.0 on every shape, also on six larger ones up to 1000 x 520 x 2048)."""
+    from conftest import report
+    from llmc_amd.compression.quantization import kernel as KN
+    g = load_golden('fp8_triton_more')
+    for i in range(int(g['n_gemm'])):
+        p = f'g{i}_'
+        M, N, Kd = [int(v) for v in g[p + 'shape']]
+        a8 = torch.from_numpy(g[p + 'a_bits']).cuda().view(torch.float8_e4m3fn)
+        w8 = torch.from_numpy(g[p + 'w_bits']).cuda().view(torch.float8_e4m3fn)
+        a_s, w_s = torch.from_numpy(g[p + 'a_s']).cuda(), torch.from_numpy(g[p + 'w_s']).cuda()
+        c = KN.fp8_gemm(a8, a_s, w8, w_s, dtype=torch.bfloat16)
+        c32 = KN.fp8_gemm(a8, a_s, w8, w_s, dtype=torch.float32)
+        ref32 = torch.from_numpy(g[p + 'c_f32'])
+        eq16 = float((c.cpu() == ref32.to(torch.bfloat16)).float().mean())      # Triton's bf16 output = its fp32 one rounded (checked when the golden was made)
+        eq32 = float((c32.cpu().view(torch.int32) == ref32.view(torch.int32)).float().mean())
+        report(f'fp8_triton_more/{M}x{N}x{Kd}', bf16_equal=eq16, f32_equal=eq32)
+        assert eq16 == 1.0 and eq32 == 1.0, (M, N, Kd, eq16, eq32)
