@@ -381,7 +381,8 @@ struct Fp8GemmArgs {
     const void* bias; void* C;
     int ntm, ntn, sbm, sbn, nsn, nrounds;
 #ifdef LLMC_LAB
-    int abl;      // tools/probes/fp8_gemm_lab.hip: 1 no accumulator update, 2 no DMA after a tile's first stage, 4 no MFMA
+    int abl;      // tools/probes/fp8_gemm_lab.hip: 1 no accumulator update, 2 no DMA after a tile's first stage, 4 no MFMA, 16 / 32 update
+                  // variants, 64 no barrier in the K loop, 128 no fragment reads after a tile's first
 #endif
 };
 
@@ -614,15 +615,26 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                     }
                 }
                 if constexpr (i == 0 && j < 3) {
+#ifdef LLMC_LAB
+                    if (!(a.abl & 128))
+#endif
+                    {
                     fa[(j + 1) & 1][0] = frag(adA, (j + 1) * 4096, 0);
                     fa[(j + 1) & 1][1] = frag(adA, (j + 1) * 4096, 1);
+                    }
                 }
                 if constexpr (more && t == 7) {
                     // every fragment of this slot is in registers: publish the next slot (my pieces landed, then everybody's)
                     // and fetch its first fragments while updates 6 and 7 are still to run
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LLMC_LAB
+                    if (!(a.abl & 64))
+#endif
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef LLMC_LAB
+                    if (!(a.abl & 128))
+#endif
                     first_frags(st ^ (uint32_t)G2_STAGE);
                 }
                 __builtin_amdgcn_sched_barrier(0);

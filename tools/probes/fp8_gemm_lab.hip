@@ -8,9 +8,10 @@
 int main() {
     const int64_t M = 16384;
     const int64_t shapes[][2] = {{14336, 4096}, {4096, 14336}};
-    const char* names[] = {"full", "no accumulator update", "no DMA after a tile's first stage", "no update, no DMA", "no MFMA",
-                           "no MFMA, no DMA", "one fma per element", "one fma per element, no DMA", "update does not read the MFMA results", "same, no DMA"};
-    const int abls[] = {0, 1, 2, 3, 4, 6, 16, 18, 32, 34};
+    const char* names[] = {"full", "no accumulator update", "no DMA after a tile's first stage", "no update, no DMA", "no barrier in the K loop",
+                           "no fragment reads after the first", "no barrier, no reads", "no update, no DMA, no barrier", "no update, no DMA, no reads",
+                           "no update, no DMA, no barrier, no reads (MFMA stream + loop)"};
+    const int abls[] = {0, 1, 2, 3, 64, 128, 192, 67, 131, 195};
     for (auto& sh : shapes) {
         const int64_t N = sh[0], K = sh[1], nkb = K / 128;
         uint8_t *A, *B; float *As, *Bs; void* C;
