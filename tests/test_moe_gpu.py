@@ -1,0 +1,89 @@
+"""GPTQ through the host classes on a sparse mixture-of-experts block (llmc/models/mixtral.py:62-86's subset table: all experts'
+w1 / w3 and the router in ONE subset, one subset per expert's w2) with real top-2 routing on the GPU: experts see different
+(routed) tokens, and an expert that receives no token in a calibration sample is skipped by the forward — its Linears' hooks do
+not fire for that sample. Every expert must get the Hessian of exactly ITS tokens: checked through what the
+Hessian decides — the actorder permutation — against one computed directly from the routed tokens, and through the
+quantization error on those tokens."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class Cfg(dict):
+    __getattr__ = dict.get
+
+
+def _routed_inputs(block, data):
+    """The tokens every expert (and the router) sees, by plain forward hooks on an untouched copy of the block."""
+    seen = {}
+    hooks = []
+    for name, m in block.named_modules():
+        if isinstance(m, torch.nn.Linear):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out, n=name: seen.setdefault(n, []).append(inp[0].detach().reshape(-1, inp[0].shape[-1]))))
+    with torch.no_grad():
+        for x in data:
+            block(x.cuda())
+    for h in hooks:
+        h.remove()
+    return seen
+
+
+def test_gptq_on_a_sparse_moe_block_with_skipped_experts():
+    import llmc_amd.compression.quantization as Q
+    from toy_model import ToyMoeModel, calib_input
+    model = ToyMoeModel(hidden=128, inner=256, n_experts=4, seed=3)
+    inp = calib_input(model, n_seq=6, seq=48, seed=5)
+    # expert 3 is starved in the first three samples: a strong input feature that its router row dislikes
+    blk = model.get_blocks()[0]
+    with torch.no_grad():
+        blk.ln.weight.fill_(1.0)
+        blk.ln.bias.zero_()
+        blk.block_sparse_moe.gate.weight[3, 7] = 4.0
+    for i, x in enumerate(inp['data']):
+        x[..., 7] = (-6.0 if i < 3 else 6.0) + 0.1 * x[..., 7]
+    ref = copy.deepcopy(blk).cuda()
+    seen = _routed_inputs(ref, inp['data'])
+    calls = {n: len(v) for n, v in seen.items()}
+    assert calls['block_sparse_moe.gate'] == 6 and calls['block_sparse_moe.experts.3.w1'] == 3, calls      # skipped three times
+    assert all(calls[f'block_sparse_moe.experts.{e}.w1'] == 6 for e in range(3)), calls
+
+    qc = Cfg(weight=Cfg(bit=4, symmetric=False, granularity='per_group', group_size=128),
+             special=Cfg(actorder=True, static_groups=False, percdamp=0.01, blocksize=128, true_sequential=False),
+             quant_out=False)
+    algo = Q.GPTQ(model, qc, copy.deepcopy(inp), None, Cfg(calib=Cfg(seq_len=48), model=Cfg(type='Mixtral')))
+    algo.run_block_loop()
+    out = model.get_blocks()[0]
+    rtn_q = Q.IntegerQuantizer(4, False, 'per_group', group_size=128)
+    algo.deploy('fake_quant')
+    qblk = model.get_blocks()[0].cuda()
+    for e in range(4):
+        w1, w3 = out.get_submodule(f'block_sparse_moe.experts.{e}.w1'), out.get_submodule(f'block_sparse_moe.experts.{e}.w3')
+        # w1 and w3 of an expert see the same tensor: one Hessian, one permutation; other experts' tokens differ
+        assert torch.equal(w1.buf_perm, w3.buf_perm), e
+        x = torch.cat(seen[f'block_sparse_moe.experts.{e}.w1']).double()
+        H = x.T @ x
+        want = torch.argsort(torch.diag(H), descending=True)
+        got = w1.buf_perm.to(want.device)
+        # the permutation orders the Hessian diagonal of exactly this expert's routed tokens (ties / near-ties aside)
+        d = torch.diag(H)
+        assert bool((d[got][:-1] >= d[got][1:] * (1 - 1e-3)).all()), e
+        assert (got[:16] == want[:16]).float().mean() >= 0.75, (e, got[:16].tolist(), want[:16].tolist())
+        # GPTQ beats round-to-nearest on the expert's own tokens
+        w = ref.get_submodule(f'block_sparse_moe.experts.{e}.w1').weight.data.float()
+        wq = qblk.get_submodule(f'block_sparse_moe.experts.{e}.w1').weight.data.float()
+        rtn = rtn_q.fake_quant_weight_dynamic(ref.get_submodule(f'block_sparse_moe.experts.{e}.w1').weight.data).float()
+        xf = x.float()
+        assert (xf @ (wq - w).T).norm() < (xf @ (rtn - w).T).norm(), e
+    perms = [out.get_submodule(f'block_sparse_moe.experts.{e}.w1').buf_perm for e in range(4)]
+    assert not torch.equal(perms[0], perms[1]) and not torch.equal(perms[2], perms[3])
+    # the router saw every token of every sample: its permutation follows the full input's Hessian diagonal
+    xg = torch.cat(seen['block_sparse_moe.gate']).double()
+    dg = torch.diag(xg.T @ xg)
+    pg = out.block_sparse_moe.gate.buf_perm.to(dg.device)
+    assert bool((dg[pg][:-1] >= dg[pg][1:] * (1 - 1e-3)).all())
+    for n, m in out.named_modules():
+        if hasattr(m, 'weight') and isinstance(getattr(m, 'weight', None), torch.Tensor) and m.weight.dim() == 2:
+            assert torch.isfinite(m.weight).all(), n

@@ -31,10 +31,11 @@ def main():
         t_w = timed(lambda: KN.weight_cast_to_fp8(w, 128))
         a8, a_s = KN.act_quant(x, 128)
         w8, w_s = KN.weight_cast_to_fp8(w, 128)
+        t_d = timed(lambda: KN.weight_cast_to_bf16(w8, w_s, 128))
         t_g = timed(lambda: KN.fp8_gemm(a8, a_s, w8, w_s))
         fl = 2.0 * M * N * K
         print(f'M={M} N={N} K={K}: act_quant {t_a*1e6:.0f} us = {3.0*M*K/t_a/1e12:.2f} TB/s (2MK read + MK write) | '
-              f'weight_cast_to_fp8 {t_w*1e6:.0f} us = {3.0*N*K/t_w/1e12:.2f} TB/s | fp8_gemm {t_g*1e3:.2f} ms = '
+              f'weight_cast_to_fp8 {t_w*1e6:.0f} us = {3.0*N*K/t_w/1e12:.2f} TB/s | weight_cast_to_bf16 {t_d*1e6:.0f} us = {3.0*N*K/t_d/1e12:.2f} TB/s | fp8_gemm {t_g*1e3:.2f} ms = '
               f'{fl/t_g/1e12:.0f} TFLOP/s = {fl/t_g/5e15:.3f} of the 5 PF fp8 MFMA peak', flush=True)
 
 
