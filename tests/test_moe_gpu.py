@@ -87,3 +87,44 @@ def test_gptq_on_a_sparse_moe_block_with_skipped_experts():
     for n, m in out.named_modules():
         if hasattr(m, 'weight') and isinstance(getattr(m, 'weight', None), torch.Tensor) and m.weight.dim() == 2:
             assert torch.isfinite(m.weight).all(), n
+
+
+def test_awq_on_a_sparse_moe_block_inspecting_the_moe_module():
+    """The Mixtral MoE subset under AWQ (llmc/models/mixtral.py:62-74): nine layers (four experts' w1 / w3 and the router), the
+    inspected module is the whole sparse MoE — inside it every expert's Linears see their routed tokens only (ragged, small
+    token counts), the search input is the MoE block's own input captured through get_extra_modules. The transformation must
+    leave the block's function unchanged (scales folded into the LayerNorm and the weights) and fake-quantization after it must
+    hurt less than without it."""
+    import llmc_amd.compression.quantization as Q
+    from toy_model import ToyMoeModel, calib_input
+    model = ToyMoeModel(hidden=128, inner=256, n_experts=4, seed=11)
+    inp = calib_input(model, n_seq=4, seq=64, seed=13)
+    with torch.no_grad():       # outlier channels behind the LayerNorm (a fresh LayerNorm flattens the calibration data's)
+        model.get_blocks()[0].ln.weight[torch.tensor([5, 40, 77, 101])] *= 25.0
+    blk0 = copy.deepcopy(model.get_blocks()[0]).cuda()
+    qc = Cfg(weight=Cfg(bit=4, symmetric=True, granularity='per_group', group_size=128),
+             special=Cfg(trans=True, trans_version='v2', weight_clip=False, save_scale=True, scale_path='/tmp/llmc_moe_scales'), quant_out=False)
+    algo = Q.Awq(model, qc, copy.deepcopy(inp), None, Cfg(calib=Cfg(seq_len=64), model=Cfg(type='Mixtral')))
+    algo.run_block_loop()
+    blk = model.get_blocks()[0].cuda()
+    scale = algo.act_scales['blocks.0.block_sparse_moe.gate']
+    assert scale.shape == (128,) and float(scale.max() / scale.min()) > 1.5          # a non-trivial transformation
+    x = torch.cat([d.cuda() for d in inp['data']])
+    with torch.no_grad():
+        y0, y1 = blk0(x).float(), blk(x).float()
+    # same function up to 16-bit rounding of the folded parameters (the routing may flip for a few borderline tokens)
+    rel = ((y1 - y0).norm() / y0.norm()).item()
+    assert rel < 0.03, rel
+    # and the point of it: W4 fake-quant of the transformed experts is closer to the float block than W4 of the original
+    q = Q.IntegerQuantizer(4, True, 'per_group', group_size=128)
+
+    def fq_block(b):
+        b = copy.deepcopy(b)
+        for n, m in b.named_modules():
+            if isinstance(m, torch.nn.Linear) and n.endswith(('w1', 'w3')):
+                m.weight.data = q.fake_quant_weight_dynamic(m.weight.data)
+        return b
+    with torch.no_grad():
+        e_plain = (fq_block(blk0)(x).float() - y0).norm().item()
+        e_awq = (fq_block(blk)(x).float() - y0).norm().item()
+    assert e_awq < e_plain, (e_awq, e_plain)
