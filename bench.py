@@ -404,6 +404,25 @@ def run_awq(args):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # weight_clip: True in awq_w_only.yml runs AutoClipper after the scale search (auto_clip.py:37-77: every Linear except q / k,
+    # n_sample_token = calib seq_len = 512). Not part of configs[2]'s metric (scale search + fake-quant evaluation); timed once,
+    # outside the timed region, and reported beside it.
+    clip_ms = None
+    try:
+        step_tok = max(1, N // seq)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for name, K, layers in groups:
+            xs = acts[name][0::step_tok]
+            for (lname, R), w in zip(layers, weights[name]):
+                if lname in ('q_proj', 'k_proj'):
+                    continue
+                awq_ops.clip_search(w, xs, wq, True)
+        e1.record()
+        torch.cuda.synchronize()
+        clip_ms = e0.elapsed_time(e1)
+    except Exception:
+        clip_ms = None
     n_layers = sum(len(ls) for _, _, ls in groups)
     fl_eval = sum(2.0 * N * sum(r for _, r in ls) * K for _, K, ls in groups)        # one evaluation of every subset
     fl = sum(f for _, _, f in gemm_ev)
@@ -432,7 +451,8 @@ def run_awq(args):
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'AWQ W4A16 g128 sym, trans v2, 20-point scale search with inspect = the Linear layers, '
                                    f'{args.model}-shaped random-init layers, 1 block (7 Linear, 4 subsets) per step per GPU',
-                       'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU'},
+                       'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU',
+                       'auto_clip_ms_per_block_not_in_value': clip_ms},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                          'frac': ach * 1e12 / PEAK_MFMA_16BIT, 'traffic': awq_traffic, 'traffic_source': awq_traffic_src,
                          'kernel': 'k_linear_eval4 (llmc_linear_eval_kt, the 21 products of a search; k_linear_eval when K % 128 != 0)', 'launches': len(gemm_ev),
