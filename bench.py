@@ -786,6 +786,8 @@ def main():
         acts[groups[0][0]] = hand['cur']
 
     def step_handoff(record):
+        if args.dry and os.environ.get('LLMC_BENCH_DRY_FAIL_HANDOFF') == '1':
+            raise RuntimeError('injected hand-off failure (dry-run test of the fallback)')
         handoff_start()
         out = step_independent(record)
         handoff_finish()
@@ -799,6 +801,24 @@ def main():
         ops.sync()
 
     last = None
+    handoff_error = None
+    if handoff:
+        # Safety net for the first multi-GPU run on hardware: if the owner-to-owner transfer raises (on every rank, as an
+        # unavailable peer-to-peer path would: a rank that fails alone leaves its ring neighbours waiting until the process
+        # group's 180 s timeout), all ranks agree to fall back to the same ownership without the hand-off, and the line says so —
+        # better than no scaling line at all.
+        ok = 1
+        try:
+            step_handoff(False)
+            ops.sync()
+        except Exception as e:      # noqa: BLE001
+            ok, handoff_error = 0, f'{type(e).__name__}: {str(e)[:200]}'
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            handoff_error = handoff_error or 'the hand-off failed on another rank'
+            handoff = False
+            step = step_independent
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -902,6 +922,8 @@ def main():
         }
         if independent_value is not None:
             out['independent_value'] = independent_value      # layers/s of the same ownership without the hand-off
+        if handoff_error is not None:
+            out['handoff_error'] = handoff_error              # the run fell back to the ownership without the hand-off
         if world == 1 and not args.no_extras and not args.dry and args.model == 'llama3-8b' and args.variant == 'w_only':
             # free this run's tensors first: the secondary workloads are child processes on the same GPU
             acts.clear(); weights.clear(); ops.accs.clear(); ops.hwork.clear(); last = None

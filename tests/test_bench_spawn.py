@@ -10,10 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(extra):
+def run(extra, env_extra=None):
     env = dict(os.environ)
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
+    env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry', '--steps', '2',
                         '--warmup', '1'] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -38,6 +39,15 @@ def test_self_spawn_two_ranks_dry(mode):
         assert 'handed owner-to-owner' in j['config']['parallelism'] and j['independent_value'] > 0
     if mode == 'independent':
         assert 'independent_value' not in j
+
+
+def test_handoff_failure_falls_back_to_the_same_ownership_without_it():
+    """The safety net of the first multi-GPU run: the transfer raising (on every rank, like an unavailable peer-to-peer path)
+    makes the ranks agree to continue with the same ownership without the hand-off; the line carries the reason."""
+    j = run([], {'LLMC_BENCH_DRY_FAIL_HANDOFF': '1'})
+    assert j['n_gpus'] == 2 and j['value'] > 0 and j['scaling'] == 'weak'
+    assert 'handoff_error' in j and 'no data-path traffic' in j['config']['parallelism']
+    assert 'independent_value' not in j
 
 
 def test_single_rank_needs_a_gpu_or_dry():
