@@ -1,0 +1,111 @@
+"""The drop-in claim EXECUTED: the reference's own pipeline — `llmc/__main__.py:28-176 main(config)`
+with its `MODEL_REGISTRY` adapters (`models/llama.py:52-91`, `models/opt.py:53-90`), `BaseDataset`, `collect_first_block_input`,
+`ALGO_REGISTRY[method](...)`, `run_block_loop()` (`compression/blockwise_optimization.py:53-61`), `deploy_all_modality` and
+`PerplexityEval` — runs twice in one process on a random-init checkpoint written by `save_pretrained`: once untouched
+(oracle/_ref_gpu = plain copy of the reference, on this GPU through PyTorch-ROCm) and once after the single line
+`llmc_amd.register_into(ALGO_REGISTRY)` of INTEGRATION.md section 1. Configurations are the reference's CI files
+(`ci_check/gptq_w_only.yml`: W4 asym g128, actorder, true_sequential, quant_out; `ci_check/awq_w4a16_fakequant_eval.yml`: trans v2
++ weight_clip) and BASELINE configs[0] (RTN W8A16 per-channel, OPT-125M widths). Compared: what every Linear ends with after
+`deploy('fake_quant')` (the fake-quantized weight = codes x scales), `buf_scales / buf_zeros / buf_perm`, and the perplexity the
+reference's evaluator reports. RTN must be bit-identical; GPTQ / AWQ within the statistical envelope of DESIGN 4a (measured
+values go to LLMC_TEST_ACTUALS via conftest.report)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, 'tools', 'ref_pipeline.py')
+
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref_gpu', 'llmc')),
+                               reason='oracle/_ref_gpu (plain copy of the reference, made by __graft_entry__.build()) is absent')
+
+
+def run_arms(tmp_path, arch, methods):
+    out = str(tmp_path / 'out')
+    r = subprocess.run([sys.executable, TOOL, '--arms', 'ref,ours', '--methods', ','.join(methods), '--arch', arch,
+                        '--assets', str(tmp_path / ('assets_' + arch)), '--outdir', out],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = {}
+    for m in methods:
+        res[m] = (dict(np.load(os.path.join(out, f'ref_{m}_{arch}.npz'))), dict(np.load(os.path.join(out, f'ours_{m}_{arch}.npz'))))
+    return res
+
+
+def layer_names(d):
+    return sorted(k[:-len('/weight')] for k in d if k.endswith('/weight'))
+
+
+def compare(tag, ref, ours):
+    from conftest import report
+    assert str(ref['class_module']).startswith('llmc.compression.quantization')          # the reference's own class ran ...
+    assert str(ours['class_module']).startswith('llmc_amd.compression.quantization')     # ... and ours, through the same main()
+    names = layer_names(ref)
+    assert names == layer_names(ours) and int(ref['n_linear']) == int(ours['n_linear']) == len(names) > 0
+    stats = {}
+    for n in names:
+        assert str(ref[n + '/type']).endswith('EffcientFakeQuantLinear') and str(ours[n + '/type']).endswith('EffcientFakeQuantLinear'), n
+        assert str(ours[n + '/type']).startswith('llmc_amd.'), n
+        a, b = ref[n + '/weight'], ours[n + '/weight']
+        assert a.shape == b.shape, n
+        tol = 1e-3 * float(np.abs(a).max())
+        st = {'w_equal': float((a == b).mean()), 'w_close': float((np.abs(a - b) <= tol).mean())}
+        if n + '/buf_scales' in ref and ref[n + '/buf_scales'].size > 1:
+            sa, sb = ref[n + '/buf_scales'].reshape(-1), ours[n + '/buf_scales'].reshape(-1)
+            assert sa.shape == sb.shape, n
+            rel = np.abs(sa - sb) / np.maximum(np.abs(sa), 1e-30)
+            st['s_1e4'] = float((rel <= 1e-4).mean())
+            st['s_1e2'] = float((rel <= 1e-2).mean())
+        if n + '/buf_zeros' in ref and ref[n + '/buf_zeros'].size > 1:
+            st['z_equal'] = float((ref[n + '/buf_zeros'].reshape(-1) == ours[n + '/buf_zeros'].reshape(-1)).mean())
+        if n + '/buf_perm' in ref:
+            st['perm_equal'] = float((ref[n + '/buf_perm'] == ours[n + '/buf_perm']).mean())
+        stats[n] = st
+        report(f'ref_pipeline/{tag}/{n}', **st)
+    pa, pb = float(ref['ppl'][-1]), float(ours['ppl'][-1])
+    report(f'ref_pipeline/{tag}/ppl', ref=pa, ours=pb)
+    return stats, pa, pb
+
+
+def block_of(name):
+    parts = name.split('.')
+    return int(parts[parts.index('layers') + 1])
+
+
+@needs_ref
+def test_llama_gptq_and_awq_through_the_reference_main(tmp_path):
+    res = run_arms(tmp_path, 'llama', ['gptq', 'awq'])
+    # ---- GPTQ (ci_check/gptq_w_only.yml)
+    stats, pa, pb = compare('llama_gptq', *res['gptq'])
+    for n, st in stats.items():
+        first = block_of(n) == 0 and ('q_proj' in n or 'k_proj' in n or 'v_proj' in n)
+        # the first subset sees bit-identical inputs in both arms: only the Hessian / factor rounding differs. Every later layer's
+        # calibration input was produced by already-quantized layers (true_sequential + quant_out), so differences compound.
+        assert st['w_close'] >= (0.995 if first else 0.90), (n, st)
+        assert st['perm_equal'] >= (0.98 if first else 0.80), (n, st)
+        assert st['s_1e2'] >= (0.99 if first else 0.85), (n, st)
+    assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)
+    # ---- AWQ (ci_check/awq_w4a16_fakequant_eval.yml): scale search + clip, folded into LN / previous fc
+    stats, pa, pb = compare('llama_awq', *res['awq'])
+    for n, st in stats.items():
+        assert st['w_close'] >= 0.97, (n, st)
+    assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)
+
+
+@needs_ref
+def test_opt_rtn_gptq_through_the_reference_main(tmp_path):
+    res = run_arms(tmp_path, 'opt', ['rtn', 'gptq'])
+    # ---- BASELINE configs[0]: RTN W8A16 per-channel on OPT-125M widths — integer work, bit-identical
+    stats, pa, pb = compare('opt_rtn', *res['rtn'])
+    for n, st in stats.items():
+        assert st['w_equal'] == 1.0, (n, st)
+    assert abs(pa - pb) <= 2e-3 * pa, (pa, pb)           # the evaluator's forward runs on our GEMM in one arm, on rocBLAS in the other
+    stats, pa, pb = compare('opt_gptq', *res['gptq'])
+    for n, st in stats.items():
+        first = block_of(n) == 0 and ('q_proj' in n or 'k_proj' in n or 'v_proj' in n)
+        assert st['w_close'] >= (0.995 if first else 0.90), (n, st)
+    assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)
