@@ -201,7 +201,7 @@ int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, int64_t K, co
                       float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream);
 
 /* `W = tmp[:, invperm]` after the column loop (gptq.py:186-188) and any other fp32 column gather:
- * out[r][j] = in[r][idx[j]], in/out [R, K] fp32 contiguous, K % 4 == 0, K <= 16384, out must not alias in. */
+ * out[r][j] = in[r][idx[j]], in/out [R, K] fp32 contiguous, K % 4 == 0, K <= 40960 (one row staged in LDS), out must not alias in. */
 int llmc_gather_cols(const float* in, int64_t R, int64_t K, const int64_t* idx, float* out, llmc_stream_t stream);
 
 /* gptq.py:172-174: cholesky -> cholesky_inverse -> cholesky(upper). Computes the same upper factor U

@@ -28,6 +28,9 @@ def hessian_prep(H, W, perm, percdamp, want_h=True, h_out=None):
     return Hout, Wout
 
 
+GATHER_MAX_K = 40960      # llmc_gather_cols stages one fp32 row in LDS (160 KB): K = 28672 (70B down_proj) included
+
+
 def gather_cols(src, idx):
     """out[:, j] = src[:, idx[j]] for fp32 [R, K] on the GPU (the reference's `tmp[:, invperm]`, gptq.py:186-188)."""
     _ffi.require_gpu(src, idx)

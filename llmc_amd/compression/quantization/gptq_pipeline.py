@@ -94,8 +94,8 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
     if perm is not None:
         invperm = torch.argsort(perm)
         K4 = tmp.shape[1]
-        # gptq.py:188. LDS-staged gather where the shape allows it (K % 4 == 0, K <= 16384)
-        tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= 16384) else tmp.index_select(1, invperm)
+        # gptq.py:188. LDS-staged gather where the shape allows it (K % 4 == 0, K <= 40960: a row of up to 160 KB staged in LDS)
+        tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= gptq_ops.GATHER_MAX_K) else tmp.index_select(1, invperm)
     out = []
     r0 = 0
     for r in rows:
@@ -143,7 +143,7 @@ def quantize_owq(W, H, cfg, n_out, wquantizer, rtn_scales=None, rtn_zeros=None, 
     tmp[:, n_nonout:] = Wp[:, n_nonout:]                     # gptq.py:187: the compensated fp outlier columns
     invperm = torch.argsort(perm)
     K4 = tmp.shape[1]
-    tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= 16384) else tmp.index_select(1, invperm)
+    tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= gptq_ops.GATHER_MAX_K) else tmp.index_select(1, invperm)
     return GptqResult(weight=tmp, scales=s, zeros=None if cfg.symmetric else z, perm=perm,
                       loss=losses.sum() if losses is not None else None, info=info)
 

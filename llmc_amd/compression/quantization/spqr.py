@@ -109,7 +109,7 @@ def quantize_stacked(W_list, H, cfg):
         tmp, losses, mask, s, z = spqr_quantize(Wl, U, cfg, thr)
         if invperm is not None:
             K = tmp.shape[1]
-            tmp = gptq_ops.gather_cols(tmp, invperm) if (K % 4 == 0 and K <= 16384) else tmp.index_select(1, invperm)
+            tmp = gptq_ops.gather_cols(tmp, invperm) if (K % 4 == 0 and K <= gptq_ops.GATHER_MAX_K) else tmp.index_select(1, invperm)
             mask = mask.index_select(1, invperm)
         out.append(SpqrResult(weight=tmp, mask=mask.bool(), scales=s, zeros=z, perm=perm, loss=losses.sum(),
                               threshold=thr, info=info))

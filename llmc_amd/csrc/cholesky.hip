@@ -373,9 +373,10 @@ __global__ __launch_bounds__(256) void k_gather_w(const T* __restrict__ W, int64
 }
 
 
-// LDS-staged gathers (K % 4 == 0, K*4 <= 64 KB): a workgroup reads ONE source row contiguously (16-B loads), keeps it
-// in LDS as fp32, and writes the permuted row contiguously (16-B stores) — both HBM streams coalesced; the random
-// access happens in LDS. The element-wise kernels above remain for other shapes.
+// LDS-staged gathers (K % 4 == 0, K*4 <= 160 KB, i.e. K <= 40960: a 70B down_proj row, K = 28672, is 112 KB): a workgroup
+// reads ONE source row contiguously (16-B loads), keeps it in LDS as fp32, and writes the permuted row contiguously (16-B
+// stores) — both HBM streams coalesced; the random access happens in LDS. The element-wise kernels above remain for other
+// shapes.
 template <typename T> __device__ __forceinline__ float4 load4_f32(const T* p);
 template <> __device__ __forceinline__ float4 load4_f32<float>(const float* p) {
     return *reinterpret_cast<const float4*>(p);
@@ -421,16 +422,21 @@ __global__ __launch_bounds__(512) void k_gather_lds(const T* __restrict__ in, in
     }
 }
 
+static constexpr int GATHER_LDS_MAX = 160 * 1024;   // the whole LDS of a CU (one workgroup per CU above 80 KB)
+
 template <typename T, int MODE>
 static int gather_lds_launch(const T* in, int64_t R, int64_t K, const int64_t* idx, const uint8_t* dead,
                              float percdamp, const float* diag_mean, float* out, hipStream_t st) {
+    // rows above 64 KB need the kernel's dynamic-LDS ceiling raised once (per device and instantiation)
+    if (K * 4 > 65536)
+        if (int rc = ensure_dynamic_lds((const void*)k_gather_lds<T, MODE>, GATHER_LDS_MAX)) return rc;
     hipLaunchKernelGGL((k_gather_lds<T, MODE>), dim3((unsigned)R), dim3(512), (size_t)K * 4, st, in, (int)K, idx, dead,
                        percdamp, diag_mean, out);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }
 static inline bool gather_lds_ok(int64_t K, const void* in, const void* out, int esz) {
-    return K % 4 == 0 && K * 4 <= 65536 && ((uintptr_t)in % (4 * esz)) == 0 && ((uintptr_t)out & 15) == 0;
+    return K % 4 == 0 && K * 4 <= GATHER_LDS_MAX && ((uintptr_t)in % (4 * esz)) == 0 && ((uintptr_t)out & 15) == 0;
 }
 
 }  // namespace llmc
@@ -444,7 +450,7 @@ extern "C" int llmc_gather_cols(const float* in, int64_t R, int64_t K, const int
     hipStream_t st = (hipStream_t)stream;
     if (gather_lds_ok(K, in, out, 4))
         return gather_lds_launch<float, 0>(in, R, K, idx, nullptr, 0.0f, nullptr, out, st);
-    set_last_error_msg("gather_cols: K must be a multiple of 4 with K <= 16384 and 16-byte aligned rows");
+    set_last_error_msg("gather_cols: K must be a multiple of 4 with K <= 40960 and 16-byte aligned rows");
     return LLMC_ENOTSUP;
 }
 

@@ -20,7 +20,7 @@ def cu(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
 
 
-@pytest.mark.parametrize('R', [16384, 28672])
+@pytest.mark.parametrize('R', [16384, 28672, 57344])      # 57344 = the Llama-3-70B gate|up stack
 @pytest.mark.parametrize('static_groups', [False, True])
 def test_column_loop_many_rows_bit_exact(R, static_groups):
     """R >= 16384 selects k_gptq_block<*, 1024> (gptq_loop.hip); bench's gate|up stack has R = 28672."""
