@@ -11,9 +11,17 @@ from .module_utils import _LLMC_LINEAR_TYPES_, _TRANSFORMERS_LINEAR_TYPES_
 
 
 class AutoClipper:
-    def __init__(self, w_only, wquantizer, aquantizer, clip_version, clip_sym, save_clip, padding_mask):
+    def __init__(self, w_only, wquantizer, aquantizer, clip_version, clip_sym, save_clip, padding_mask,
+                 external_ranges=False):
         if clip_version not in ('v1', 'v2'):
             raise Exception('Not support other clip version')
+        if clip_version == 'v2' and not external_ranges:
+            # fail where the configuration is read, not after block 0's calibration forward: the v2 range SEARCH
+            # (auto_clip.py:262-272) is not built — see _auto_clip_layer_v2. Callers that bring their own ranges (llmc's
+            # two-stage pipelines load clips.pth) ask for the durable half explicitly: apply_clip / get_clip_factor.
+            raise NotImplementedError('AutoClipper clip_version v2: the range search is outside the hot path (per_channel + '
+                                      'activation-quantized pipelines). Pass external_ranges=True (quant.special.'
+                                      'clip_external_ranges: True) to use apply_clip / get_clip_factor with ranges of your own')
         if not w_only:
             raise NotImplementedError('AutoClipper with activation quantization (fake_quantize_input, auto_clip.py:276-281) '
                                       'is outside the hot path')

@@ -199,13 +199,15 @@ class Awq(BaseBlockwiseQuantization):
                     if len(input) == 1:
                         # one batch (the shipped bs: -1): loss_mean = loss, scales_mean = scales; the 20 losses and
                         # the running best stay on the device — no host sync per grid point (the reference's .item())
+                        # Like the reference (best_error = inf, `loss_mean < best_error`, awq.py:189,245): a NaN loss never
+                        # wins, whichever grid point it occurs at, and the first finite minimum is kept.
                         loss = loss.reshape(1).float()
                         if best_scales is None:
-                            best_err_dev, best_scales = loss, scales
-                        else:
-                            better = loss < best_err_dev
-                            best_scales = torch.where(better, scales, best_scales)
-                            best_err_dev = torch.where(better, loss, best_err_dev)
+                            best_err_dev = torch.full_like(loss, float('inf'))
+                            best_scales = torch.zeros_like(scales)
+                        better = loss < best_err_dev
+                        best_scales = torch.where(better, scales, best_scales)
+                        best_err_dev = torch.where(better, loss, best_err_dev)
                         continue
                     loss = float(loss)
                     n_samples = self.n_samples
@@ -214,6 +216,8 @@ class Awq(BaseBlockwiseQuantization):
                     if loss_mean < best_error:             # inside the batch loop, like the reference
                         best_error, best_scales = loss_mean, scales_mean
         if len(input) == 1:
+            if not bool(torch.isfinite(best_err_dev).all()):      # the subset's one host sync; the reference ends with best_scales = None here
+                raise RuntimeError('AWQ scale search: no grid point produced a finite loss')
             return best_scales, best_err_dev
         return best_scales, torch.tensor([best_error], dtype=torch.float32, device=dev)
 

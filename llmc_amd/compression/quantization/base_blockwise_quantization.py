@@ -123,7 +123,8 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             self.auto_clipper = AutoClipper(
                 w_only=self.w_only, wquantizer=self.wquantizer, aquantizer=self.aquantizer,
                 clip_version=self.clip_version, clip_sym=special.get('clip_sym', self.wquantizer.sym),
-                save_clip=self.save_clip, padding_mask=self.padding_mask)
+                save_clip=self.save_clip, padding_mask=self.padding_mask,
+                external_ranges=special.get('clip_external_ranges', False))
         self.save_scale = special.get('save_scale', False)
         if self.save_scale:
             self.scale_path = special['scale_path']

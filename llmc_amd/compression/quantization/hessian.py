@@ -25,7 +25,12 @@ class HessianAccumulator:
 
     DIRECT_TOKENS = 16384          # calls at least this large go straight to the kernel
     SHORT_TOKENS = 256             # samples shorter than this are packed together at flush time
-    MAX_PENDING_TOKENS = 1 << 19   # references held at most (4 GiB of 16-bit activations at K = 4096)
+    MAX_PENDING_TOKENS = 1 << 19   # references one accumulator holds at most, in tokens ...
+    MAX_PENDING_BYTES = 16 << 30   # ... and in bytes (tokens * K * 2): one 128 x 2048 x 28672 input (14 GiB) is still one launch
+    GLOBAL_PENDING_BYTES = 48 << 30   # all accumulators of the process together (every subset of a block stays pending until its
+    #                                   transform: 13 GiB for a Llama-3-8B block, 26 GiB for a 70B one); past it the adder flushes early.
+    #                                   The reference frees each activation right after add_batch (gptq.py:254-295).
+    _global_pending = 0            # bytes of deferred references held by all accumulators
     COPY_FLUSH_TOKENS = 65536      # defer=False: private copies are flushed at this many tokens
 
     def __init__(self, columns, device, defer=True, max_pending_tokens=None):
@@ -38,6 +43,7 @@ class HessianAccumulator:
         self.max_pending_tokens = int(max_pending_tokens or self.MAX_PENDING_TOKENS)
         self._pending = []        # (x2d, b, src, version) — src is None for private copies
         self._pending_tok = 0
+        self._pending_bytes = 0
         self.timing = None   # optional list of (e0, e1, e2, T, K): e0..e1 around the MFMA kernel, e1..e2 the reduction
 
     @property
@@ -88,20 +94,32 @@ class HessianAccumulator:
         else:
             self._pending.append((x, b, inp, inp._version))            # deferred: a reference, checked at flush
         self._pending_tok += T
+        nbytes = T * self.K * x.element_size()
+        self._pending_bytes += nbytes
+        HessianAccumulator._global_pending += nbytes
         self.nsamples += b
-        if self._pending_tok >= (self.max_pending_tokens if self.defer else self.COPY_FLUSH_TOKENS):
+        if (self._pending_tok >= (self.max_pending_tokens if self.defer else self.COPY_FLUSH_TOKENS)
+                or self._pending_bytes >= self.MAX_PENDING_BYTES
+                or HessianAccumulator._global_pending >= self.GLOBAL_PENDING_BYTES):
             self.flush()
         return self._H
+
+    def _drop_pending(self):
+        HessianAccumulator._global_pending = max(0, HessianAccumulator._global_pending - self._pending_bytes)
+        self._pending, self._pending_tok, self._pending_bytes = [], 0, 0
 
     def flush(self):
         """One launch per (dtype, row stride) for everything pending (no-op when nothing is)."""
         if not self._pending:
             return
-        pend, self._pending, self._pending_tok = self._pending, [], 0
-        for x, _, src, ver in pend:
+        # validate BEFORE anything is dropped: a caller that catches this still holds a consistent accumulator (the pending
+        # samples and nsamples agree; reset() discards them)
+        for x, _, src, ver in self._pending:
             if src is not None and src._version != ver:
                 raise RuntimeError('hessian: a deferred calibration tensor was modified in place before its Hessian was '
                                    'accumulated; construct the accumulator with defer=False (GPTQ: special.hessian_defer: False)')
+        pend = self._pending
+        self._drop_pending()
         # short samples (and whatever shares their dtype) are packed into one compact tensor per dtype
         b_total = sum(b for _, b, _, _ in pend)
         by_key, short = {}, {}
@@ -119,6 +137,8 @@ class HessianAccumulator:
         if not groups:                                  # only empty calls: H <- H * n/(n+b)
             if self._flushed:
                 self._H.mul_(self._flushed / (self._flushed + b_total))
+            else:
+                self._H.zero_()                         # after reset() the buffer still holds the previous Hessian: 0 * n/(n+b)
             self._flushed += b_total
             return
         # the sequences of the whole flush enter the running mean with the first launch; the others add their products
@@ -179,8 +199,14 @@ class HessianAccumulator:
         """Start a new Hessian in the same buffers (the first launch overwrites H: n_before = 0)."""
         self.nsamples = 0
         self._flushed = 0
-        self._pending, self._pending_tok = [], 0
+        self._drop_pending()
 
     def release_workspace(self):
         self._ws = None
-        self._pending, self._pending_tok = [], 0
+        self._drop_pending()
+
+    def __del__(self):
+        try:
+            self._drop_pending()
+        except Exception:       # noqa: BLE001 (interpreter shutdown)
+            pass

@@ -25,7 +25,7 @@ def case(name, device):
     kw = dict(group_size=gs) if gs else {}
     wq = IntegerQuantizer(4, bool(sym), 'per_group' if gs else 'per_channel', calib_algo='learnable', **kw)
     ac = AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v2', clip_sym=bool(clip_sym),
-                     save_clip=True, padding_mask=None)
+                     save_clip=True, padding_mask=None, external_ranges=True)
     w = t('w')
     layer = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device=device, dtype=dt)
     layer.weight.data = w.clone()
@@ -48,6 +48,9 @@ def test_v2_search_is_declared_out_of_scope():
     with pytest.raises(NotImplementedError, match='v2'):
         ac.auto_clip_layer(0, 'fc', layer.weight, [torch.zeros(1, 4, layer.weight.shape[1], dtype=layer.weight.dtype)], 20, 0.5, 4)
     from llmc_amd.compression.quantization.auto_clip import AutoClipper
+    with pytest.raises(NotImplementedError, match='external_ranges'):       # v2 without ranges of the caller's own: at construction
+        AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v2', clip_sym=True, save_clip=False,
+                    padding_mask=None)
     with pytest.raises(Exception, match='clip version'):
         AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v3', clip_sym=True, save_clip=False,
                     padding_mask=None)

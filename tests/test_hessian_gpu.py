@@ -211,3 +211,58 @@ def test_deferred_sample_modified_before_flush_raises():
     x.mul_(2)                                               # the producer reuses the buffer
     with pytest.raises(RuntimeError):
         acc.H
+
+
+def test_failed_flush_keeps_the_pending_samples_and_reset_then_empty_calls_start_from_zero():
+    """(a) a flush that raises (a deferred tensor was modified) must not drop the pending samples while nsamples
+    still counts them; (b) after reset(), a first flush that holds only EMPTY calls (an expert without tokens) must not let the
+    previous Hessian leak into the new one through alpha = n/(n+b)."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    K = 256
+    acc = HessianAccumulator(K, 'cuda')
+    xs = [make_x(300, K, 'bf16', 40 + i).cuda() for i in range(3)]
+    for x in xs:
+        acc.add(x)
+    xs[1].mul_(2.0)
+    with pytest.raises(RuntimeError):
+        acc.flush()
+    assert acc.nsamples == 3 and len(acc._pending) == 3 and acc._pending_bytes == 3 * 300 * K * 2
+    # (b): fill H, reset, then an empty call, a flush, and one real sample: H must be that sample's Hessian alone
+    acc.reset()
+    assert len(acc._pending) == 0 and acc._pending_bytes == 0
+    acc.add(xs[0])
+    assert float(acc.H.abs().max()) > 0
+    acc.reset()
+    acc.add(torch.empty((1, 0, K), dtype=torch.bfloat16, device='cuda'))
+    acc.flush()
+    assert float(acc._H.abs().max()) == 0.0
+    acc.add(xs[2])
+    H = acc.H.cpu().numpy()
+    Href, n = G.add_batch(np.zeros((K, K), np.float32), 1, xs[2].float().cpu().numpy())   # one empty sample came first: n = 1
+    assert acc.nsamples == 2 and n == 2
+    assert rel_err(H, Href).max() < 1e-5
+
+
+def test_pending_references_are_bounded_in_bytes(monkeypatch):
+    """the bound on deferred references counts bytes (tokens x K x 2), per accumulator and across accumulators."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    K = 512
+    monkeypatch.setattr(HessianAccumulator, 'MAX_PENDING_BYTES', 3 * 400 * K * 2)
+    a = HessianAccumulator(K, 'cuda')
+    xs = [make_x(400, K, 'bf16', 50 + i).cuda() for i in range(4)]
+    a.add(xs[0]); a.add(xs[1])
+    assert len(a._pending) == 2
+    a.add(xs[2])                                    # reaches the per-accumulator bound: flushed
+    assert len(a._pending) == 0 and a._flushed == 3
+    monkeypatch.setattr(HessianAccumulator, 'MAX_PENDING_BYTES', 1 << 40)
+    monkeypatch.setattr(HessianAccumulator, 'GLOBAL_PENDING_BYTES', HessianAccumulator._global_pending + 3 * 400 * K * 2)
+    b = HessianAccumulator(K, 'cuda')
+    a.add(xs[3]); b.add(xs[0])
+    assert len(a._pending) == 1 and len(b._pending) == 1
+    b.add(xs[1])                                    # the global budget: the adder flushes
+    assert len(b._pending) == 0 and len(a._pending) == 1
+    ref = HessianAccumulator(K, 'cuda', defer=False)
+    for x in xs:
+        ref.add(x)
+    # an early flush splits the running mean into two updates: the same matrix up to fp32 rounding
+    assert rel_err(a.H.cpu().numpy(), ref.H.cpu().numpy()).max() < 1e-5
