@@ -77,6 +77,8 @@ def parse_args(argv=None):
                          'handoff = the same ownership, and the calibration activations entering a block arrive from the '
                          'rank that owns the previous block over RCCL send/recv (xGMI), overlapped with compute; '
                          'cooperative = all ranks share ONE block (broadcast / sample-sharded all_reduce, strong scaling)')
+    ap.add_argument('--helpers', choices=['none', 'wide', 'all'], default=None,
+                    help='which chains may use the internal helper streams of K3 / K4 (pipelined schedules, round 4): none, the widest (down_proj), all')
     ap.add_argument('--wide-helper', type=int, default=0, help='1: the widest chain (down_proj) keeps its internal helper stream (measured 94.5 vs 93.7 ms per step without: the three other chains already fill the gaps)')
     ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
     ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
@@ -710,7 +712,7 @@ def main():
             g0 = groups[order[0]]
             with ops.cu_reserve(args.reserve):
                 Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
-            chain(0, order[0], helper=args.wide_helper)
+            chain(0, order[0], helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
         else:
             if args.order == 'k1first':
                 for name, K, layers in groups:
@@ -721,7 +723,7 @@ def main():
                     Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
                 # one stream per chain, internal helper streams off (--wide-helper 1 gives the widest chain its helper:
                 # measured 94.5 against 93.7 ms per step, gpurun_out/r03g: the other chains already fill its gaps)
-                chain(si, gi, helper=bool(args.wide_helper) and si == 0)
+                chain(si, gi, helper=(args.helpers == 'all') or ((args.helpers == 'wide' or bool(args.wide_helper)) and si == 0))
         for st in set(evs):
             cur.wait_stream(st)
         return outs

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "sgemm.h"
 #include "side_stream.h"
+#include "pipe_streams.h"
 
 namespace llmc {
 
@@ -90,21 +91,73 @@ __device__ __forceinline__ void wave_potrf32_inv(float* __restrict__ S, float* _
         E[r] = row == j ? 1.0f : 0.0f;
     }
     bool bad = false;
+    // Round 4: pivots in PANELS of four. Rows 4q .. 4q+3 sit in the four registers 4(q>>1) .. +3 of ONE half-wave
+    // (q & 1), so a panel is factored on the VALU alone — pivot, rsq + Newton, scale the row, and update the (at most
+    // three) later rows of the panel with one v_readlane + one fma each, the same fma(-u, row_i, row_k) the matrix pipe
+    // would do — while the matrix pipe applies the PREVIOUS panel's pivots to the identity half (E). The rows below the
+    // panel then get the panel's four pivots as two rank-2 updates per accumulator (both k-slots of v_mfma_f32_32x32x2:
+    // the second pivot's row is moved to the other half-wave by v_permlane32_swap). Before (round 3) every pivot waited
+    // for its own two dependent MFMAs (2 x 64 pipe cycles + the accumulator read-back): 269 cycles per pivot measured
+    // (profiles/r04_potrf_stamps.txt); now the matrix pipe carries 4 MFMAs per panel and the pivot chain is VALU-only.
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;   // register and half-wave holding row i
-        const float d = rdlane(A[ri], hi * 32 + i);
-        if (!(d > 0.0f)) bad = true;
-        float rinv = __builtin_amdgcn_rsqf(d);
-        rinv = rinv * (1.5f - 0.5f * d * rinv * rinv);
-        const bool mine = h == hi;
-        const float va = (mine && j >= i) ? A[ri] * rinv : 0.0f;   // scaled row i of A (upper part), other half 0
-        const float ve = mine ? E[ri] * rinv : 0.0f;               // scaled row i of the identity half
-        A[ri] = mine ? va : A[ri];
-        E[ri] = mine ? ve : E[ri];
-        const float mult = (mine && j > i) ? -va : 0.0f;           // -u_ik as the multiplier of row k = j, k > i
-        A = __builtin_amdgcn_mfma_f32_32x32x2f32(mult, va, A, 0, 0, 0);
-        E = __builtin_amdgcn_mfma_f32_32x32x2f32(mult, ve, E, 0, 0, 0);
+    for (int q = 0; q < 8; ++q) {
+        const int rb = 4 * (q >> 1), hq = q & 1;
+        const bool mine = h == hq;
+        float row[4], va[4], rinv[4], m[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) row[t] = A[rb + t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * q + t;
+            const float d = rdlane(row[t], hq * 32 + i);
+            if (!(d > 0.0f)) bad = true;
+            float ri = __builtin_amdgcn_rsqf(d);
+            ri = ri * (1.5f - 0.5f * d * ri * ri);
+            rinv[t] = ri;
+            va[t] = (mine && j >= i) ? row[t] * ri : 0.0f;          // scaled row i (upper part); the other half-wave holds 0
+#pragma unroll
+            for (int s2 = t + 1; s2 < 4; ++s2) {
+                m[t][s2] = rdlane(va[t], hq * 32 + 4 * q + s2);     // u_{i, 4q+s2}
+                row[s2] = __builtin_fmaf(-m[t][s2], va[t], row[s2]);
+            }
+        }
+        // the identity half of the panel, with the multipliers found above
+        float er[4], ve[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) er[t] = E[rb + t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ve[t] = mine ? er[t] * rinv[t] : 0.0f;
+#pragma unroll
+            for (int s2 = t + 1; s2 < 4; ++s2) er[s2] = __builtin_fmaf(-m[t][s2], ve[t], er[s2]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            A[rb + t] = mine ? va[t] : A[rb + t];
+            E[rb + t] = mine ? ve[t] : E[rb + t];
+        }
+        if (q < 7) {
+            // rows >= 4q+4: two rank-2 updates per accumulator. Operand lanes 0..31 = k-slot 0, 32..63 = k-slot 1.
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const float b0 = va[2 * pr], b1 = va[2 * pr + 1];
+                const float e0 = ve[2 * pr], e1 = ve[2 * pr + 1];
+                const float a0 = (mine && j >= 4 * q + 4) ? -b0 : 0.0f;      // -u_{i,k} as the multiplier of row k = j
+                const float a1 = (mine && j >= 4 * q + 4) ? -b1 : 0.0f;
+                float opa, opb, ope;
+                if (hq == 0) {       // data in lanes 0..31: x = [p0 | 0], y = [p1 | 0] -> [p0 | p1]
+                    opa = __int_as_float(__builtin_amdgcn_permlane32_swap(__float_as_int(a0), __float_as_int(a1), false, false)[0]);
+                    opb = __int_as_float(__builtin_amdgcn_permlane32_swap(__float_as_int(b0), __float_as_int(b1), false, false)[0]);
+                    ope = __int_as_float(__builtin_amdgcn_permlane32_swap(__float_as_int(e0), __float_as_int(e1), false, false)[0]);
+                } else {             // data in lanes 32..63: swap(y, x) leaves [p1 | p0] in the second result
+                    opa = __int_as_float(__builtin_amdgcn_permlane32_swap(__float_as_int(a1), __float_as_int(a0), false, false)[1]);
+                    opb = __int_as_float(__builtin_amdgcn_permlane32_swap(__float_as_int(b1), __float_as_int(b0), false, false)[1]);
+                    ope = __int_as_float(__builtin_amdgcn_permlane32_swap(__float_as_int(e1), __float_as_int(e0), false, false)[1]);
+                }
+                A = __builtin_amdgcn_mfma_f32_32x32x2f32(opa, opb, A, 0, 0, 0);
+                E = __builtin_amdgcn_mfma_f32_32x32x2f32(opa, ope, E, 0, 0, 0);
+            }
+        }
     }
     if (bad && lane == 0) atomicCAS(info, 0, kglobal + 1);
 #pragma unroll
@@ -176,21 +229,28 @@ __global__ __launch_bounds__(256, 2) void k_potrf_inv(float* __restrict__ W, int
     {
         float4 ld4[16];
         const bool full = nb == NB && (ld % 4 == 0) && (k0 % 4 == 0);
+        // the whole-block path has NO control flow between its 16 loads: with the edge path merged into the same loop the
+        // compiler waited for every load before issuing the next (16 serialised round trips, 22.6k of the kernel's 93.7k
+        // cycles: profiles/r04_potrf_stamps.txt)
+        if (full) {
+            const float* base = W + (int64_t)(k0 + (tid >> 5)) * ld + k0 + (tid & 31) * 4;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e4 = tid + 256 * q;            // float4 index: row = e4 >> 5, col4 = e4 & 31
-            const int i = e4 >> 5, j = (e4 & 31) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (full) {
-                v = *reinterpret_cast<const float4*>(W + (int64_t)(k0 + i) * ld + k0 + j);
-            } else if (i < nb) {
-                const float* p = W + (int64_t)(k0 + i) * ld + k0 + j;
-                if (j < nb) v.x = p[0];
-                if (j + 1 < nb) v.y = p[1];
-                if (j + 2 < nb) v.z = p[2];
-                if (j + 3 < nb) v.w = p[3];
+            for (int q = 0; q < 16; ++q) ld4[q] = *reinterpret_cast<const float4*>(base + (int64_t)(8 * q) * ld);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e4 = tid + 256 * q;            // float4 index: row = e4 >> 5, col4 = e4 & 31
+                const int i = e4 >> 5, j = (e4 & 31) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nb) {
+                    const float* p = W + (int64_t)(k0 + i) * ld + k0 + j;
+                    if (j < nb) v.x = p[0];
+                    if (j + 1 < nb) v.y = p[1];
+                    if (j + 2 < nb) v.z = p[2];
+                    if (j + 3 < nb) v.w = p[3];
+                }
+                ld4[q] = v;
             }
-            ld4[q] = v;
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -306,8 +366,8 @@ __global__ __launch_bounds__(256) void k_zero_subdiag(float* __restrict__ W, int
 
 // copy the inverted diagonal blocks into the work matrix (upper), before the doubling levels
 __global__ __launch_bounds__(256) void k_place_diag_inv(float* __restrict__ W, int64_t ld, int K,
-                                                        const float* __restrict__ Vbuf) {
-    const int b = blockIdx.x;
+                                                        const float* __restrict__ Vbuf, int b0) {
+    const int b = b0 + blockIdx.x;
     const int k0 = b * NB;
     const int nb = min(NB, K - k0);
     const float* V = Vbuf + (int64_t)b * NB * NB;
@@ -522,13 +582,33 @@ static size_t gemm6_bytes(int64_t K) {
     return align256(mx);
 }
 
+// the top level of the triangular inverse: the one pair [0, h_top) | [h_top, K) with h_top the largest NB * 2^n below K
+static inline int64_t top_level_h(int64_t K) {
+    int64_t h = NB;
+    while (2 * h < K) h *= 2;
+    return h;
+}
+static size_t top_x_bytes(int64_t K) {
+    const int64_t h = top_level_h(K), n2 = K - h;
+    return K > 1024 ? align256((size_t)h * (size_t)((n2 + 3) / 4 * 4) * 4) : 0;
+}
+static size_t top_g6_bytes(int64_t K) {
+    const int64_t h = top_level_h(K), n2 = K - h;
+    if (K <= 1024 || h < GEMM6_MIN_H || h % 256 || n2 % 256) return 0;
+    const size_t a = gemm6_ws_bytes((int)h, (int)n2, (int)h), b = gemm6_ws_bytes((int)h, (int)n2, (int)n2);
+    return align256(a > b ? a : b);
+}
+
 extern "C" size_t llmc_chol_inv_upper_ws_bytes(int64_t K) {
     if (K <= 0) return 0;
     size_t work = align256((size_t)K * K * 4);
     size_t vbuf = align256((size_t)ceil_div64(K, NB) * NB * NB * 4);
     size_t xbuf = align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
-    return work + vbuf + xbuf + gemm6_bytes(K);
+    // pipelined schedule: the top inverse level's X = A^-1 C runs beside the factorisation's last blocks with buffers of its own
+    return work + vbuf + xbuf + gemm6_bytes(K) + top_x_bytes(K) + top_g6_bytes(K);
 }
+
+static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev, hipStream_t st, PipeStreams* ps);
 
 extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
     LLMC_REQUIRE(A && ws && info_dev && K64 > 0, "chol_inv_upper: null/empty argument");
@@ -536,6 +616,16 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     LLMC_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)ws & 255) == 0, "chol_inv_upper: alignment");
     hipStream_t st = (hipStream_t)stream;
     const int K = (int)K64;
+    // Round 4: the pipelined schedule (three helper streams, the inverse behind the factorisation) for every matrix with
+    // more than two outer blocks, when helper streams are allowed. Same kernels, same tiles, same order of the updates an
+    // element receives: bit-identical to the serial schedule below (tests/test_gptq_gpu.py). LLMC_K3_PIPE=0 turns it off.
+    {
+        const char* e = getenv("LLMC_K3_PIPE");
+        const bool want = !(e && e[0] == '0') && !getenv("LLMC_NO_SIDE_STREAM") && helper_streams_enabled() &&
+                          !getenv("LLMC_K3_FP32") && K > 1024;
+        if (want)
+            if (PipeStreams* ps = pipe_streams_for(st)) return chol_inv_upper_pipelined(A, K, ws, info_dev, st, ps);
+    }
     float* Wk = (float*)ws;
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
@@ -668,7 +758,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     }
     (void)nblk;
     // ---- V = U'^-1: inverted diagonal blocks, then doubling levels
-    hipLaunchKernelGGL(k_place_diag_inv, dim3((K + NB - 1) / NB), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf);
+    hipLaunchKernelGGL(k_place_diag_inv, dim3((K + NB - 1) / NB), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf, 0);
     LLMC_LAUNCH_CHECK();
     if (use_x3t && use_g6 && K > GEMM6_MIN_H) {
         hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
@@ -719,5 +809,286 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     }
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);
     LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The pipelined schedule of llmc_chol_inv_upper (round 4). Streams: `st` (the caller's) carries the CHAIN — per 128-wide
+// factor step k_potrf_inv, the panel solve and the update of the outer block's OWN columns, and per 512-wide outer block
+// the update of the next block's diagonal 512 x 512 — nothing else. `fast` carries what the chain needs one block later:
+// every step's far panel solve / far in-block update and the far update of the next block's rows right of its diagonal.
+// `bulk` carries the far update of everything below the next block, its top 512 rows first (event R1: all the next
+// block's far update waits for) and then the rest. `inv` runs the triangular inverse BEHIND the factorisation: a pair of a
+// doubling level is launched as soon as the factor rows it covers are final and nobody reads the factor entries it
+// overwrites any more; the one pair of the top level has its X = A^-1 C on `bulk` with buffers of its own while the last
+// outer blocks are still being factored. Dependencies (E = event):
+//   far panel / far in-block update of a step   <- the step's near panel solve (reads V_b and the near panel)
+//   next block's diagonal update (st)           <- all far panels of the block (fast), R1 of the previous block (bulk)
+//   next block's rows, far columns (fast)       <- R1 of the previous block
+//   far-rest of block b (bulk)                  <- far panels of block b; the bulk stream's own order (block b - 1 first)
+//   inverse pairs inside block b (inv)          <- the block's steps (st) and far in-block updates (fast): last readers of
+//                                                  the block's diagonal 512 x 512
+//   inverse pairs spanning blocks (inv)         <- additionally the whole far-rest of block b - 1 (bulk): the last reader of
+//                                                  factor entries right of the diagonal blocks they overwrite
+// Every element receives the updates of the outer blocks in ascending order whatever the streams do, from the same
+// kernels on the same tile grid as the serial schedule: the factor is bit-identical to it.
+// ---------------------------------------------------------------------------------------------------------------------
+static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev, hipStream_t caller, PipeStreams* ps) {
+    // the chain's stream: the caller's, or an internal one when the caller is on the NULL stream (pipe_streams.h)
+    hipStream_t st = pipe_chain_stream(ps, caller);
+    if (st != caller) {
+        hipEvent_t ec = nullptr;
+        if (int rc = ps->record(caller, &ec)) return rc;
+        if (int rc = pipe_wait(st, ec)) return rc;
+    }
+    float* Wk = (float*)ws;
+    float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
+    float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
+    void* G6buf = (char*)Xbuf + align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
+    float* XbufTop = (float*)((char*)G6buf + gemm6_bytes(K));
+    void* G6top = (char*)XbufTop + top_x_bytes(K);
+    const bool use_g6 = getenv("LLMC_K3_NO_GEMM6") == nullptr;
+    hipStream_t fast = ps->fast, bulk = ps->bulk, inv = ps->inv;
+    LLMC_HIP_CHECK(hipMemsetAsync(info_dev, 0, 4, st));
+    if (int rc = ensure_dynamic_lds((const void*)k_potrf_inv, (NB * PLD + 32 * PLD + 64) * (int)sizeof(float))) return rc;
+
+    dim3 tgrid((K + 31) / 32, (K + 31) / 32);
+    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
+    LLMC_LAUNCH_CHECK();
+    if (use_g6 && K > GEMM6_MIN_H) {     // gemm6 reads triangular operands at 256 granularity; nothing writes below the diagonal
+        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
+        LLMC_LAUNCH_CHECK();
+    }
+    hipEvent_t e0 = nullptr;
+    if (int rc = ps->record(st, &e0)) return rc;      // the helpers start behind the caller's stream
+    if (int rc = pipe_wait(fast, e0)) return rc;
+    if (int rc = pipe_wait(bulk, e0)) return rc;
+    if (int rc = pipe_wait(inv, e0)) return rc;
+
+    const int NBO = 4 * NB;
+    auto panel_solve = [&](const float* Vb, int c0, int nb, int col0, int ncols, hipStream_t s_) -> int {
+        if (ncols <= 0) return LLMC_OK;
+        float* P = Wk + (size_t)c0 * K + col0;
+        SgemmArgs g{};
+        g.A = Vb; g.lda = NB; g.B = P; g.ldb = K; g.C = P; g.ldc = K;
+        g.M = g.M_last = nb; g.N = g.N_last = ncols; g.Kd = g.Kd_last = nb;
+        g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
+        return sgemm_launch(g, true, false, s_);
+    };
+    auto inblock_update = [&](int c0, int nb, int oend, int col0, int ncols, hipStream_t s_) -> int {
+        const int mrows = oend - (c0 + nb);
+        if (mrows <= 0 || ncols <= 0) return LLMC_OK;
+        SgemmArgs u{};
+        u.A = Wk + (size_t)c0 * K + c0 + nb; u.lda = K;
+        u.B = Wk + (size_t)c0 * K + col0; u.ldb = K;
+        u.C = Wk + (size_t)(c0 + nb) * K + col0; u.ldc = K;
+        u.M = u.M_last = mrows; u.N = u.N_last = ncols; u.Kd = u.Kd_last = nb;
+        u.epilogue = SG_SUB; u.c_upper_only = col0 == c0 + nb ? 1 : 0; u.batch = 1;
+        return sgemm_launch(u, true, false, s_);
+    };
+    // T[r0 .. r0+M, c0 .. c0+N] -= P[:, r0 ..]^T P[:, c0 ..] with P = factor rows k0 .. k0+Kd (split-bf16 product)
+    auto far_update = [&](int k0, int Kd, int r0, int M, int c0, int N, int upper, hipStream_t s_) -> int {
+        if (M <= 0 || N <= 0) return LLMC_OK;
+        SgemmArgs u{};
+        u.A = Wk + (size_t)k0 * K + r0; u.lda = K;
+        u.B = Wk + (size_t)k0 * K + c0; u.ldb = K;
+        u.C = Wk + (size_t)r0 * K + c0; u.ldc = K;
+        u.M = u.M_last = M; u.N = u.N_last = N; u.Kd = u.Kd_last = Kd;
+        u.epilogue = SG_SUB; u.c_upper_only = upper; u.batch = 1;
+        return gemm3_tn_launch(u, s_);
+    };
+
+    // ---- triangular inverse, level by level as the factor rows become final -------------------------------------------
+    const int64_t h_top = top_level_h(K);
+    int nlev = 0;
+    for (int64_t h = NB; h < K; h *= 2) ++nlev;
+    int launched[32] = {};                 // pairs of level li (h = NB << li) already launched
+    auto pair_count = [&](int64_t h) { return (int)((K - h + 2 * h - 1) / (2 * h)); };
+    // pairs [z0, z1) of level h on stream s_ (X through Xbuf from its start: the stream is in order)
+    auto launch_pairs = [&](int64_t h, int z0, int z1, hipStream_t s_) -> int {
+        const int npairs = pair_count(h);
+        const int64_t o_last = (int64_t)(npairs - 1) * 2 * h;
+        const int n2_last = (int)((K - o_last - h) < h ? (K - o_last - h) : h);
+        const int64_t stride = 2 * h * ((int64_t)K + 1);
+        const bool has_last = z1 == npairs;
+        const int n2b = has_last ? n2_last : (int)h;
+        const int cnt = z1 - z0;
+        const int64_t ldX = (cnt == 1 && has_last) ? ((n2_last + 3) / 4) * 4 : h;
+        const bool lvl_x3 = h >= 512;
+        const bool lvl_g6 = lvl_x3 && use_g6 && h >= GEMM6_MIN_H && h % 256 == 0 && n2_last % 256 == 0;
+        if (lvl_g6) {
+            for (int z = z0; z < z1; ++z) {
+                const int n2 = z == npairs - 1 ? n2_last : (int)h;
+                int rc = gemm6_launch(Wk + z * stride, K, Wk + h + z * stride, K, Xbuf, ldX, (int)h, n2, (int)h, 1, 0, 1.0f,
+                                      G6buf, s_);
+                if (rc) return rc;
+                rc = gemm6_launch(Xbuf, ldX, Wk + h * ((int64_t)K + 1) + z * stride, K, Wk + h + z * stride, K, (int)h, n2,
+                                  n2, 0, 1, -1.0f, G6buf, s_);
+                if (rc) return rc;
+            }
+            return LLMC_OK;
+        }
+        SgemmArgs x{};
+        x.A = Wk + z0 * stride; x.lda = K; x.sA = stride;
+        x.B = Wk + h + z0 * stride; x.ldb = K; x.sB = stride;
+        x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
+        x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2b; x.Kd = x.Kd_last = (int)h;
+        x.epilogue = SG_SET; x.a_upper = 1; x.batch = cnt;
+        int rc = lvl_x3 ? gemm3_launch(x, false, s_) : sgemm_launch(x, false, false, s_);
+        if (rc) return rc;
+        SgemmArgs y{};
+        y.A = Xbuf; y.lda = ldX; y.sA = h * h;
+        y.B = Wk + h * ((int64_t)K + 1) + z0 * stride; y.ldb = K; y.sB = stride;
+        y.C = Wk + h + z0 * stride; y.ldc = K; y.sC = stride;
+        y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2b; y.Kd = (int)h; y.Kd_last = n2b;
+        y.epilogue = SG_NEG; y.b_upper = 1; y.batch = cnt;
+        return lvl_x3 ? gemm3_launch(y, false, s_) : sgemm_launch(y, false, false, s_);
+    };
+    const int n2_top = (int)(K - h_top);
+    const int64_t ldXtop = ((n2_top + 3) / 4) * 4;
+    const bool top_g6 = use_g6 && h_top >= GEMM6_MIN_H && h_top % 256 == 0 && n2_top % 256 == 0;
+    bool top_x_done = false;
+    hipEvent_t eTopX = nullptr;
+    auto launch_top_x = [&](hipStream_t s_) -> int {       // X = A^-1 C of the top pair, into its own buffer
+        if (top_g6) return gemm6_launch(Wk, K, Wk + h_top, K, XbufTop, ldXtop, (int)h_top, n2_top, (int)h_top, 1, 0, 1.0f, G6top, s_);
+        SgemmArgs x{};
+        x.A = Wk; x.lda = K; x.B = Wk + h_top; x.ldb = K; x.C = XbufTop; x.ldc = ldXtop;
+        x.M = x.M_last = (int)h_top; x.N = x.N_last = n2_top; x.Kd = x.Kd_last = (int)h_top;
+        x.epilogue = SG_SET; x.a_upper = 1; x.batch = 1;
+        return h_top >= 512 ? gemm3_launch(x, false, s_) : sgemm_launch(x, false, false, s_);
+    };
+    auto launch_top_y = [&](hipStream_t s_) -> int {       // C = -X B^-1
+        if (top_g6)
+            return gemm6_launch(XbufTop, ldXtop, Wk + h_top * ((int64_t)K + 1), K, Wk + h_top, K, (int)h_top, n2_top, n2_top, 0, 1,
+                                -1.0f, G6top, s_);
+        SgemmArgs y{};
+        y.A = XbufTop; y.lda = ldXtop; y.B = Wk + h_top * ((int64_t)K + 1); y.ldb = K; y.C = Wk + h_top; y.ldc = K;
+        y.M = y.M_last = (int)h_top; y.N = y.N_last = n2_top; y.Kd = y.Kd_last = n2_top;
+        y.epilogue = SG_NEG; y.b_upper = 1; y.batch = 1;
+        return h_top >= 512 ? gemm3_launch(y, false, s_) : sgemm_launch(y, false, false, s_);
+    };
+
+    hipEvent_t R1_prev = nullptr, R2_prev = nullptr;
+    for (int k0 = 0; k0 < K; k0 += NBO) {
+        const int nbo = K - k0 < NBO ? K - k0 : NBO;
+        const int oend = k0 + nbo;
+        const int nfar = K - oend;
+        // ---- the block's factor steps
+        for (int c0 = k0; c0 < oend; c0 += NB) {
+            const int b = c0 / NB;
+            const int nb = K - c0 < NB ? K - c0 : NB;
+            float* Vb = Vbuf + (size_t)b * NB * NB;
+            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (NB * PLD + 32 * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
+                               nb, Vb, info_dev);
+            LLMC_LAUNCH_CHECK();
+            if (K - c0 - nb <= 0) break;
+            const int nnear = oend - (c0 + nb);
+            int rc = panel_solve(Vb, c0, nb, c0 + nb, nnear, st);
+            if (rc) return rc;
+            if (nfar > 0) {
+                hipEvent_t e = nullptr;
+                if ((rc = ps->record(st, &e))) return rc;
+                if ((rc = pipe_wait(fast, e))) return rc;
+                if ((rc = panel_solve(Vb, c0, nb, oend, nfar, fast))) return rc;
+                if ((rc = inblock_update(c0, nb, oend, oend, nfar, fast))) return rc;
+            }
+            if ((rc = inblock_update(c0, nb, oend, c0 + nb, nnear, st))) return rc;
+        }
+        // ---- end of the block
+        hipEvent_t eE = nullptr, eF = nullptr;
+        int rc = ps->record(st, &eE);
+        if (rc) return rc;
+        if ((rc = ps->record(fast, &eF))) return rc;
+        hipEvent_t R1 = nullptr, R2 = nullptr;
+        if (nfar > 0) {
+            const int m1 = nfar < NBO ? nfar : NBO, m2 = nfar - m1;
+            // next block's diagonal: the only far update the chain itself waits for
+            if ((rc = pipe_wait(st, eF))) return rc;
+            if ((rc = pipe_wait(st, R1_prev))) return rc;
+            if ((rc = far_update(k0, nbo, oend, m1, oend, m1, 1, st))) return rc;
+            if (m2 > 0) {
+                // next block's rows right of its diagonal: before that block's far panel solves on the same stream
+                if ((rc = pipe_wait(fast, R1_prev))) return rc;
+                if ((rc = far_update(k0, nbo, oend, m1, oend + m1, m2, 0, fast))) return rc;
+                // everything below the next block: its top 512 rows first
+                if ((rc = pipe_wait(bulk, eF))) return rc;
+                const int mt = m2 < NBO ? m2 : NBO;
+                if ((rc = far_update(k0, nbo, oend + m1, mt, oend + m1, m2, 1, bulk))) return rc;
+                if ((rc = ps->record(bulk, &R1))) return rc;
+                if (m2 > mt)
+                    if ((rc = far_update(k0, nbo, oend + m1 + mt, m2 - mt, oend + m1 + mt, m2 - mt, 1, bulk))) return rc;
+                if ((rc = ps->record(bulk, &R2))) return rc;
+            }
+        }
+        // ---- the inverse of what is final now (rows < oend)
+        if ((rc = pipe_wait(inv, eE))) return rc;
+        if ((rc = pipe_wait(inv, eF))) return rc;
+        {
+            const int b0 = k0 / NB, nbk = (nbo + NB - 1) / NB;
+            hipLaunchKernelGGL(k_place_diag_inv, dim3(nbk), dim3(256), 0, inv, Wk, (int64_t)K, K, (const float*)Vbuf, b0);
+            LLMC_LAUNCH_CHECK();
+        }
+        bool waited_bulk = false;
+        {
+            int li = 0;
+            for (int64_t h = NB; h < K; h *= 2, ++li) {
+                if (h == h_top) break;                      // the top pair has its own path
+                const int npairs = pair_count(h);
+                int z1 = launched[li];
+                while (z1 < npairs) {
+                    const int64_t o = (int64_t)z1 * 2 * h;
+                    const int64_t e = o + 2 * h < K ? o + 2 * h : K;
+                    if (e > oend) break;
+                    ++z1;
+                }
+                if (z1 > launched[li]) {
+                    if (2 * h > NBO && !waited_bulk) {      // the pair overwrites factor entries earlier far-rests read
+                        if ((rc = pipe_wait(inv, R2_prev))) return rc;
+                        waited_bulk = true;
+                    }
+                    if ((rc = launch_pairs(h, launched[li], z1, inv))) return rc;
+                    launched[li] = z1;
+                }
+            }
+        }
+        // the top pair's X as soon as its A half is inverted (rows < h_top final, the lower levels of that half launched)
+        if (!top_x_done && nlev >= 1 && oend >= h_top && oend < K) {
+            hipEvent_t eA = nullptr;
+            if ((rc = ps->record(inv, &eA))) return rc;          // the A half's inverse is complete behind this point
+            if ((rc = pipe_wait(bulk, eA))) return rc;
+            if ((rc = launch_top_x(bulk))) return rc;
+            if ((rc = ps->record(bulk, &eTopX))) return rc;
+            top_x_done = true;
+        }
+        R1_prev = R1;                 // null when this block had no far-rest: then there is no block after the next
+        if (R2) R2_prev = R2;         // sticky: the latest far-rest on the bulk stream, whichever block issued it
+    }
+    // ---- the top pair: X (unless already running) and Y = -X B^-1 once the B half is inverted
+    if (nlev >= 1) {
+        hipEvent_t eB = nullptr;
+        int rc = ps->record(inv, &eB);
+        if (rc) return rc;
+        if ((rc = pipe_wait(bulk, eB))) return rc;
+        if (!top_x_done) {
+            if ((rc = launch_top_x(bulk))) return rc;
+        }
+        if ((rc = launch_top_y(bulk))) return rc;
+    }
+    // ---- join the helpers, write U
+    for (hipStream_t s_ : {fast, bulk, inv}) {
+        hipEvent_t e = nullptr;
+        int rc = ps->record(s_, &e);
+        if (rc) return rc;
+        if ((rc = pipe_wait(st, e))) return rc;
+    }
+    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);
+    LLMC_LAUNCH_CHECK();
+    (void)eTopX;
+    if (st != caller) {
+        hipEvent_t ec = nullptr;
+        if (int rc = ps->record(st, &ec)) return rc;
+        if (int rc = pipe_wait(caller, ec)) return rc;
+    }
     return LLMC_OK;
 }

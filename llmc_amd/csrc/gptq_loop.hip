@@ -16,6 +16,7 @@
 #include "quant_math.h"
 #include "sgemm.h"
 #include "side_stream.h"
+#include "pipe_streams.h"
 
 namespace llmc {
 
@@ -431,7 +432,7 @@ static constexpr int GRP = 4;  // 128-column blocks per outer group (far updates
 
 extern "C" size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K) {
     if (R <= 0 || K <= 0) return 0;
-    return 2 * (size_t)R * BS * GRP * sizeof(float);   // double-buffered err columns (look-ahead)
+    return 3 * (size_t)R * BS * GRP * sizeof(float);   // err columns of three groups in flight (pipelined far updates)
 }
 
 extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
@@ -468,25 +469,44 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     } else if (!per_channel) {
         LLMC_REQUIRE(col_group != nullptr, "gptq_quantize: col_group required with static groups");
     }
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
     const int ELD = BS * GRP;
-    float* ErrBuf[2] = {(float*)ws, (float*)ws + (size_t)R * ELD};   // [R, GRP*128] x 2: err columns of a group
-    SideStream* side = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : side_stream_for(st);
-    bool pending_side = false;
+    float* ErrBuf[3] = {(float*)ws, (float*)ws + (size_t)R * ELD, (float*)ws + 2 * (size_t)R * ELD};   // [R, GRP*128] x 3
+    // Round 4 schedule. The caller's stream carries the CHAIN: per 128-column block the in-block kernel and the update of the
+    // rest of its group's columns, per group the update of the NEXT group's columns. The `bulk` helper stream (CU-masked:
+    // pipe_streams.h) carries the update of everything beyond the next group, the columns of the group after next FIRST
+    // (event C1: all the next group's own update waits for), then the rest. Round 3 joined the whole side update before
+    // every group's far update, so the chain stood still while ~430 us of fp32 far update drained. Per element the updates
+    // still arrive in the reference's order (block 0, 1, 2, ...: bulk stream order, then the chain behind C1), from the
+    // same kernels on the same tile grid: bit-identical to one stream (LLMC_NO_SIDE_STREAM=1), which tests compare.
+    PipeStreams* ps = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : pipe_streams_for(caller);
+    hipStream_t st = ps ? pipe_chain_stream(ps, caller) : caller;
+    hipStream_t bulk = ps ? ps->bulk : st;
+    if (ps) {
+        hipEvent_t e0 = nullptr;
+        int rc = ps->record(caller, &e0);
+        if (rc) return rc;
+        if (st != caller && (rc = pipe_wait(st, e0))) return rc;
+        if ((rc = pipe_wait(bulk, e0))) return rc;
+    }
+    hipEvent_t C1_prev = nullptr;                 // the previous group's far-far update has reached the next group's columns
+    hipEvent_t C2_hist[3] = {nullptr, nullptr, nullptr};   // ... is complete (its err buffer may be rewritten)
     const int force_generic = getenv("LLMC_GPTQ_GENERIC") ? 1 : 0;
     // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as
     // "W -= chain over the block's 128 k" (gptq.py:244). Columns inside the current outer group get them right
     // after each block (the next block needs them); columns beyond the group get the group's GRP updates in one
     // phased GEMM that keeps the C tile in registers — same arithmetic, one pass over the far columns per group.
-    // The far update is split: the next group's columns on the main stream, everything beyond on a side stream,
-    // overlapped with the next group's latency-bound in-block kernels (the order per element is unchanged).
     int gidx = 0;
     for (int64_t g0 = 0; g0 < NQ; g0 += (int64_t)BS * GRP, ++gidx) {
         const int64_t gend = g0 + (int64_t)BS * GRP < NQ ? g0 + (int64_t)BS * GRP : NQ;
         // columns updated right after every block: up to the end of the outer group; in the LAST group also the
         // never-visited columns beyond n_quant (their group-wide phased update could start on a ragged phase)
         const int64_t near_end = gend == NQ ? K : gend;
-        float* Err = ErrBuf[gidx & 1];
+        float* Err = ErrBuf[gidx % 3];
+        if (ps && C2_hist[gidx % 3]) {            // the far-far update that read this err buffer three groups ago
+            int rc = pipe_wait(st, C2_hist[gidx % 3]);
+            if (rc) return rc;
+        }
         for (int64_t i1 = g0; i1 < gend; i1 += BS) {
             const int count = (int)(NQ - i1 < BS ? NQ - i1 : BS);
             GptqBlockArgs a;
@@ -529,10 +549,10 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
         }
         if (near_end < K) {    // far columns: GRP phases of 128
             const int64_t gend2 = gend + (int64_t)BS * GRP < K ? gend + (int64_t)BS * GRP : K;
-            if (side && pending_side) {   // columns gend.. were last written by the previous group's side update,
-                int rc = join_from_side(side, st);   // which also still reads the other err buffer
+            // the next group's columns were last written by the previous group's far-far update (its first part)
+            if (ps) {
+                int rc = pipe_wait(st, C1_prev);
                 if (rc) return rc;
-                pending_side = false;
             }
             SgemmArgs g{};
             g.A = Err; g.lda = ELD;
@@ -542,27 +562,42 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
             g.epilogue = SG_SUB; g.batch = 1; g.phase_len = BS;
             int rc = sgemm_launch(g, false, false, st);
             if (rc) return rc;
+            C1_prev = nullptr;
             if (gend2 < K) {
+                if (ps) {
+                    hipEvent_t e = nullptr;       // this group's err columns are complete on the chain
+                    if ((rc = ps->record(st, &e))) return rc;
+                    if ((rc = pipe_wait(bulk, e))) return rc;
+                }
+                // first the columns of the group after next, then the rest (same tiles as one launch: column tiles are
+                // independent and both cuts are multiples of the tile width)
+                const int64_t gend3 = gend2 + (int64_t)BS * GRP < K ? gend2 + (int64_t)BS * GRP : K;
                 SgemmArgs h = g;
                 h.B = Hinv + g0 * K + gend2;
                 h.C = W + gend2;
-                h.N = h.N_last = (int)(K - gend2);
-                if (side) {
-                    rc = fork_to_side(side, st);   // this group's err columns are complete on main
-                    if (rc) return rc;
-                    rc = sgemm_launch(h, false, false, side->side);
-                    if (rc) return rc;
-                    pending_side = true;
-                } else {
-                    rc = sgemm_launch(h, false, false, st);
-                    if (rc) return rc;
+                h.N = h.N_last = (int)(gend3 - gend2);
+                if ((rc = sgemm_launch(h, false, false, bulk))) return rc;
+                if (ps && (rc = ps->record(bulk, &C1_prev))) return rc;
+                if (gend3 < K) {
+                    SgemmArgs h2 = g;
+                    h2.B = Hinv + g0 * K + gend3;
+                    h2.C = W + gend3;
+                    h2.N = h2.N_last = (int)(K - gend3);
+                    if ((rc = sgemm_launch(h2, false, false, bulk))) return rc;
                 }
+                if (ps && (rc = ps->record(bulk, &C2_hist[gidx % 3]))) return rc;
             }
         }
     }
-    if (side && pending_side) {
-        int rc = join_from_side(side, st);
+    if (ps) {
+        hipEvent_t e = nullptr;
+        int rc = ps->record(bulk, &e);
         if (rc) return rc;
+        if ((rc = pipe_wait(st, e))) return rc;
+        if (st != caller) {
+            if ((rc = ps->record(st, &e))) return rc;
+            if ((rc = pipe_wait(caller, e))) return rc;
+        }
     }
     return LLMC_OK;
 }

@@ -469,3 +469,60 @@ def test_owq_column_loop_and_layer_finish_match_reference_golden():
         fq = GPTQ.w_qdq(this, layer, wq)
         assert fq.dtype == TDm[str(g[p + 'w_qdq_dtype'])]
         np.testing.assert_array_equal(bits(fq.float().cpu().numpy()), bits(g[p + 'w_qdq']), err_msg=name)
+
+
+@pytest.mark.parametrize('K', [1536, 2432, 4096, 5248, 14336])
+def test_pipelined_factorisation_is_bit_identical_to_the_single_stream_schedule(K):
+    """Round 4: llmc_chol_inv_upper runs its chain, the far updates and the triangular inverse on four streams (cholesky.hip,
+    chol_inv_upper_pipelined). Same kernels, same tiles, same order of the updates an element receives: the factor must equal
+    the single-stream schedule's bit for bit (a missing dependency would show as a difference or as run-to-run noise), from
+    the default stream (the chain moves to an internal stream) and from a side stream, and the failure flag must survive."""
+    from llmc_amd import _ffi
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
+    gen = torch.Generator(device='cuda').manual_seed(K)
+    X = torch.randn(2 * K, K, generator=gen, device='cuda')
+    H = (X.T @ X) / K
+    H.diagonal().add_(0.05)
+    del X
+    with _ffi.helper_streams(False):
+        U0 = chol_inv_upper(H.clone(), check=False).clone()
+    U1 = chol_inv_upper(H.clone(), check=False).clone()              # pipelined, called from the default stream
+    assert torch.equal(U0, U1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        U2 = chol_inv_upper(H.clone(), check=False).clone()          # pipelined, the caller's own stream carries the chain
+        U3 = chol_inv_upper(H.clone(), check=False).clone()
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(U0, U2) and torch.equal(U0, U3)
+    Hbad = H.clone()
+    Hbad[K // 2, K // 2] = -1.0
+    _, info = chol_inv_upper(Hbad, check=False, return_info=True)
+    assert int(info.item()) != 0
+
+
+@pytest.mark.parametrize('shape', [(512, 4096), (4096, 2048), (192, 5248)])
+def test_pipelined_column_loop_is_bit_identical_to_the_single_stream_schedule(shape):
+    """K4's far updates on the bulk stream (columns of the group after next first) against everything on one stream."""
+    from llmc_amd import _ffi
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper, gptq_quantize
+    R, K = shape
+    gen = torch.Generator(device='cuda').manual_seed(R + K)
+    X = torch.randn(2 * K, K, generator=gen, device='cuda')
+    H = (X.T @ X) / K
+    H.diagonal().add_(0.05)
+    U = chol_inv_upper(H, check=False)
+    W = torch.randn(R, K, generator=gen, device='cuda') * 0.02
+    with _ffi.helper_streams(False):
+        ref = gptq_quantize(W.clone(), U, False, 0.0, 15.0, 128)
+    for _ in range(2):
+        out = gptq_quantize(W.clone(), U, False, 0.0, 15.0, 128)
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = gptq_quantize(W.clone(), U, False, 0.0, 15.0, 128)
+    torch.cuda.current_stream().wait_stream(side)
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
