@@ -85,11 +85,10 @@ inline PipeStreams* pipe_streams_for(hipStream_t main_st) {
     const bool masked = !(e && e[0] == '0');
     if (!pipe_make_stream(&p->fast, masked) || !pipe_make_stream(&p->bulk, masked) || !pipe_make_stream(&p->inv, masked))
         return nullptr;
-    {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) hi = 0;
-        if (hipStreamCreateWithPriority(&p->chain, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
-    }
+    // NORMAL priority: a high-priority chain stream made everything slower (K3 32.1 ms against 21.9 with the chain on the
+    // caller's own normal-priority stream, gpurun_out/r04c/k3_time_q8.txt) — the far updates' waves are evicted for every
+    // small chain kernel
+    if (hipStreamCreateWithFlags(&p->chain, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (int i = 0; i < PipeStreams::NEV; ++i)
         if (hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     p->ok = true;

@@ -472,7 +472,7 @@ def test_owq_column_loop_and_layer_finish_match_reference_golden():
 
 
 @pytest.mark.parametrize('K', [1536, 2432, 4096, 5248, 14336])
-def test_pipelined_factorisation_is_bit_identical_to_the_single_stream_schedule(K):
+def test_pipelined_factorisation_is_bit_identical_to_the_single_stream_schedule(K, monkeypatch):
     """Round 4: llmc_chol_inv_upper runs its chain, the far updates and the triangular inverse on four streams (cholesky.hip,
     chol_inv_upper_pipelined). Same kernels, same tiles, same order of the updates an element receives: the factor must equal
     the single-stream schedule's bit for bit (a missing dependency would show as a difference or as run-to-run noise), from
@@ -484,8 +484,10 @@ def test_pipelined_factorisation_is_bit_identical_to_the_single_stream_schedule(
     H = (X.T @ X) / K
     H.diagonal().add_(0.05)
     del X
+    monkeypatch.delenv('LLMC_K3_PIPE', raising=False)
     with _ffi.helper_streams(False):
         U0 = chol_inv_upper(H.clone(), check=False).clone()
+    monkeypatch.setenv('LLMC_K3_PIPE', '1')
     U1 = chol_inv_upper(H.clone(), check=False).clone()              # pipelined, called from the default stream
     assert torch.equal(U0, U1)
     side = torch.cuda.Stream()
