@@ -140,11 +140,18 @@ int llmc_pack_awq_gemm(const void* weight, int wdt, const void* scales, int sdt,
                        int64_t R, int64_t K, int64_t g, int32_t* qweight, int32_t* qzeros,
                        void* scales_out_f16, llmc_stream_t stream);
 
-/* FloatQuantizer e4m3 weight path with use_qtorch semantics pinned to torch's float8_e4m3fn cast
- * (quant.py:1043-1072, 1195-1221): scale = absmax.clamp(1e-5) / 448 per row of the [G, g] view
- * (G = 1 per-tensor, G = R per-channel), q = RNE_e4m3(x / scale). out_fp8 [G, g] bytes (OCP e4m3fn),
- * scales [G] in dtype sdt: ATen yields fp32 for the 0-dim per-tensor scale (absmax / tensor(448.)) and the
- * tensor dtype for per-channel. fake != 0 writes dequantised q * scale in dt to out instead of fp8 bytes.
+/* FloatQuantizer weight / activation path, e4m3 and e5m2 (quant.py:963-1003, 1043-1072, 1161-1221):
+ * scale = absmax.clamp(1e-5) / finfo(float8 type).max (448 / 57344) per row of the [G, g] view (G = 1 per-tensor, G = R
+ * per-channel / per-token), q = float_quantize(x / scale, e_bits, m_bits, 'nearest'). `fake` is a flag word:
+ *   bit 0      write dequantised q * scale in dt to `out` instead of 8-bit codes
+ *   bits 4-5   format: 0 = e4m3, 1 = e5m2 (quant.py:983-984, 1162-1163)
+ *   bit 8      rounding semantics: 1 = qtorch.quant.float_quantize as llmc calls it (third-party, not vendored by the
+ *              reference: QPyTorch 0.3.0's published CPU algorithm restated in csrc/fp8_math.h and oracle/quant_ref.py —
+ *              IEEE-style formats, ties away from zero, saturation at 240 / 57344); 0 = torch's dtype cast
+ *              (.to(torch.float8_e4m3fn / float8_e5m2): round to nearest even, OCP e4m3fn up to 448), which is what
+ *              the reference's real-quant path ends in (quant.py:1183, 1211) and what its Triton kernels compute.
+ * Codes are OCP e4m3fn / IEEE e5m2 bytes in both cases (every qtorch result is representable). scales [G] in dtype sdt:
+ * ATen yields fp32 for the 0-dim per-tensor scale and the tensor dtype for per-channel.
  * static_scales != 0: `scales` is INPUT (fake_quant_act_static / real_quant_weight_static, quant.py:1083-1099). */
 size_t llmc_fp8_quant_ws_bytes(int64_t G, int64_t g);
 int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int fake, void* out, void* scales, int sdt,
@@ -357,7 +364,8 @@ int llmc_test_gemm3(const float* A, const float* B, float* C, int64_t lda, int64
  * [ceil(M/block), ceil(N/block)]: scale = max(absmax, clamp_min) / 448; q = e4m3fn(W / scale) (fp32 division, RNE).
  * clamp_min = 1e-5: FloatQuantizer (`.clamp(min=1e-5)`, zero scales replaced by 1); clamp_min = 0: the Triton kernel
  * (an all-zero block yields scale 0 and NaN codes, like 0 / 0 there). fake bit 0: out is dt = q * scale, else e4m3
- * bytes; fake bit 1: `scales` is an INPUT (the *_static forms, quant.py:1074-1160). */
+ * bytes; fake bit 1: `scales` is an INPUT (the *_static forms, quant.py:1074-1160); fake bit 8: qtorch.float_quantize
+ * rounding (FloatQuantizer) instead of the e4m3fn cast (the Triton kernels), see llmc_fp8_quant. */
 int llmc_fp8_block_quant(const void* W, int dt, int64_t M, int64_t N, int block, float clamp_min, int fake, void* out,
                          float* scales, llmc_stream_t stream);
 /* weight_cast_to_bf16 (kernel.py:89-143; quant.py:18-30): out[m, n] = float(W8[m, n]) * scales[m/block, n/block] in out_dt. */

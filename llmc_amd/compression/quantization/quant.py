@@ -4,7 +4,7 @@ Mirrors llmc/compression/quantization/quant.py: class names, constructor kwargs,
 argument meaning, return shapes/dtypes (BaseQuantizer :46-658, IntegerQuantizer :661-960,
 FloatQuantizer :963-1229).  In scope: calib_algo 'minmax' (the algorithm of every GPTQ/AWQ/RTN config
 named in BASELINE.json); granularity per_group / per_channel / per_token / per_tensor / per_head;
-FloatQuantizer e4m3 with the qtorch path pinned to torch.float8_e4m3fn's RNE cast.
+FloatQuantizer e4m3 / e5m2 with qtorch.float_quantize restated (fp8_semantics='cast': torch's dtype cast).
 Also in scope: calib_algo 'mse' (get_mse_range, quant.py:145-203).
 Also in scope: calib_algo 'learnable' (get_learnable_range, quant.py:205-224: the range AutoClipper's clip v2 factors scale).
 Out of scope (raise NotImplementedError): hqq range search, W48.
@@ -441,22 +441,40 @@ def pack_lsb(codes, bits):
 
 
 class FloatQuantizer(BaseQuantizer):
-    """FP8 e4m3 (OCP) symmetric quantizer, the `use_qtorch: True` path of the reference's FP8 configs
-    (quant.py:963-1229). qtorch is not vendored by the reference; its e4m3 rounding is pinned here to torch's own
-    float8_e4m3fn cast (RNE), which is also what the reference's real-quant path ends in (quant.py:1183,1211)."""
+    """FP8 symmetric quantizer, e4m3 and e5m2: the `use_qtorch: True` path of the reference's FP8 configs
+    (quant.py:963-1229). The rounding is `qtorch.quant.float_quantize(x, e_bits, m_bits, rounding='nearest')`
+    (quant.py:1066-1068) — a third-party library the reference does not vendor (requirements/runtime.txt:29, no version pin)
+    and this image does not have; its published algorithm (QPyTorch 0.3.0, quant_cpu.cpp / bit_helper.cpp) is restated in
+    csrc/fp8_math.h and oracle/quant_ref.py: IEEE-style (e, m) formats with ties away from zero and saturation, so for
+    e4m3 the largest code is 240 although qmax (finfo(float8_e4m3fn).max = 448) scales the tensor to +-448: every
+    |x / scale| >= 248 lands on 240. `fp8_semantics='cast'` selects torch's own dtype cast instead (round to nearest even,
+    OCP e4m3fn up to 448): what the reference's Triton kernels and its final `.to(torch.float8_e4m3fn)` compute."""
+
+    _FMT = {'e4m3': (0, 4, 3, torch.float8_e4m3fn), 'e5m2': (1, 5, 2, torch.float8_e5m2)}
 
     def __init__(self, bit, symmetric, granularity, **kwargs):
         super().__init__(bit, symmetric, granularity, **kwargs)
         self.sym = True
         self.quant_type = 'float-quant'
-        if self.bit != 'e4m3':
-            raise NotImplementedError(f'FloatQuantizer bit={self.bit}: only e4m3 is on the accelerated path')
+        if self.bit not in self._FMT:
+            raise NotImplementedError(f'FloatQuantizer bit={self.bit}: e4m3 and e5m2 are on the accelerated path '
+                                      '(e3m2 / e4m7 / e2m1 of quant.py:988-990 are not 8-bit storage formats)')
         if self.granularity not in ('per_tensor', 'per_channel', 'per_token', 'per_block'):
             raise NotImplementedError(f'FloatQuantizer granularity={self.granularity}')
-        self.e_bits, self.m_bits = 4, 3
+        self._fmt, self.e_bits, self.m_bits, self._tdtype = self._FMT[self.bit]
+        if self.granularity == 'per_block' and self.bit != 'e4m3':
+            raise NotImplementedError('FloatQuantizer per_block: e4m3 only (the DeepSeek-V3 checkpoint format)')
         self.use_qtorch = self.kwargs.get('use_qtorch', True)
-        self.qmax = torch.tensor(448.0)
-        self.qmin = torch.tensor(-448.0)
+        if not self.use_qtorch:
+            raise NotImplementedError('FloatQuantizer use_qtorch=False (get_float_qparams, quant.py:1005-1041: hard-coded '
+                                      '.cuda(), per-element exponent scales) is outside the hot path')
+        sem = self.kwargs.get('fp8_semantics', 'qtorch')
+        if sem not in ('qtorch', 'cast'):
+            raise ValueError(f"fp8_semantics must be 'qtorch' or 'cast', got {sem!r}")
+        self._mode = (self._fmt << 4) | (0x100 if sem == 'qtorch' else 0)
+        fmax = float(torch.finfo(self._tdtype).max)             # quant.py:985-1003
+        self.qmax = torch.tensor(fmax)
+        self.qmin = torch.tensor(-fmax)
 
     def _run(self, tensor, fake, scales=None):
         _ffi.require_gpu(tensor, scales)
@@ -474,7 +492,7 @@ class FloatQuantizer(BaseQuantizer):
             s = torch.empty(G, dtype=sdtype, device=tensor.device)
         out = torch.empty_like(tensor) if fake else torch.empty(tensor.shape, dtype=torch.uint8, device=tensor.device)
         ws = None if static else _ffi.workspace(L.llmc_fp8_quant_ws_bytes(G, g), tensor.device)
-        _ffi.check(L.llmc_fp8_quant(_ffi.ptr(tensor), _ffi.dt(tensor), G, g, int(fake), _ffi.ptr(out), _ffi.ptr(s),
+        _ffi.check(L.llmc_fp8_quant(_ffi.ptr(tensor), _ffi.dt(tensor), G, g, int(bool(fake)) | self._mode, _ffi.ptr(out), _ffi.ptr(s),
                                     _ffi.dt(sdtype), int(static), _ffi.ptr(ws), _ffi.stream()), 'llmc_fp8_quant')
         return out, s.reshape(self._qparam_shape(tensor))
 
@@ -492,7 +510,7 @@ class FloatQuantizer(BaseQuantizer):
         s = (scales.reshape(mb, nb).to(device=w.device, dtype=torch.float32).contiguous() if static
              else torch.empty((mb, nb), dtype=torch.float32, device=w.device))
         out = torch.empty_like(w) if fake else torch.empty((M, N), dtype=torch.uint8, device=w.device)
-        _ffi.check(L.llmc_fp8_block_quant(_ffi.ptr(w), _ffi.dt(w), M, N, b, 1e-5, int(bool(fake)) | (2 if static else 0),
+        _ffi.check(L.llmc_fp8_block_quant(_ffi.ptr(w), _ffi.dt(w), M, N, b, 1e-5, int(bool(fake)) | (2 if static else 0) | (self._mode & 0x100),
                                           _ffi.ptr(out), _ffi.ptr(s), _ffi.stream()), 'llmc_fp8_block_quant')
         return out, s
 
@@ -532,7 +550,7 @@ class FloatQuantizer(BaseQuantizer):
         return out.reshape(weight.shape)
 
     def _finish(self, bits, scales, shape):
-        weight = bits.view(torch.float8_e4m3fn).reshape(shape)
+        weight = bits.view(self._tdtype).reshape(shape)
         qshape = 1 if self.granularity == 'per_tensor' else (shape[0], -1)
         return weight, scales.reshape(qshape), None
 
@@ -561,9 +579,11 @@ def weight_cast_to_bf16(weight, scale, block_size):
     return _cast(weight.contiguous(), scale.contiguous(), block_size, dtype=torch.bfloat16)
 
 
-def weight_cast_to_fp8(weight, block_size):
-    """quant.py:33-43: FloatQuantizer(e4m3, per_block).real_quant_weight_dynamic -> (fp8 weight, fp32 block scales)."""
-    q = FloatQuantizer(bit='e4m3', symmetric=True, granularity='per_block', block_size=block_size, use_qtorch=True)
+def weight_cast_to_fp8(weight, block_size, fp8_semantics='qtorch'):
+    """quant.py:33-43: FloatQuantizer(e4m3, per_block).real_quant_weight_dynamic -> (fp8 weight, fp32 block scales).
+    (kernel.py's function of the same name is the Triton kernel's arithmetic: the e4m3fn cast, no scale clamp.)"""
+    q = FloatQuantizer(bit='e4m3', symmetric=True, granularity='per_block', block_size=block_size, use_qtorch=True,
+                       fp8_semantics=fp8_semantics)
     w, s, _ = q.real_quant_weight_dynamic(weight)
     return w, s
 

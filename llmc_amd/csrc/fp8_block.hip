@@ -95,16 +95,24 @@ __global__ __launch_bounds__(256) void k_fp8_block_quant128(const T* __restrict_
     for (int j = 0; j < 8; ++j) {
         const int64_t off = (r0 + (tid >> 4) + 16 * j) * N + col;
         uint8_t q[8];
+        float dq[8];
+        if (fake & 0x100) {          // FloatQuantizer: qtorch.float_quantize (fp8_math.h), not the dtype cast
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            const uint32_t c = fb_f32x2_to_e4m3fn(v[j][e] / s + 0.0f, v[j][e + 1] / s + 0.0f);
-            q[e] = (uint8_t)c;
-            q[e + 1] = (uint8_t)(c >> 8);
+            for (int e = 0; e < 8; ++e) q[e] = fp8_encode(v[j][e] / s + 0.0f, 0, 1, &dq[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const uint32_t c = fb_f32x2_to_e4m3fn(v[j][e] / s + 0.0f, v[j][e + 1] / s + 0.0f);
+                q[e] = (uint8_t)c;
+                q[e + 1] = (uint8_t)(c >> 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dq[e] = fb_e4m3fn_to_f32(q[e]);
         }
         if (fake & 1) {
             float y[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = opaque_f32(fb_e4m3fn_to_f32(q[e]) * s);
+            for (int e = 0; e < 8; ++e) y[e] = opaque_f32(dq[e] * s);
             store8<T>((T*)out + off, y);
         } else store8_bytes((uint8_t*)out + off, q);
     }
@@ -142,8 +150,9 @@ __global__ __launch_bounds__(256) void k_fp8_block_quant(const T* __restrict__ W
         const int64_t r = r0 + i / b, c = c0 + i % b;
         if (r < M && c < N) {
             const float x = to_f32<T>(W[r * N + c]);
-            const uint8_t q = fb_f32_to_e4m3fn(x / s + 0.0f);
-            if (fake & 1) ((T*)out)[r * N + c] = from_f32<T>(opaque_f32(fb_e4m3fn_to_f32(q) * s));
+            float dq;
+            const uint8_t q = fp8_encode(x / s + 0.0f, 0, (fake & 0x100) ? 1 : 0, &dq);
+            if (fake & 1) ((T*)out)[r * N + c] = from_f32<T>(opaque_f32(dq * s));
             else ((uint8_t*)out)[r * N + c] = q;
         }
     }

@@ -1,7 +1,8 @@
 // fp8_pack.hip — K11 FP8 (OCP e4m3fn) weight quantization and the AutoAWQ GEMM packer (K7b).
-//   llmc_fp8_quant      FloatQuantizer sym e4m3: scale = absmax.clamp(1e-5)/448, q = RNE_e4m3(x / scale)
-//                       (quant.py:545-553, 1061-1072, 1195-1221). qtorch is not vendored by the reference;
-//                       rounding is pinned to torch.float8_e4m3fn's cast (RNE, no saturation: > 464 -> NaN).
+//   llmc_fp8_quant      FloatQuantizer sym e4m3 / e5m2: scale = absmax.clamp(1e-5) / finfo.max, q = float_quantize(x / scale)
+//                       (quant.py:545-553, 983-1003, 1061-1072, 1195-1221) with qtorch's arithmetic restated (fp8_math.h:
+//                       qtorch_quantize; the library is a third-party dependency absent from the reference tree), or
+//                       torch's own dtype cast (float8_e4m3fn / float8_e5m2, RNE) for the callers that end in one.
 //   llmc_pack_awq_gemm  module_utils.py:1004-1065.
 #include "common.h"
 #include "fp8_math.h"
@@ -13,16 +14,26 @@ static constexpr int FB = 256;
 // amax[row] = clamp(absmax, 1e-5) in dt (from llmc_minmax_qparams with qmax = 1). scale = amax / 448 in the
 // scales' dtype sdt: ATen promotes the 0-dim per-tensor absmax (dt) / 0-dim fp32 qmax to fp32, but keeps dt for
 // the per-channel [R,1] absmax.
+// mode: bit 0 fake (write dequantized values), bits 4-5 format (0 e4m3, 1 e5m2), bit 8 semantics (0 torch's dtype cast,
+// 1 qtorch.float_quantize: fp8_math.h)
+static constexpr int FP8_FAKE = 1, FP8_FMT_SHIFT = 4, FP8_QTORCH = 0x100;
 template <typename T>
-__device__ __forceinline__ void fp8_one(float w, float s, int tdt, int fake, int DT, T* of, uint8_t* ob) {
+__device__ __forceinline__ void fp8_one(float w, float s, int tdt, int mode, int DT, T* of, uint8_t* ob) {
     const float t = rnd(rnd(w / s, tdt) + 0.0f, tdt);          // tensor / scales + zeros
-    const uint8_t q = f32_to_e4m3fn(t);
-    if (fake) *of = from_f32<T>(opaque_f32(e4m3fn_to_f32(q) * s));   // fp32 product, one rounding to dt
+    float v;
+    const uint8_t q = fp8_encode(t, (mode >> FP8_FMT_SHIFT) & 3, mode & FP8_QTORCH, &v);
+    if (mode & FP8_FAKE) *of = from_f32<T>(opaque_f32(v * s));   // fp32 product, one rounding to dt
     else *ob = q;
 }
-// two elements: one hardware conversion (fp8_math.h)
+// two elements: one hardware conversion (fp8_math.h) on the e4m3 cast path
 template <typename T>
-__device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, int fake, T* of, uint8_t* ob) {
+__device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, int mode, T* of, uint8_t* ob) {
+    if (mode & ~FP8_FAKE) {
+        fp8_one<T>(w0, s, tdt, mode, 0, &of[0], &ob[0]);
+        fp8_one<T>(w1, s, tdt, mode, 0, &of[1], &ob[1]);
+        return;
+    }
+    const int fake = mode & FP8_FAKE;
     const float t0 = rnd(rnd(w0 / s, tdt) + 0.0f, tdt), t1 = rnd(rnd(w1 / s, tdt) + 0.0f, tdt);
     const uint32_t c = f32x2_to_e4m3fn(t0, t1);
     const uint8_t q0 = (uint8_t)c, q1 = (uint8_t)(c >> 8);
@@ -38,7 +49,9 @@ __device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, in
 template <typename T>
 __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const T* __restrict__ amax, int sdt,
                                                  void* __restrict__ scales, int static_scales, int64_t G, int64_t g,
-                                                 int fake, void* __restrict__ out) {
+                                                 int mode, void* __restrict__ out) {
+    const int fake = mode & FP8_FAKE;
+    const float fmax = fp8_format_max((mode >> FP8_FMT_SHIFT) & 3);
     constexpr int DT = dt_of<T>::value;
     constexpr int V = 16 / sizeof(T);
     const int pdt = promote(DT, sdt);
@@ -54,7 +67,7 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
             if (static_scales) {
                 s = load_as_f32(scales, row, sdt);
             } else {
-                s = rnd(to_f32<T>(amax[row]) / 448.0f, sdt);
+                s = rnd(to_f32<T>(amax[row]) / fmax, sdt);
                 if (e0 == row * g) store_from_f32(scales, row, sdt, s);
             }
             if (s == 0.0f) s = 1.0f;                              // scales[scales == 0] = 1 (quant.py:1062)
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
             T of[V];
             uint8_t ob[V];
 #pragma unroll
-            for (int k = 0; k < V; k += 2) fp8_two<T>(to_f32<T>(wv[k]), to_f32<T>(wv[k + 1]), s, tdt, fake, &of[k], &ob[k]);
+            for (int k = 0; k < V; k += 2) fp8_two<T>(to_f32<T>(wv[k]), to_f32<T>(wv[k + 1]), s, tdt, mode, &of[k], &ob[k]);
             if (fake) {
                 uint4 o;
                 __builtin_memcpy(&o, of, 16);
@@ -89,13 +102,13 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
         if (static_scales) {
             s = load_as_f32(scales, row, sdt);
         } else {
-            s = rnd(to_f32<T>(amax[row]) / 448.0f, sdt);
+            s = rnd(to_f32<T>(amax[row]) / fmax, sdt);
             if (i == row * g) store_from_f32(scales, row, sdt, s);
         }
         if (s == 0.0f) s = 1.0f;
         T of;
         uint8_t ob;
-        fp8_one<T>(to_f32<T>(W[i]), s, tdt, fake, DT, &of, &ob);
+        fp8_one<T>(to_f32<T>(W[i]), s, tdt, mode, DT, &of, &ob);
         if (fake) ((T*)out)[i] = of; else ((uint8_t*)out)[i] = ob;
     }
 }

@@ -893,19 +893,71 @@ def suite_fp8():
     save('fp8', **out)
 
 
+def _qtorch_stub(x, e, m, rounding='nearest'):
+    """float_quantize bound to the RESTATEMENT of qtorch's published algorithm (oracle/quant_ref.py:qtorch_float_quantize):
+    qtorch itself is a third-party dependency that is neither vendored by the reference nor installed here."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import quant_ref as QR
+    assert rounding == 'nearest'
+    return torch.from_numpy(QR.qtorch_float_quantize(x.detach().float().numpy(), e, m)).reshape(x.shape)
+
+
+def suite_fp8_qtorch():
+    """FloatQuantizer e4m3 AND e5m2 (quant.py:983-984, 1162-1163) with float_quantize = the restated qtorch: the reference's
+    own class code around it (scales from finfo.max, the division in the tensor dtype, `.to(float8 type)` of the quantized
+    values, the fp32 dequantisation product) runs unchanged. Weights are drawn so that a good part of |x / scale| lies above
+    240, where qtorch's e4m3 saturates and the OCP cast of the older goldens (fp8.npz) does not."""
+    import llmc.compression.quantization.quant as qmod
+    qmod.float_quantize = _qtorch_stub
+    out = {}
+    gen = torch.Generator().manual_seed(70)
+    ci = 0
+    for bit in ('e4m3', 'e5m2'):
+        for dt in ('bf16', 'f16'):
+            for gran in ('per_tensor', 'per_channel'):
+                q = qmod.FloatQuantizer(bit, True, gran, use_qtorch=True)
+                w = (torch.randn(24, 160, generator=gen) * 0.05).to(DT[dt])
+                w[3, 5] = 0.0
+                w[4, 6] = -0.0
+                w[5, :8] = w.abs().max() * torch.tensor([1.0, -0.99, 0.75, -0.6, 0.56, -0.5536, 0.53, 0.25]).to(DT[dt])
+                rw, rs, _ = q.real_quant_weight_dynamic(w)
+                fk = q.fake_quant_weight_dynamic(w)
+                p = f'c{ci}_'
+                out[p + 'w'] = f32(w)
+                out[p + 'bits'] = rw.view(torch.uint8).numpy()
+                out[p + 'scales'] = f32(rs).reshape(-1)
+                out[p + 'fake'] = f32(fk)
+                out[p + 'dt'] = np.array(dt)
+                out[p + 'gran'] = np.array(gran)
+                out[p + 'bit'] = np.array(bit)
+                ci += 1
+    out['n'] = np.array(ci)
+    save('fp8_qtorch', **out)
+
+
+def suite_fp8_block_qtorch():
+    """suite_fp8_block with float_quantize = the restated qtorch (see suite_fp8_qtorch): FloatQuantizer e4m3 per_block and
+    the reference's non-Triton weight_cast_to_fp8 / weight_cast_to_bf16 (quant.py:18-43), which go through the same class."""
+    _fp8_block(_qtorch_stub, 'fp8_block_qtorch', 78)
+
+
 def suite_fp8_block():
     """FloatQuantizer e4m3 `per_block` (128 x 128 tiles, DeepSeek-V3 layout) and the reference's non-Triton
-    weight_cast_to_fp8 / weight_cast_to_bf16 (quant.py:18-43). float_quantize is bound to torch's e4m3fn cast as in
-    suite_fp8 (qtorch is not vendored). The Triton kernels (kernel.py) cannot run here: act_quant and fp8_gemm are
-    checked against oracle/quant_ref.py's restatement only (parity unpinned for those two)."""
-    import llmc.compression.quantization.quant as qmod
-
+    weight_cast_to_fp8 / weight_cast_to_bf16 (quant.py:18-43). float_quantize is bound to torch's e4m3fn cast (the
+    arithmetic of the reference's Triton kernels, kernel.py; `fp8_semantics='cast'` here). The Triton kernels cannot run in
+    this container: their goldens come from the MI355X (tools/fp8_triton_golden.py)."""
     def fq(x, e, m, rounding='nearest'):
         assert (e, m) == (4, 3)
         return x.to(torch.float8_e4m3fn).float()
+    _fp8_block(fq, 'fp8_block', 77)
+
+
+def _fp8_block(fq, fname, seed):
+    import llmc.compression.quantization.quant as qmod
     qmod.float_quantize = fq
     out = {}
-    gen = torch.Generator().manual_seed(77)
+    gen = torch.Generator().manual_seed(seed)
     ci = 0
     # N is kept a multiple of the block: the reference's restore_tensor (quant.py:647-651) scrambles a padded N
     for dt, (M, N), bsz in (('bf16', (200, 384), 128), ('f16', (128, 256), 128), ('bf16', (100, 192), 64)):
@@ -931,7 +983,7 @@ def suite_fp8_block():
         out[p + 'block'] = np.array(bsz)
         ci += 1
     out['n'] = np.array(ci)
-    save('fp8_block', **out)
+    save(fname, **out)
 
 
 def suite_e2e():
@@ -1185,7 +1237,7 @@ def suite_mse():
     save('mse', **out)
 
 SUITES = {'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
-          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
+          'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'fp8_qtorch': suite_fp8_qtorch, 'fp8_block_qtorch': suite_fp8_block_qtorch, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(SUITES)

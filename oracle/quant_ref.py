@@ -208,26 +208,126 @@ def e4m3fn_bits_to_f32(b):
     return (sign * v).astype(np.float32)
 
 
-def fp8_quant(w2d, dt):
-    """FloatQuantizer e4m3 sym weight path (quant.py:545-553 with qmax = tensor(448.), :1061-1072, :1211).
-    Per-tensor (one row): absmax is a 0-dim dt tensor, absmax / tensor(448.) promotes to fp32 and x / scale keeps
+# ---- qtorch.quant.float_quantize(x, exp, man, rounding='nearest') ---------------------------------------------------------
+# THIRD-PARTY ARITHMETIC, ABSENT FROM /root/reference: llmc's FloatQuantizer.quant (quant.py:1061-1072) calls
+# `float_quantize(scaled.float(), e_bits, m_bits, rounding='nearest')` of QPyTorch ("qtorch", requirements/runtime.txt:29,
+# NO version pin; the last release is 0.3.0). qtorch is not installed here and there is no network, so its published
+# algorithm is RESTATED below from QPyTorch 0.3.0's CPU kernel (qtorch/quant/quant_cpu/quant_cpu.cpp:float_quantize_nearest,
+# bit_helper.cpp:round_bitwise_nearest / clip_exponent; Python defaults subnormals=True, saturate=True) — parity for this
+# one function is anchored on that restatement, not on a run of qtorch itself:
+#   target_exp = biased exponent of x - 127;  min_exp = -(2^(exp-1) - 2)
+#   x in the target's subnormal range (target_exp < min_exp):   shift = sign(x) * 2^min_exp;  q = rnd(x + shift) - shift
+#   otherwise:                                                  q = rnd(x), then clip_exponent
+#   rnd(v): (bits(v) + (1 << (22 - man))) & ~((1 << (23 - man)) - 1)     -> round to nearest, TIES AWAY FROM ZERO
+#   clip_exponent: max exponent = 2^(exp-1) - 1 (the top exponent code is kept for infinity, IEEE style); a value that
+#                  rounds beyond it SATURATES to +-(2 - 2^-man) * 2^max_exp.
+# For (exp, man) = (4, 3) this is an IEEE-style e4m3 whose largest value is 240 — NOT the OCP e4m3fn of
+# torch.float8_e4m3fn (largest 448, round to nearest EVEN, overflow -> NaN) that llmc takes its qmax = 448 from
+# (quant.py:985-1003). The two differ (tests/test_oracle_golden.py::test_qtorch_vs_torch_cast_where_they_differ):
+#   * every |x / s| >= 248 (the binades [256, 448] and the rounding interval below them): qtorch returns +-240, the cast
+#     returns the nearest of 256, 288, ..., 448;   * exact ties: away from zero vs to even;   * |x / s| > 464: 240 vs NaN.
+# For (5, 2) the grids coincide (largest value 57344 either way); only ties and the overflow value differ.
+def qtorch_float_quantize(x, exp, man):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    bits = x.view(np.uint32)
+    sign = bits & np.uint32(0x80000000)
+    t_exp = ((bits & np.uint32(0x7fffffff)) >> np.uint32(23)).astype(np.int64) - 127
+    min_exp = -((1 << (exp - 1)) - 2)
+    max_store = (1 << (exp - 1)) - 1 + 127
+    mask = np.uint32((1 << (23 - man)) - 1)
+    half = np.uint32(1 << (23 - man - 1))
+
+    def rnd_bits(b):
+        return (b + half) & ~mask
+
+    # normal range
+    q = rnd_bits(bits)
+    qe = ((q & np.uint32(0x7fffffff)) >> np.uint32(23)).astype(np.int64)
+    max_man = np.uint32(((1 << man) - 1) << (23 - man))
+    sat = sign | np.uint32(max_store << 23) | max_man
+    q = np.where((q != 0) & (qe > max_store), sat, q).astype(np.uint32)
+    normal = q.view(np.float32)
+    # subnormal range of the target format
+    shift_bits = (np.uint32((127 + min_exp) << 23) | sign).astype(np.uint32)
+    shift = shift_bits.view(np.float32)
+    with np.errstate(over='ignore', invalid='ignore'):
+        val = (x + shift).astype(np.float32)
+        sub = (rnd_bits(val.view(np.uint32)).astype(np.uint32).view(np.float32) - shift).astype(np.float32)
+    return np.where(t_exp < min_exp, sub, normal).astype(np.float32)
+
+
+def f32_to_e5m2_bits(a):
+    """torch's .to(torch.float8_e5m2): IEEE-style binary8 (5, 2), round to nearest even, overflow -> inf (0x7c), NaN 0x7f."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = a.view(np.uint32)
+    sign = ((b >> np.uint32(24)) & np.uint32(0x80)).astype(np.uint8)
+    x = np.abs(a).astype(np.float64)
+    nan = np.isnan(a)
+    e = np.floor(np.log2(np.where(x > 0, x, 1.0)))
+    e = np.clip(e, -14, 15)
+    step = np.exp2(e - 2)
+    q = np.rint(x / step) * step
+    e2 = np.clip(np.floor(np.log2(np.where(q > 0, q, 1.0))), -14, 15)
+    is_sub = q < 2.0 ** -14
+    exp_field = np.where(is_sub, 0, e2 + 15).astype(np.int64)
+    man_field = np.where(is_sub, np.rint(q / 2.0 ** -16), np.rint((q / np.exp2(e2) - 1.0) * 4)).astype(np.int64)
+    bits = (exp_field << 2) | man_field
+    bits = np.where(q > 57344.0, 0x7c, bits)
+    bits = np.where(np.isinf(a), 0x7c, bits)
+    bits = np.where(nan, 0x7f, bits)
+    return bits.astype(np.uint8) | sign
+
+
+def e5m2_bits_to_f32(b):
+    b = np.asarray(b, dtype=np.uint8)
+    return (b.astype(np.uint16) << np.uint16(8)).view(np.float16).astype(np.float32)
+
+
+FP8_FORMATS = {'e4m3': (4, 3, 448.0), 'e5m2': (5, 2, 57344.0)}
+
+
+def fp8_encode(t, fmt='e4m3', sem='cast'):
+    """(codes uint8, decoded values fp32) of the scaled tensor t. sem 'cast': torch's dtype cast (float8_e4m3fn /
+    float8_e5m2, RNE) — make_golden's stand-in of rounds 1-3 and the arithmetic of the reference's Triton kernels;
+    sem 'qtorch': qtorch.float_quantize as FloatQuantizer.quant calls it (restated above), followed by the exact cast."""
+    e, m, _ = FP8_FORMATS[fmt]
+    to_bits, from_bits = (f32_to_e4m3fn_bits, e4m3fn_bits_to_f32) if fmt == 'e4m3' else (f32_to_e5m2_bits, e5m2_bits_to_f32)
+    if sem == 'qtorch':
+        v = qtorch_float_quantize(t, e, m)
+        return to_bits(v), v
+    b = to_bits(t)
+    return b, from_bits(b)
+
+
+def fp8_quant(w2d, dt, fmt='e4m3', sem='cast'):
+    """FloatQuantizer sym weight path (quant.py:545-553 with qmax = tensor(finfo.max), :1061-1072, :1211).
+    Per-tensor (one row): absmax is a 0-dim dt tensor, absmax / tensor(qmax) promotes to fp32 and x / scale keeps
     the tensor dtype with an fp32 scalar. Per-channel: everything stays in dt.
     Returns (bits uint8 [G,g], scales [G,1] fp32 container, scale dtype)."""
+    fmax = np.float32(FP8_FORMATS[fmt][2])
     mx = w2d.max(axis=-1, keepdims=True)
     mn = w2d.min(axis=-1, keepdims=True)
     a = np.maximum(np.maximum(np.abs(mx), np.abs(mn)), rnd(np.float32(1e-5), dt))
     sdt = F32 if w2d.shape[0] == 1 else dt
     with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
-        s = rnd(a / np.float32(448.0), sdt)
+        s = rnd(a / fmax, sdt)
         t = rnd(rnd(w2d / s, dt) + np.float32(0.0), dt)   # tensor / scales + zeros (0.0): -0 becomes +0
-    bits = f32_to_e4m3fn_bits(t)              # float_quantize(.float(), 4, 3) then .to(float8_e4m3fn)
+    bits, _ = fp8_encode(t, fmt, sem)           # float_quantize(.float(), e, m) then .to(float8 type)
     return bits, s, sdt
 
 
-def fp8_fake(w2d, dt):
+def fp8_fake(w2d, dt, fmt='e4m3', sem='cast'):
     """fake_quant_weight_dynamic: (q - 0) * s is an fp32 product, then .to(dt)  (quant.py:1074-1080, 1165-1176)."""
-    bits, s, _ = fp8_quant(w2d, dt)
-    return rnd(e4m3fn_bits_to_f32(bits) * s, dt)
+    fmax = np.float32(FP8_FORMATS[fmt][2])
+    mx = w2d.max(axis=-1, keepdims=True)
+    mn = w2d.min(axis=-1, keepdims=True)
+    a = np.maximum(np.maximum(np.abs(mx), np.abs(mn)), rnd(np.float32(1e-5), dt))
+    sdt = F32 if w2d.shape[0] == 1 else dt
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        s = rnd(a / fmax, sdt)
+        t = rnd(rnd(w2d / s, dt) + np.float32(0.0), dt)
+    _, v = fp8_encode(t, fmt, sem)
+    return rnd(v * s, dt)
 
 
 def mse_range(x, sym, qmin, qmax, round_zp=True, maxshrink=0.8, grid=100, norm=2.4):
@@ -314,7 +414,7 @@ def per_tensor_asym_fake_and_codes(w, dt, qmin, qmax):
 
 # ---- FP8 e4m3 per_block (quant.py:132-143, 612-658, 1043-1072): b x b tiles, fp32 scale = max(absmax, 1e-5) / 448,
 # q = e4m3(x / scale) in fp32 (the dimensioned fp32 scale promotes the 16-bit tensor), fake = q * scale rounded once.
-def fp8_per_block(w, dt, block):
+def fp8_per_block(w, dt, block, sem='cast'):
     w = np.asarray(w, dtype=np.float32)
     M, N = w.shape
     mb, nb = -(-M // block), -(-N // block)
@@ -328,7 +428,7 @@ def fp8_per_block(w, dt, block):
             s = np.float32(max(np.abs(blk).max(), np.float32(1e-5))) / np.float32(448.0)
             scales[i, j] = s
             y = (blk / s + np.float32(0.0)).astype(np.float32)
-            b = f32_to_e4m3fn_bits(y)
+            b, v = fp8_encode(y, 'e4m3', sem)
             bits[sl] = b
-            fake[sl] = rnd((e4m3fn_bits_to_f32(b) * s).astype(np.float32), dt)
+            fake[sl] = rnd((v * s).astype(np.float32), dt)
     return bits, scales, fake

@@ -210,30 +210,41 @@ def test_auto_clip_layer_with_several_batches_matches_reference_golden():
         assert (host(mn) == g[p + 'best_min']).mean() == 1.0, name
 
 
-def test_fp8_vs_reference_golden():
+@pytest.mark.parametrize('golden,sem', [('fp8_qtorch', 'qtorch'), ('fp8', 'cast')])
+def test_fp8_vs_reference_golden(golden, sem):
+    """FloatQuantizer e4m3 / e5m2 against the reference's class code: fp8_qtorch.npz = float_quantize bound to the restated
+    qtorch (the default semantics: ties away from zero, saturation at 240 / 57344), fp8.npz = bound to torch's dtype cast
+    (fp8_semantics='cast': what the reference's Triton kernels and its final .to(float8) compute)."""
     from llmc_amd.compression.quantization import FloatQuantizer
-    g = load_golden('fp8')
+    g = load_golden(golden)
+    seen = set()
     for ci in range(int(g['n'])):
         p = f'c{ci}_'
         dt, gran = str(g[p + 'dt']), str(g[p + 'gran'])
-        q = FloatQuantizer('e4m3', True, gran, use_qtorch=True)
+        bit = str(g[p + 'bit']) if p + 'bit' in g.files else 'e4m3'
+        seen.add(bit)
+        q = FloatQuantizer(bit, True, gran, use_qtorch=True, fp8_semantics=sem)
         w = dev(g[p + 'w'], dt)
         rw, rs, rz = q.real_quant_weight_dynamic(w)
-        assert rw.dtype == torch.float8_e4m3fn and rz is None
-        np.testing.assert_array_equal(rw.view(torch.uint8).cpu().numpy(), g[p + 'bits'])
+        assert rw.dtype == (torch.float8_e4m3fn if bit == 'e4m3' else torch.float8_e5m2) and rz is None
+        np.testing.assert_array_equal(rw.view(torch.uint8).cpu().numpy(), g[p + 'bits'], err_msg=f'{golden} {ci}')
         np.testing.assert_array_equal(bits(host(rs).reshape(-1)), bits(g[p + 'scales']))
         fk = q.fake_quant_weight_dynamic(w)
-        np.testing.assert_array_equal(bits(host(fk)), bits(g[p + 'fake']))
+        np.testing.assert_array_equal(bits(host(fk)), bits(g[p + 'fake']), err_msg=f'{golden} {ci}')
         # static path with the same scales reproduces the dynamic result
         fs = q.fake_quant_weight_static(w, {'scales': rs})
         assert torch.equal(fs, fk)
+        if sem == 'qtorch' and bit == 'e4m3' and gran == 'per_tensor':   # the saturation the restated qtorch implies
+            assert float(fk.float().abs().max()) <= 240.0 * float(rs.float().reshape(())) * (1 + 2.0 ** -7)
+            assert float(fk.float().abs().max()) < 0.6 * float(w.float().abs().max())
+    assert seen == ({'e4m3', 'e5m2'} if golden == 'fp8_qtorch' else {'e4m3'})
 
 
 def test_fp8_mixtral_expert_shape_vs_torch_cast():
     from llmc_amd.compression.quantization import FloatQuantizer
     gen = torch.Generator().manual_seed(3)
     w = (torch.randn(14336, 4096, generator=gen) * 0.03).to(torch.bfloat16).cuda()
-    q = FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True)
+    q = FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True, fp8_semantics='cast')
     rw, rs, _ = q.real_quant_weight_dynamic(w)
     s = w.abs().max().float().clamp(min=float(torch.tensor(1e-5, dtype=torch.bfloat16))) / 448.0
     assert rs.dtype == torch.float32 and torch.equal(rs.reshape(()), s)

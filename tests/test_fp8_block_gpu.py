@@ -14,15 +14,18 @@ pytestmark = pytest.mark.gpu
 TD = {'f16': torch.float16, 'bf16': torch.bfloat16}
 
 
-def test_per_block_quantizer_and_weight_casts_match_reference_golden():
+@pytest.mark.parametrize('golden,sem', [('fp8_block_qtorch', 'qtorch'), ('fp8_block', 'cast')])
+def test_per_block_quantizer_and_weight_casts_match_reference_golden(golden, sem):
+    """fp8_block_qtorch.npz: the reference's class with float_quantize = the restated qtorch (FloatQuantizer's default here);
+    fp8_block.npz: bound to torch's e4m3fn cast (fp8_semantics='cast', the Triton kernels' arithmetic)."""
     from llmc_amd.compression.quantization import FloatQuantizer
     from llmc_amd.compression.quantization.quant import weight_cast_to_bf16, weight_cast_to_fp8
-    g = load_golden('fp8_block')
+    g = load_golden(golden)
     for ci in range(int(g['n'])):
         p = f'c{ci}_'
         dt, b = TD[str(g[p + 'dt'])], int(g[p + 'block'])
         w = torch.from_numpy(g[p + 'w']).to(dt).cuda()
-        q = FloatQuantizer('e4m3', True, 'per_block', block_size=b, use_qtorch=True)
+        q = FloatQuantizer('e4m3', True, 'per_block', block_size=b, use_qtorch=True, fp8_semantics=sem)
         rw, rs, rz = q.real_quant_weight_dynamic(w)
         assert rw.dtype == torch.float8_e4m3fn and rz is None and rs.dtype == torch.float32
         assert tuple(rs.shape) == g[p + 'scales'].shape
@@ -36,7 +39,7 @@ def test_per_block_quantizer_and_weight_casts_match_reference_golden():
         # static forms with the scales just found reproduce the dynamic results
         assert torch.equal(q.fake_quant_weight_static(w, {'scales': s4}), fk)
         assert torch.equal(q.real_quant_weight_static(w, {'scales': s4})[0].view(torch.uint8), rw.view(torch.uint8))
-        w8, s8 = weight_cast_to_fp8(w, b)
+        w8, s8 = weight_cast_to_fp8(w, b, fp8_semantics=sem)
         np.testing.assert_array_equal(w8.view(torch.uint8).cpu().numpy(), g[p + 'cast_bits'])
         np.testing.assert_array_equal(s8.cpu().numpy().view(np.uint32), g[p + 'cast_scales'].view(np.uint32))
         back = weight_cast_to_bf16(w8, s8, b)

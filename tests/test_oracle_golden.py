@@ -241,6 +241,78 @@ def test_fp8_e4m3_bit_exact_vs_torch_cast_path():
         np.testing.assert_array_equal(fake.view(np.uint32), g[p + 'fake'].view(np.uint32))
 
 
+def test_fp8_qtorch_semantics_e4m3_and_e5m2_bit_exact():
+    """fp8_qtorch.npz: llmc's FloatQuantizer with float_quantize bound to the restated qtorch algorithm. The oracle's
+    restatement of everything AROUND that call (scales from finfo.max, division and +0 in the tensor dtype, the exact cast of
+    the quantized values, the fp32 dequantisation product) must reproduce the reference class bit for bit, for both formats."""
+    g = load_golden('fp8_qtorch')
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        dt, gran, bit = str(g[p + 'dt']), str(g[p + 'gran']), str(g[p + 'bit'])
+        w = g[p + 'w']
+        w2 = w.reshape(1, -1) if gran == 'per_tensor' else w
+        b, s, sdt = Q.fp8_quant(w2, dt, bit, 'qtorch')
+        np.testing.assert_array_equal(s.reshape(-1).view(np.uint32), g[p + 'scales'].view(np.uint32))
+        np.testing.assert_array_equal(b.reshape(w.shape), g[p + 'bits'], err_msg=str(ci))
+        fake = Q.fp8_fake(w2, dt, bit, 'qtorch').reshape(w.shape)
+        np.testing.assert_array_equal(fake.view(np.uint32), g[p + 'fake'].view(np.uint32), err_msg=str(ci))
+    g = load_golden('fp8_block_qtorch')
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        bits, scales, fake = Q.fp8_per_block(g[p + 'w'], str(g[p + 'dt']), int(g[p + 'block']), 'qtorch')
+        np.testing.assert_array_equal(scales.view(np.uint32), g[p + 'scales'].view(np.uint32), err_msg=str(ci))
+        np.testing.assert_array_equal(bits, g[p + 'bits'], err_msg=str(ci))
+        np.testing.assert_array_equal(fake.view(np.uint32), g[p + 'fake'].view(np.uint32), err_msg=str(ci))
+
+
+def _fp8_boundary_patterns(man, lo_exp, hi_exp):
+    """every fp32 whose leading bits select a grid point, a midpoint or a quarter point of an (e, man) grid, +-2 ulp, both signs"""
+    vals = []
+    for e in range(lo_exp, hi_exp + 1):
+        for m in range(0, 1 << (man + 2)):
+            base = ((e + 127) << 23) | (m << (23 - man - 2))
+            vals.extend(base + d for d in (-2, -1, 0, 1, 2))
+    v = np.array(vals, dtype=np.uint32)
+    x = np.concatenate([v, v | np.uint32(0x80000000)]).view(np.float32)
+    return x[np.isfinite(x)]
+
+
+def test_qtorch_vs_torch_cast_where_they_differ():
+    """The restated qtorch.float_quantize(x, 4, 3) / (x, 5, 2) against torch's float8 casts over every boundary pattern of
+    the grids: they agree everywhere EXCEPT (a) exact ties (away from zero vs to even), (b) e4m3 from
+    |x| >= 248 on — qtorch's IEEE-style e4m3 ends at 240 and saturates, the OCP e4m3fn of llmc's qmax goes on to 448 and
+    turns NaN above 464 —, (c) e5m2 above 61440 (57344 vs inf), (d) inputs one or two ulp below a midpoint of the SUBNORMAL
+    grid, where qtorch's `x + 2^min_exp` addition rounds first (a double rounding). Also pins the oracle's own bit-level
+    casts to torch's."""
+    import torch
+    x = np.concatenate([_fp8_boundary_patterns(3, -12, 9), np.array([0.0, -0.0], np.float32)])
+    qt = Q.qtorch_float_quantize(x, 4, 3)
+    tc = torch.from_numpy(x).to(torch.float8_e4m3fn).float().numpy()
+    mine = Q.e4m3fn_bits_to_f32(Q.f32_to_e4m3fn_bits(x))
+    assert np.array_equal(np.nan_to_num(mine, nan=-1.0), np.nan_to_num(tc, nan=-1.0))       # oracle cast == torch cast
+    ax = np.abs(x)
+    same = (qt == tc) | (np.isnan(qt) & np.isnan(tc))
+    tie = (ax.view(np.uint32) & np.uint32((1 << 20) - 1)) == np.uint32(1 << 19)
+    normal = (ax >= 2.0 ** -6) & (ax < 248.0)
+    assert same[normal & ~tie].all()                       # off the ties the two roundings agree on the common range
+    assert (~same[normal & tie]).sum() > 0 and (np.abs(qt[normal & tie]) >= np.abs(tc[normal & tie])).all()   # away from zero
+    assert (~same[ax >= 248.0]).all() and (np.abs(qt[ax >= 248.0]) == 240.0).all()           # saturation at 240
+    sub = ax < 2.0 ** -6
+    assert (np.abs(qt[sub] - tc[sub]) <= 2.0 ** -9 + 1e-12).all() and same[sub].mean() > 0.97  # same grid, a neighbour at most
+    assert np.array_equal(Q.qtorch_float_quantize(np.float32([448.0, -448.0, 240.0, 247.9, 248.0]), 4, 3),
+                          np.float32([240.0, -240.0, 240.0, 240.0, 240.0]))
+    x5 = _fp8_boundary_patterns(2, -18, 16)
+    q5 = Q.qtorch_float_quantize(x5, 5, 2)
+    t5 = torch.from_numpy(x5).to(torch.float8_e5m2).float().numpy()
+    m5 = Q.e5m2_bits_to_f32(Q.f32_to_e5m2_bits(x5))
+    assert np.array_equal(np.nan_to_num(m5, nan=-1.0, posinf=1e30, neginf=-1e30), np.nan_to_num(t5, nan=-1.0, posinf=1e30, neginf=-1e30))
+    a5 = np.abs(x5)
+    same5 = (q5 == t5)
+    tie5 = (a5.view(np.uint32) & np.uint32((1 << 21) - 1)) == np.uint32(1 << 20)
+    n5 = (a5 >= 2.0 ** -14) & (a5 < 61440.0)
+    assert same5[n5 & ~tie5].all() and (np.abs(q5[a5 >= 61440.0]) == 57344.0).all()
+
+
 def test_auto_clip_matches_reference():
     """auto_clip_layer restated with the reference's roundings chooses the reference's clip level for EVERY (row, group)
     of the goldens: one batch (clip.npz) and the list form (clip_mb.npz, error averaged over the batches)."""
