@@ -13,7 +13,6 @@
 #include "common.h"
 #include "sgemm.h"
 #include "side_stream.h"
-#include "pipe_streams.h"
 
 namespace llmc {
 
@@ -582,33 +581,16 @@ static size_t gemm6_bytes(int64_t K) {
     return align256(mx);
 }
 
-// the top level of the triangular inverse: the one pair [0, h_top) | [h_top, K) with h_top the largest NB * 2^n below K
-static inline int64_t top_level_h(int64_t K) {
-    int64_t h = NB;
-    while (2 * h < K) h *= 2;
-    return h;
-}
-static size_t top_x_bytes(int64_t K) {
-    const int64_t h = top_level_h(K), n2 = K - h;
-    return K > 1024 ? align256((size_t)h * (size_t)((n2 + 3) / 4 * 4) * 4) : 0;
-}
-static size_t top_g6_bytes(int64_t K) {
-    const int64_t h = top_level_h(K), n2 = K - h;
-    if (K <= 1024 || h < GEMM6_MIN_H || h % 256 || n2 % 256) return 0;
-    const size_t a = gemm6_ws_bytes((int)h, (int)n2, (int)h), b = gemm6_ws_bytes((int)h, (int)n2, (int)n2);
-    return align256(a > b ? a : b);
-}
+static constexpr int NBO_ = 4 * NB;     // outer block of the factorisation
+static size_t panel_bytes(int64_t K) { return align256((size_t)NBO_ * (size_t)((K + 3) / 4 * 4) * 4); }
 
 extern "C" size_t llmc_chol_inv_upper_ws_bytes(int64_t K) {
     if (K <= 0) return 0;
     size_t work = align256((size_t)K * K * 4);
     size_t vbuf = align256((size_t)ceil_div64(K, NB) * NB * NB * 4);
     size_t xbuf = align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
-    // pipelined schedule: the top inverse level's X = A^-1 C runs beside the factorisation's last blocks with buffers of its own
-    return work + vbuf + xbuf + gemm6_bytes(K) + top_x_bytes(K) + top_g6_bytes(K);
+    return work + vbuf + xbuf + gemm6_bytes(K) + panel_bytes(K);     // + the far panel of one outer block (round 4)
 }
-
-static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev, hipStream_t st, PipeStreams* ps);
 
 extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
     LLMC_REQUIRE(A && ws && info_dev && K64 > 0, "chol_inv_upper: null/empty argument");
@@ -616,19 +598,6 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     LLMC_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)ws & 255) == 0, "chol_inv_upper: alignment");
     hipStream_t st = (hipStream_t)stream;
     const int K = (int)K64;
-    // Round 4: a pipelined schedule (three helper streams, the inverse behind the factorisation). Same kernels, same tiles,
-    // same order of the updates an element receives: bit-identical to the schedule below (tests/test_gptq_gpu.py).
-    {
-        // Measured (gpurun_out/r04c): from a caller's own stream the pipelined schedule takes 21.9 ms at K = 14336, exactly
-        // what the single-stream schedule takes: the "latency-bound" steps are wide, inefficient kernels that already fill
-        // the CUs, so overlapping them with the far updates only moves the same work around. It stays available for A/B
-        // runs (LLMC_K3_PIPE=1) and is pinned bit-identical by tests; the default is the round-3 schedule.
-        const char* e = getenv("LLMC_K3_PIPE");
-        const bool want = (e && e[0] == '1') && !getenv("LLMC_NO_SIDE_STREAM") && helper_streams_enabled() &&
-                          !getenv("LLMC_K3_FP32") && K > 1024;
-        if (want)
-            if (PipeStreams* ps = pipe_streams_for(st)) return chol_inv_upper_pipelined(A, K, ws, info_dev, st, ps);
-    }
     float* Wk = (float*)ws;
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
@@ -641,26 +610,24 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
     LLMC_LAUNCH_CHECK();
 
-    const int nblk = (K + NB - 1) / NB;
+    float* Pbuf = (float*)((char*)G6buf + gemm6_bytes(K));
     // ---- blocked upper Cholesky Wk = U'^T U', two-level: 128-wide factor steps inside 512-wide outer blocks.
-    // Inside an outer block every step updates only the rows of that block (Kd = 128, few rows); the rows
-    // beyond it receive ONE symmetric update with Kd = 512 per outer block, which is where the flops are and
-    // runs the fp32-MFMA GEMM at its long-K efficiency instead of its short-K one (tools/bench_sgemm.py).
-    const int NBO = 4 * NB;
+    // Inside an outer block every step touches only the block's OWN 512 columns (potrf, a 128 x <= 384 panel solve, a
+    // <= 384 x <= 384 update). The rows beyond the block receive ONE symmetric update with Kd = 512 per outer block, which
+    // is where the flops are.
+    // Round 4, the far panel LEFT-LOOKING: the factor rows of the block right of its diagonal, P = U'_bb^-T A[b, far], are
+    // ONE product with the inverse of the block's 512 x 512 factor instead of four panel solves and four in-block updates
+    // over all far columns (eight wide, short-K launches per block at 32-50 TFLOP/s: 10 ms of kernel time per benchmark
+    // step, profiles/r03_kernel_stats.txt). That inverse is the first two doubling levels of the triangular inverse on the
+    // block's diagonal — work the inverse phase did anyway, now done when the block is finished. The product is not done
+    // in place (every output row needs every input row of its column): it goes to a panel buffer and is copied back.
+    const int NBO = NBO_;
     SideStream* side = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : side_stream_for(st);
     bool pending_side = false;
-    // The large products of K3 (far updates, triangular-inverse levels >= 512) run as split-bf16 products on the 16-bit
-    // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
+    // The large products of K3 (far panels, far updates, triangular-inverse levels >= 512) run as split-bf16 products on the
+    // 16-bit MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
     // the fp32 MFMA path.
     const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
-    const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
-    // Inside an outer block the columns split into NEAR (the block's own, which the next factor step needs) and FAR (all
-    // the columns to its right, needed by the later far panel solves and by the block's far update). The near panel solve
-    // and near update stay on the caller's stream between the diagonal factorisations — three small latency-bound
-    // kernels per step; the far panel solve and far in-block update of the same step (128 x nfar products: the bulk of a
-    // step's work) run on the helper stream behind an event, concurrently with the next steps' chain. Same kernels, same
-    // arithmetic per element and the same order of the updates an element receives (all of step c before step c + 1 on
-    // either stream), so the factor is bit-identical with or without the helper stream.
     auto panel_solve = [&](const float* Vb, int c0, int nb, int col0, int ncols, hipStream_t s_) -> int {
         if (ncols <= 0) return LLMC_OK;
         float* P = Wk + (size_t)c0 * K + col0;     // rows c0..c0+nb, cols col0..col0+ncols
@@ -683,232 +650,10 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         u.epilogue = SG_SUB; u.c_upper_only = col0 == c0 + nb ? 1 : 0; u.batch = 1;   // the far columns lie right of every row
         return sgemm_launch(u, true, false, s_);
     };
-    for (int k0 = 0; k0 < K; k0 += NBO) {
-        const int nbo = K - k0 < NBO ? K - k0 : NBO;
-        const int oend = k0 + nbo;
-        const int nfar = K - oend;
-        for (int c0 = k0; c0 < oend; c0 += NB) {
-            const int b = c0 / NB;
-            const int nb = K - c0 < NB ? K - c0 : NB;
-            float* Vb = Vbuf + (size_t)b * NB * NB;
-            hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (NB * PLD + 32 * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
-                               nb, Vb, info_dev);
-            LLMC_LAUNCH_CHECK();
-            if (K - c0 - nb <= 0) break;
-            const int nnear = oend - (c0 + nb);
-            if (!side || nfar <= 0) {
-                // one stream: near and far columns in ONE panel solve and ONE update per step (the split costs two more
-                // launches per step, 1.3 ms over a K = 14336 factorisation, and buys nothing without a second stream)
-                int rc = panel_solve(Vb, c0, nb, c0 + nb, K - c0 - nb, st);
-                if (rc) return rc;
-                rc = inblock_update(c0, nb, oend, c0 + nb, K - c0 - nb, st);
-                if (rc) return rc;
-                continue;
-            }
-            int rc = panel_solve(Vb, c0, nb, c0 + nb, nnear, st);
-            if (rc) return rc;
-            rc = fork_to_side(side, st);      // the far part of this step: behind the near panel, beside the rest of the chain
-            if (rc) return rc;
-            pending_side = true;
-            rc = panel_solve(Vb, c0, nb, oend, nfar, side->side);
-            if (rc) return rc;
-            rc = inblock_update(c0, nb, oend, oend, nfar, side->side);
-            if (rc) return rc;
-            rc = inblock_update(c0, nb, oend, c0 + nb, nnear, st);
-            if (rc) return rc;
-        }
-        if (nfar > 0) {
-            // far trailing update T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo), in two parts: the rows
-            // of the NEXT outer block on the main stream (its factor steps need them), the rows below on the side
-            // stream, overlapped with the next outer block's latency-bound diagonal / panel kernels.
-            float* P = Wk + (size_t)k0 * K + oend;
-            const int m1 = nfar < NBO ? nfar : NBO;
-            if (side && pending_side) {          // the block's far panels (and the previous block's side update) are complete
-                int rc = join_from_side(side, st);
-                if (rc) return rc;
-                pending_side = false;
-            }
-            SgemmArgs u{};
-            u.A = P; u.lda = K; u.B = P; u.ldb = K;
-            u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
-            u.M = u.M_last = m1; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
-            u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
-            int rc = use_x3u ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
-            if (rc) return rc;
-            const int m2 = nfar - m1;
-            if (m2 > 0) {
-                SgemmArgs v{};
-                v.A = P + m1; v.lda = K; v.B = P + m1; v.ldb = K;
-                v.C = Wk + (size_t)(oend + m1) * K + oend + m1; v.ldc = K;
-                v.M = v.M_last = m2; v.N = v.N_last = m2; v.Kd = v.Kd_last = nbo;
-                v.epilogue = SG_SUB; v.c_upper_only = 1; v.batch = 1;
-                if (side) {
-                    rc = fork_to_side(side, st);   // P is final on main at this point
-                    if (rc) return rc;
-                    rc = use_x3 ? gemm3_tn_launch(v, side->side) : sgemm_launch(v, true, false, side->side);
-                    if (rc) return rc;
-                    pending_side = true;
-                } else {
-                    rc = use_x3 ? gemm3_tn_launch(v, st) : sgemm_launch(v, true, false, st);
-                    if (rc) return rc;
-                }
-            }
-        }
-    }
-    if (side && pending_side) {
-        int rc = join_from_side(side, st);
-        if (rc) return rc;
-    }
-    (void)nblk;
-    // ---- V = U'^-1: inverted diagonal blocks, then doubling levels
-    hipLaunchKernelGGL(k_place_diag_inv, dim3((K + NB - 1) / NB), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf, 0);
-    LLMC_LAUNCH_CHECK();
-    if (use_x3t && use_g6 && K > GEMM6_MIN_H) {
-        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
-        LLMC_LAUNCH_CHECK();
-    }
-    for (int64_t h = NB; h < K; h *= 2) {
-        const int npairs = (int)((K - h + 2 * h - 1) / (2 * h));  // pairs with a non-empty right block
-        if (npairs <= 0) break;
-        const int64_t o_last = (int64_t)(npairs - 1) * 2 * h;
-        const int n2_last = (int)((K - o_last - h) < h ? (K - o_last - h) : h);
-        const int64_t stride = 2 * h * ((int64_t)K + 1);
-        // X = A^-1 C
-        SgemmArgs x{};
-        x.A = Wk; x.lda = K; x.sA = stride;                 // A^-1 at (o, o), upper
-        x.B = Wk + h; x.ldb = K; x.sB = stride;             // C at (o, o+h)
-        // X is [h x n2]: with one pair its leading dimension shrinks to n2 (keeps X within K^2/4 floats)
-        const int64_t ldX = npairs == 1 ? ((n2_last + 3) / 4) * 4 : h;
-        x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
-        x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2_last; x.Kd = x.Kd_last = (int)h;
-        x.epilogue = SG_SET; x.a_upper = 1; x.batch = npairs;
-        const bool lvl_x3 = use_x3t && h >= 512;   // small levels are latency-bound: the fp32 kernels stay
-        // large, deep levels: operands split once into stacked bf16 planes, product on the one-wave-per-SIMD GEMM
-        const bool lvl_g6 = lvl_x3 && use_g6 && h >= GEMM6_MIN_H && h % 256 == 0 && n2_last % 256 == 0;
-        int rc = LLMC_OK;
-        if (lvl_g6) {
-            for (int z = 0; z < npairs && !rc; ++z) {
-                const int n2 = z == npairs - 1 ? n2_last : (int)h;
-                rc = gemm6_launch(x.A + z * stride, K, x.B + z * stride, K, Xbuf + (int64_t)z * h * h, ldX, (int)h, n2, (int)h,
-                                  1, 0, 1.0f, G6buf, st);
-                if (rc) return rc;
-                rc = gemm6_launch(Xbuf + (int64_t)z * h * h, ldX, Wk + h * ((int64_t)K + 1) + z * stride, K,
-                                  Wk + h + z * stride, K, (int)h, n2, n2, 0, 1, -1.0f, G6buf, st);
-            }
-            if (rc) return rc;
-            continue;
-        }
-        rc = lvl_x3 ? gemm3_launch(x, false, st) : sgemm_launch(x, false, false, st);
-        if (rc) return rc;
-        // C = -X B^-1
-        SgemmArgs y{};
-        y.A = Xbuf; y.lda = ldX; y.sA = h * h;
-        y.B = Wk + h * ((int64_t)K + 1); y.ldb = K; y.sB = stride;   // B^-1 at (o+h, o+h), upper
-        y.C = Wk + h; y.ldc = K; y.sC = stride;
-        y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2_last; y.Kd = (int)h; y.Kd_last = n2_last;
-        y.epilogue = SG_NEG; y.b_upper = 1; y.batch = npairs;
-        rc = lvl_x3 ? gemm3_launch(y, false, st) : sgemm_launch(y, false, false, st);
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);
-    LLMC_LAUNCH_CHECK();
-    return LLMC_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The pipelined schedule of llmc_chol_inv_upper (round 4). Streams: `st` (the caller's) carries the CHAIN — per 128-wide
-// factor step k_potrf_inv, the panel solve and the update of the outer block's OWN columns, and per 512-wide outer block
-// the update of the next block's diagonal 512 x 512 — nothing else. `fast` carries what the chain needs one block later:
-// every step's far panel solve / far in-block update and the far update of the next block's rows right of its diagonal.
-// `bulk` carries the far update of everything below the next block, its top 512 rows first (event R1: all the next
-// block's far update waits for) and then the rest. `inv` runs the triangular inverse BEHIND the factorisation: a pair of a
-// doubling level is launched as soon as the factor rows it covers are final and nobody reads the factor entries it
-// overwrites any more; the one pair of the top level has its X = A^-1 C on `bulk` with buffers of its own while the last
-// outer blocks are still being factored. Dependencies (E = event):
-//   far panel / far in-block update of a step   <- the step's near panel solve (reads V_b and the near panel)
-//   next block's diagonal update (st)           <- all far panels of the block (fast), R1 of the previous block (bulk)
-//   next block's rows, far columns (fast)       <- R1 of the previous block
-//   far-rest of block b (bulk)                  <- far panels of block b; the bulk stream's own order (block b - 1 first)
-//   inverse pairs inside block b (inv)          <- the block's steps (st) and far in-block updates (fast): last readers of
-//                                                  the block's diagonal 512 x 512
-//   inverse pairs spanning blocks (inv)         <- additionally the whole far-rest of block b - 1 (bulk): the last reader of
-//                                                  factor entries right of the diagonal blocks they overwrite
-// Every element receives the updates of the outer blocks in ascending order whatever the streams do, from the same
-// kernels on the same tile grid as the serial schedule: the factor is bit-identical to it.
-// ---------------------------------------------------------------------------------------------------------------------
-static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev, hipStream_t caller, PipeStreams* ps) {
-    // the chain's stream: the caller's, or an internal one when the caller is on the NULL stream (pipe_streams.h)
-    hipStream_t st = pipe_chain_stream(ps, caller);
-    if (st != caller) {
-        hipEvent_t ec = nullptr;
-        if (int rc = ps->record(caller, &ec)) return rc;
-        if (int rc = pipe_wait(st, ec)) return rc;
-    }
-    float* Wk = (float*)ws;
-    float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
-    float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
-    void* G6buf = (char*)Xbuf + align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
-    float* XbufTop = (float*)((char*)G6buf + gemm6_bytes(K));
-    void* G6top = (char*)XbufTop + top_x_bytes(K);
-    const bool use_g6 = getenv("LLMC_K3_NO_GEMM6") == nullptr;
-    hipStream_t fast = ps->fast, bulk = ps->bulk, inv = ps->inv;
-    LLMC_HIP_CHECK(hipMemsetAsync(info_dev, 0, 4, st));
-    if (int rc = ensure_dynamic_lds((const void*)k_potrf_inv, (NB * PLD + 32 * PLD + 64) * (int)sizeof(float))) return rc;
-
-    dim3 tgrid((K + 31) / 32, (K + 31) / 32);
-    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
-    LLMC_LAUNCH_CHECK();
-    if (use_g6 && K > GEMM6_MIN_H) {     // gemm6 reads triangular operands at 256 granularity; nothing writes below the diagonal
-        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
-        LLMC_LAUNCH_CHECK();
-    }
-    hipEvent_t e0 = nullptr;
-    if (int rc = ps->record(st, &e0)) return rc;      // the helpers start behind the caller's stream
-    if (int rc = pipe_wait(fast, e0)) return rc;
-    if (int rc = pipe_wait(bulk, e0)) return rc;
-    if (int rc = pipe_wait(inv, e0)) return rc;
-
-    const int NBO = 4 * NB;
-    auto panel_solve = [&](const float* Vb, int c0, int nb, int col0, int ncols, hipStream_t s_) -> int {
-        if (ncols <= 0) return LLMC_OK;
-        float* P = Wk + (size_t)c0 * K + col0;
-        SgemmArgs g{};
-        g.A = Vb; g.lda = NB; g.B = P; g.ldb = K; g.C = P; g.ldc = K;
-        g.M = g.M_last = nb; g.N = g.N_last = ncols; g.Kd = g.Kd_last = nb;
-        g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
-        return sgemm_launch(g, true, false, s_);
-    };
-    auto inblock_update = [&](int c0, int nb, int oend, int col0, int ncols, hipStream_t s_) -> int {
-        const int mrows = oend - (c0 + nb);
-        if (mrows <= 0 || ncols <= 0) return LLMC_OK;
-        SgemmArgs u{};
-        u.A = Wk + (size_t)c0 * K + c0 + nb; u.lda = K;
-        u.B = Wk + (size_t)c0 * K + col0; u.ldb = K;
-        u.C = Wk + (size_t)(c0 + nb) * K + col0; u.ldc = K;
-        u.M = u.M_last = mrows; u.N = u.N_last = ncols; u.Kd = u.Kd_last = nb;
-        u.epilogue = SG_SUB; u.c_upper_only = col0 == c0 + nb ? 1 : 0; u.batch = 1;
-        return sgemm_launch(u, true, false, s_);
-    };
-    // T[r0 .. r0+M, c0 .. c0+N] -= P[:, r0 ..]^T P[:, c0 ..] with P = factor rows k0 .. k0+Kd (split-bf16 product)
-    auto far_update = [&](int k0, int Kd, int r0, int M, int c0, int N, int upper, hipStream_t s_) -> int {
-        if (M <= 0 || N <= 0) return LLMC_OK;
-        SgemmArgs u{};
-        u.A = Wk + (size_t)k0 * K + r0; u.lda = K;
-        u.B = Wk + (size_t)k0 * K + c0; u.ldb = K;
-        u.C = Wk + (size_t)r0 * K + c0; u.ldc = K;
-        u.M = u.M_last = M; u.N = u.N_last = N; u.Kd = u.Kd_last = Kd;
-        u.epilogue = SG_SUB; u.c_upper_only = upper; u.batch = 1;
-        return gemm3_tn_launch(u, s_);
-    };
-
-    // ---- triangular inverse, level by level as the factor rows become final -------------------------------------------
-    const int64_t h_top = top_level_h(K);
-    int nlev = 0;
-    for (int64_t h = NB; h < K; h *= 2) ++nlev;
-    int launched[32] = {};                 // pairs of level li (h = NB << li) already launched
+    // pairs [z0, z1) of doubling level h of the triangular inverse, in place in Wk (X through Xbuf):
+    //   [[A, C], [0, B]]^-1 = [[A^-1, -A^-1 C B^-1], [0, B^-1]] with A^-1, B^-1 already in place
+    int launched[32] = {};                 // pairs of level li (h = NB << li) done so far
     auto pair_count = [&](int64_t h) { return (int)((K - h + 2 * h - 1) / (2 * h)); };
-    // pairs [z0, z1) of level h on stream s_ (X through Xbuf from its start: the stream is in order)
     auto launch_pairs = [&](int64_t h, int z0, int z1, hipStream_t s_) -> int {
         const int npairs = pair_count(h);
         const int64_t o_last = (int64_t)(npairs - 1) * 2 * h;
@@ -917,8 +662,10 @@ static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev
         const bool has_last = z1 == npairs;
         const int n2b = has_last ? n2_last : (int)h;
         const int cnt = z1 - z0;
+        // X is [h x n2]: with one pair its leading dimension shrinks to n2 (keeps X within K^2/4 floats)
         const int64_t ldX = (cnt == 1 && has_last) ? ((n2_last + 3) / 4) * 4 : h;
-        const bool lvl_x3 = h >= 512;
+        const bool lvl_x3 = k3_x3 && h >= 512;   // small levels are latency-bound: the fp32 kernels stay
+        // large, deep levels: operands split once into stacked bf16 planes, product on the one-wave-per-SIMD GEMM
         const bool lvl_g6 = lvl_x3 && use_g6 && h >= GEMM6_MIN_H && h % 256 == 0 && n2_last % 256 == 0;
         if (lvl_g6) {
             for (int z = z0; z < z1; ++z) {
@@ -933,51 +680,44 @@ static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev
             return LLMC_OK;
         }
         SgemmArgs x{};
-        x.A = Wk + z0 * stride; x.lda = K; x.sA = stride;
-        x.B = Wk + h + z0 * stride; x.ldb = K; x.sB = stride;
+        x.A = Wk + z0 * stride; x.lda = K; x.sA = stride;                 // A^-1 at (o, o), upper
+        x.B = Wk + h + z0 * stride; x.ldb = K; x.sB = stride;             // C at (o, o+h)
         x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
         x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2b; x.Kd = x.Kd_last = (int)h;
         x.epilogue = SG_SET; x.a_upper = 1; x.batch = cnt;
         int rc = lvl_x3 ? gemm3_launch(x, false, s_) : sgemm_launch(x, false, false, s_);
         if (rc) return rc;
-        SgemmArgs y{};
+        SgemmArgs y{};                                                    // C = -X B^-1
         y.A = Xbuf; y.lda = ldX; y.sA = h * h;
-        y.B = Wk + h * ((int64_t)K + 1) + z0 * stride; y.ldb = K; y.sB = stride;
+        y.B = Wk + h * ((int64_t)K + 1) + z0 * stride; y.ldb = K; y.sB = stride;   // B^-1 at (o+h, o+h), upper
         y.C = Wk + h + z0 * stride; y.ldc = K; y.sC = stride;
         y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2b; y.Kd = (int)h; y.Kd_last = n2b;
         y.epilogue = SG_NEG; y.b_upper = 1; y.batch = cnt;
         return lvl_x3 ? gemm3_launch(y, false, s_) : sgemm_launch(y, false, false, s_);
     };
-    const int n2_top = (int)(K - h_top);
-    const int64_t ldXtop = ((n2_top + 3) / 4) * 4;
-    const bool top_g6 = use_g6 && h_top >= GEMM6_MIN_H && h_top % 256 == 0 && n2_top % 256 == 0;
-    bool top_x_done = false;
-    hipEvent_t eTopX = nullptr;
-    auto launch_top_x = [&](hipStream_t s_) -> int {       // X = A^-1 C of the top pair, into its own buffer
-        if (top_g6) return gemm6_launch(Wk, K, Wk + h_top, K, XbufTop, ldXtop, (int)h_top, n2_top, (int)h_top, 1, 0, 1.0f, G6top, s_);
-        SgemmArgs x{};
-        x.A = Wk; x.lda = K; x.B = Wk + h_top; x.ldb = K; x.C = XbufTop; x.ldc = ldXtop;
-        x.M = x.M_last = (int)h_top; x.N = x.N_last = n2_top; x.Kd = x.Kd_last = (int)h_top;
-        x.epilogue = SG_SET; x.a_upper = 1; x.batch = 1;
-        return h_top >= 512 ? gemm3_launch(x, false, s_) : sgemm_launch(x, false, false, s_);
+    // every pair of level h that lies inside rows [0, upto) and is not done yet
+    auto launch_ready = [&](int64_t h, int li, int upto, hipStream_t s_) -> int {
+        const int npairs = pair_count(h);
+        int z1 = launched[li];
+        while (z1 < npairs) {
+            const int64_t o = (int64_t)z1 * 2 * h;
+            if ((o + 2 * h < K ? o + 2 * h : K) > upto) break;
+            ++z1;
+        }
+        if (z1 == launched[li]) return LLMC_OK;
+        int rc = launch_pairs(h, launched[li], z1, s_);
+        launched[li] = z1;
+        return rc;
     };
-    auto launch_top_y = [&](hipStream_t s_) -> int {       // C = -X B^-1
-        if (top_g6)
-            return gemm6_launch(XbufTop, ldXtop, Wk + h_top * ((int64_t)K + 1), K, Wk + h_top, K, (int)h_top, n2_top, n2_top, 0, 1,
-                                -1.0f, G6top, s_);
-        SgemmArgs y{};
-        y.A = XbufTop; y.lda = ldXtop; y.B = Wk + h_top * ((int64_t)K + 1); y.ldb = K; y.C = Wk + h_top; y.ldc = K;
-        y.M = y.M_last = (int)h_top; y.N = y.N_last = n2_top; y.Kd = y.Kd_last = n2_top;
-        y.epilogue = SG_NEG; y.b_upper = 1; y.batch = 1;
-        return h_top >= 512 ? gemm3_launch(y, false, s_) : sgemm_launch(y, false, false, s_);
-    };
-
-    hipEvent_t R1_prev = nullptr, R2_prev = nullptr;
+    const bool lvl_zero_subdiag = k3_x3 && use_g6 && K > GEMM6_MIN_H;
+    if (lvl_zero_subdiag) {     // gemm6 reads triangular operands at 256 granularity; nothing below writes under the diagonal
+        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
+        LLMC_LAUNCH_CHECK();
+    }
     for (int k0 = 0; k0 < K; k0 += NBO) {
         const int nbo = K - k0 < NBO ? K - k0 : NBO;
         const int oend = k0 + nbo;
         const int nfar = K - oend;
-        // ---- the block's factor steps
         for (int c0 = k0; c0 < oend; c0 += NB) {
             const int b = c0 / NB;
             const int nb = K - c0 < NB ? K - c0 : NB;
@@ -985,113 +725,83 @@ static int chol_inv_upper_pipelined(float* A, int K, void* ws, int32_t* info_dev
             hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (NB * PLD + 32 * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
                                nb, Vb, info_dev);
             LLMC_LAUNCH_CHECK();
-            if (K - c0 - nb <= 0) break;
-            const int nnear = oend - (c0 + nb);
-            int rc = panel_solve(Vb, c0, nb, c0 + nb, nnear, st);
+            if (oend - c0 - nb <= 0) break;
+            int rc = panel_solve(Vb, c0, nb, c0 + nb, oend - (c0 + nb), st);
             if (rc) return rc;
-            if (nfar > 0) {
-                hipEvent_t e = nullptr;
-                if ((rc = ps->record(st, &e))) return rc;
-                if ((rc = pipe_wait(fast, e))) return rc;
-                if ((rc = panel_solve(Vb, c0, nb, oend, nfar, fast))) return rc;
-                if ((rc = inblock_update(c0, nb, oend, oend, nfar, fast))) return rc;
-            }
-            if ((rc = inblock_update(c0, nb, oend, c0 + nb, nnear, st))) return rc;
+            if ((rc = inblock_update(c0, nb, oend, c0 + nb, oend - (c0 + nb), st))) return rc;
         }
-        // ---- end of the block
-        hipEvent_t eE = nullptr, eF = nullptr;
-        int rc = ps->record(st, &eE);
-        if (rc) return rc;
-        if ((rc = ps->record(fast, &eF))) return rc;
-        hipEvent_t R1 = nullptr, R2 = nullptr;
-        if (nfar > 0) {
-            const int m1 = nfar < NBO ? nfar : NBO, m2 = nfar - m1;
-            // next block's diagonal: the only far update the chain itself waits for
-            if ((rc = pipe_wait(st, eF))) return rc;
-            if ((rc = pipe_wait(st, R1_prev))) return rc;
-            if ((rc = far_update(k0, nbo, oend, m1, oend, m1, 1, st))) return rc;
-            if (m2 > 0) {
-                // next block's rows right of its diagonal: before that block's far panel solves on the same stream
-                if ((rc = pipe_wait(fast, R1_prev))) return rc;
-                if ((rc = far_update(k0, nbo, oend, m1, oend + m1, m2, 0, fast))) return rc;
-                // everything below the next block: its top 512 rows first
-                if ((rc = pipe_wait(bulk, eF))) return rc;
-                const int mt = m2 < NBO ? m2 : NBO;
-                if ((rc = far_update(k0, nbo, oend + m1, mt, oend + m1, m2, 1, bulk))) return rc;
-                if ((rc = ps->record(bulk, &R1))) return rc;
-                if (m2 > mt)
-                    if ((rc = far_update(k0, nbo, oend + m1 + mt, m2 - mt, oend + m1 + mt, m2 - mt, 1, bulk))) return rc;
-                if ((rc = ps->record(bulk, &R2))) return rc;
-            }
-        }
-        // ---- the inverse of what is final now (rows < oend)
-        if ((rc = pipe_wait(inv, eE))) return rc;
-        if ((rc = pipe_wait(inv, eF))) return rc;
+        // the block's diagonal 512 x 512 of the inverse: inverted 128-blocks in place, then the levels inside the block.
+        // (The factor entries they overwrite have no reader left: the far panel below uses the inverse, not the factor.)
         {
             const int b0 = k0 / NB, nbk = (nbo + NB - 1) / NB;
-            hipLaunchKernelGGL(k_place_diag_inv, dim3(nbk), dim3(256), 0, inv, Wk, (int64_t)K, K, (const float*)Vbuf, b0);
+            hipLaunchKernelGGL(k_place_diag_inv, dim3(nbk), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf, b0);
             LLMC_LAUNCH_CHECK();
-        }
-        bool waited_bulk = false;
-        {
             int li = 0;
-            for (int64_t h = NB; h < K; h *= 2, ++li) {
-                if (h == h_top) break;                      // the top pair has its own path
-                const int npairs = pair_count(h);
-                int z1 = launched[li];
-                while (z1 < npairs) {
-                    const int64_t o = (int64_t)z1 * 2 * h;
-                    const int64_t e = o + 2 * h < K ? o + 2 * h : K;
-                    if (e > oend) break;
-                    ++z1;
-                }
-                if (z1 > launched[li]) {
-                    if (2 * h > NBO && !waited_bulk) {      // the pair overwrites factor entries earlier far-rests read
-                        if ((rc = pipe_wait(inv, R2_prev))) return rc;
-                        waited_bulk = true;
-                    }
-                    if ((rc = launch_pairs(h, launched[li], z1, inv))) return rc;
-                    launched[li] = z1;
+            for (int64_t h = NB; 2 * h <= NBO && h < K; h *= 2, ++li)
+                if (int rc = launch_ready(h, li, oend, st)) return rc;
+        }
+        if (nfar > 0) {
+            // far panel P = V_bb^T A[block rows, far cols] (V_bb upper: op(A)[i][k] = V[k][i] is lower triangular)
+            const int64_t ldp = ((int64_t)nfar + 3) / 4 * 4;
+            SgemmArgs g{};
+            g.A = Wk + (size_t)k0 * K + k0; g.lda = K;
+            g.B = Wk + (size_t)k0 * K + oend; g.ldb = K;
+            g.C = Pbuf; g.ldc = ldp;
+            g.M = g.M_last = nbo; g.N = g.N_last = nfar; g.Kd = g.Kd_last = nbo;
+            g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
+            int rc = k3_x3 ? gemm3_launch(g, true, st) : sgemm_launch(g, true, false, st);
+            if (rc) return rc;
+            LLMC_HIP_CHECK(hipMemcpy2DAsync(Wk + (size_t)k0 * K + oend, (size_t)K * 4, Pbuf, (size_t)ldp * 4, (size_t)nfar * 4,
+                                            (size_t)nbo, hipMemcpyDeviceToDevice, st));
+            // far trailing update T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo), in two parts: the rows
+            // of the NEXT outer block on the main stream (its factor steps need them), the rows below on the side
+            // stream, overlapped with the next outer block's latency-bound diagonal / panel kernels.
+            float* P = Wk + (size_t)k0 * K + oend;
+            const int m1 = nfar < NBO ? nfar : NBO;
+            SgemmArgs u{};
+            u.A = P; u.lda = K; u.B = P; u.ldb = K;
+            u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
+            u.M = u.M_last = m1; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
+            u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
+            if (side && pending_side) {          // the previous block's side update wrote the rows updated next
+                rc = join_from_side(side, st);
+                if (rc) return rc;
+                pending_side = false;
+            }
+            rc = k3_x3 ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
+            if (rc) return rc;
+            const int m2 = nfar - m1;
+            if (m2 > 0) {
+                SgemmArgs v{};
+                v.A = P + m1; v.lda = K; v.B = P + m1; v.ldb = K;
+                v.C = Wk + (size_t)(oend + m1) * K + oend + m1; v.ldc = K;
+                v.M = v.M_last = m2; v.N = v.N_last = m2; v.Kd = v.Kd_last = nbo;
+                v.epilogue = SG_SUB; v.c_upper_only = 1; v.batch = 1;
+                if (side) {
+                    rc = fork_to_side(side, st);   // P is final on main at this point
+                    if (rc) return rc;
+                    rc = k3_x3 ? gemm3_tn_launch(v, side->side) : sgemm_launch(v, true, false, side->side);
+                    if (rc) return rc;
+                    pending_side = true;
+                } else {
+                    rc = k3_x3 ? gemm3_tn_launch(v, st) : sgemm_launch(v, true, false, st);
+                    if (rc) return rc;
                 }
             }
         }
-        // the top pair's X as soon as its A half is inverted (rows < h_top final, the lower levels of that half launched)
-        if (!top_x_done && nlev >= 1 && oend >= h_top && oend < K) {
-            hipEvent_t eA = nullptr;
-            if ((rc = ps->record(inv, &eA))) return rc;          // the A half's inverse is complete behind this point
-            if ((rc = pipe_wait(bulk, eA))) return rc;
-            if ((rc = launch_top_x(bulk))) return rc;
-            if ((rc = ps->record(bulk, &eTopX))) return rc;
-            top_x_done = true;
-        }
-        R1_prev = R1;                 // null when this block had no far-rest: then there is no block after the next
-        if (R2) R2_prev = R2;         // sticky: the latest far-rest on the bulk stream, whichever block issued it
     }
-    // ---- the top pair: X (unless already running) and Y = -X B^-1 once the B half is inverted
-    if (nlev >= 1) {
-        hipEvent_t eB = nullptr;
-        int rc = ps->record(inv, &eB);
+    if (side && pending_side) {
+        int rc = join_from_side(side, st);
         if (rc) return rc;
-        if ((rc = pipe_wait(bulk, eB))) return rc;
-        if (!top_x_done) {
-            if ((rc = launch_top_x(bulk))) return rc;
-        }
-        if ((rc = launch_top_y(bulk))) return rc;
     }
-    // ---- join the helpers, write U
-    for (hipStream_t s_ : {fast, bulk, inv}) {
-        hipEvent_t e = nullptr;
-        int rc = ps->record(s_, &e);
-        if (rc) return rc;
-        if ((rc = pipe_wait(st, e))) return rc;
+    // ---- V = U'^-1: the doubling levels above the outer blocks (the levels inside them are done)
+    {
+        int li = 0;
+        for (int64_t h = NB; h < K; h *= 2, ++li)
+            if (int rc = launch_ready(h, li, K, st)) return rc;
     }
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);
     LLMC_LAUNCH_CHECK();
-    (void)eTopX;
-    if (st != caller) {
-        hipEvent_t ec = nullptr;
-        if (int rc = ps->record(st, &ec)) return rc;
-        if (int rc = pipe_wait(caller, ec)) return rc;
-    }
     return LLMC_OK;
 }
+
