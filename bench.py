@@ -8,10 +8,11 @@ inverse -> blocked column loop -> scales/zeros/compensated weights.  Synthetic i
   python bench.py --gpus N --steps K --warmup W
 N > 1 without a launcher: bench.py re-executes itself under `python -m torch.distributed.run` with N ranks (one per
 GPU, RCCL); under a launcher (WORLD_SIZE set) it is a rank.
-  --mode handoff (default for N > 1, weak scaling): every rank quantizes its own blocks; the calibration activations
-          entering a block ([n_seq, seq, K], 2 GiB) arrive from the ring predecessor over RCCL send/recv on a side
-          stream, overlapped with compute. value = layers of all ranks / max-over-ranks time; `independent_value` = the
-          same without the hand-off (a few extra steps after the timed region).
+  no --mode with N > 1 ("auto"): the timed region runs `independent` (the contract value: it cannot wedge); a few steps of
+          `handoff` and of `cooperative` follow outside it and are reported as handoff_value / cooperative_value (or *_error).
+  --mode handoff (weak scaling): every rank quantizes its own blocks; a block's OUTPUT (o_proj's quantized weights applied to
+          its calibration input, [n_seq, seq, hidden], 2 GiB) goes to the ring successor over RCCL send/recv on a side stream,
+          overlapped with the next step, and the tensor received becomes the input of the step after next.
   --mode independent (weak scaling): every rank quantizes its own blocks, no data-path traffic at all.
   --mode cooperative (strong scaling): all ranks work on ONE block per step (llmc_amd/dist/layer_shard.py):
           subsets with K <= 8192 — rank 0 broadcasts the Hessian (layers sharing an input) or the activations over
@@ -310,6 +311,14 @@ class HipOps:
                 outs.append(self.pack_lsb(codes, self.cfg.bit))
         return outs
 
+    def block_output(self, x, w, dtype):
+        """x [n_seq, seq, K] (or the list of per-call tensors) times the quantized weight w [R, K] (fp32 after GPTQ):
+        the layer's output over the calibration set, as FakeQuantLinear.forward computes it (HIP GEMM)."""
+        from llmc_amd.compression.quantization import awq_ops
+        if isinstance(x, (list, tuple)):
+            x = self.torch.cat(list(x), 0)
+        return awq_ops.linear_auto(x.reshape(-1, x.shape[-1]), w.to(dtype), None)
+
     def stream(self, i):
         if i not in self.streams:
             # stream 0 carries the longest chain: its many short kernels go ahead of the other chains' in the queues
@@ -348,6 +357,11 @@ class DryOps:
             w = w[rows[0]:rows[1]]
         s = w.abs().amax(1, keepdim=True).clamp(min=1e-5) / 7
         return [{'weight': (w / s).round().clamp(-8, 7) * s + 0 * H.diagonal().mean()}]
+
+    def block_output(self, x, w, dtype):
+        if isinstance(x, (list, tuple)):
+            x = self.torch.cat(list(x), 0)
+        return x.reshape(-1, x.shape[-1]).float() @ w.float().T
 
     def stream(self, i):
         return None
@@ -616,17 +630,37 @@ def main():
             raise SystemExit(f'rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
+    # N > 1 without --mode ("auto"): the CONTRACT value is measured with block-sharded ownership and no data-path traffic
+    # (`independent`: it cannot wedge), and two secondary values follow outside the timed region, each behind a
+    # try / except and an agreement over a Gloo control group: `handoff_value` (the same ownership with the block outputs
+    # handed owner-to-owner over RCCL send/recv) and `cooperative_value` (north_star's partition: one block shared by all
+    # ranks, activations / Hessians broadcast, the wide subset sample-sharded + all_reduce). ADVICE r03: a wedged transfer
+    # must not take the contract line with it.
+    auto = args.mode is None and world > 1
     if args.mode is None:
-        args.mode = 'handoff' if world > 1 else 'independent'
+        args.mode = 'independent'
+    ctl = None          # control-plane group (flags, max-over-ranks times): Gloo, CPU tensors — never the data path's RCCL
     if world > 1:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # a bounded collective timeout: a wedged transfer aborts the run instead of hanging the node
+        # a bounded collective timeout, and on expiry the watchdog aborts the COMMUNICATOR, not the process: the blocked
+        # call raises, the secondary measurement is recorded as failed, the line is still printed
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '2')
         if args.dry:
             dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))
+            ctl = dist.group.WORLD
         else:
-            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=180))
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=120))
+            ctl = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=300))
+
+    def ctl_reduce(value, op):
+        """max / min over ranks of a Python number through the control group"""
+        if world == 1:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=op, group=ctl)
+        return float(t.item())
 
     from llmc_amd.compression.quantization.gptq_pipeline import GptqConfig
     from llmc_amd.dist import layer_shard as LS
@@ -640,187 +674,202 @@ def main():
         cfg = GptqConfig(bit=4, symmetric=True, group_size=128, actorder=True, static_groups=True)
     groups = block_groups(args.model)
     ops = DryOps(cfg) if args.dry else HipOps(dev, cfg, args.variant)
-    coop = args.mode == 'cooperative' and world > 1
     n_layers_block = sum(len(ls) for _, _, ls in groups)
-
-    # ---- resident synthetic data. independent: every rank owns different blocks (different seeds).
-    # cooperative: one block; rank 0 holds the full activations of the broadcast subsets, every rank holds its own
-    # sequences (rank::world) of the sample-sharded ones; weights are the same on every rank (same seed).
-    acts, weights, plan = {}, {}, {}
-    for gi, (name, K, layers) in enumerate(groups):
-        seed_r = 0 if coop else rank
-        plan[name] = ('sample' if K > 8192 else 'broadcast') if coop else 'local'
-        if plan[name] == 'sample':
-            n_mine = len(range(rank, args.n_seq, world))
-            acts[name] = synth_acts(n_mine, args.seq_len, K, 64 * rank + gi, dev, dtype)
-        elif plan[name] == 'broadcast':
-            acts[name] = synth_acts(args.n_seq, args.seq_len, K, gi, dev, dtype) if rank == 0 else None
-        else:
-            acts[name] = synth_acts(args.n_seq, args.seq_len, K, seed_r * 64 + gi, dev, dtype)
-            if args.mode == 'handoff' and world > 1 and gi == 0:
-                continue_split = False      # the block's first input arrives as ONE tensor from the previous owner
-            else:
-                continue_split = True
-            if continue_split and args.calib_bs < args.n_seq and not args.dry:
-                # the hook calls' tensors: one allocation per call (calib.bs sequences each), nothing contiguous across calls
-                x = acts[name]
-                acts[name] = [x[i:i + args.calib_bs].clone() for i in range(0, args.n_seq, args.calib_bs)]
-                del x
-        weights[name] = [synth_weight(R, K, seed_r * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
-
     timing = []
 
-    def step_independent(record):
-        ops.timing = timing if record else None
-        outs = []
-        Hs = {}
-        if args.overlap <= 1 or args.dry:
-            for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
-                Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-            for name, K, layers in groups:
-                outs.append(ops.quantize(name, weights[name], Hs[name]))
-            return outs
-        # the four subsets' factorisations and column loops are independent latency-bound chains: one stream each.
-        # --order k1first (default): all four Hessians, then the four chains, widest first.
-        # --order chain: the subset with the longest K1 -> K3 -> K4 chain (down: 39 + 22 + 11 ms) goes first and its
-        # chain starts the moment its Hessian is done, the other Hessians and chains behind it. Measured on one box:
-        # 99.2 ms/step against 98.0 for k1first (K1 drops from 0.564 to 0.535 of peak): a k_syrk4 block owns its CU
-        # (512 VGPRs, 128 KiB LDS) and its tile list is static, so every CU a chain kernel holds when a Hessian starts
-        # delays that Hessian's tail, and the chain in turn waits for whole Hessians to retire.
-        cur = torch.cuda.current_stream()
-        order = sorted(range(len(groups)), key=lambda i: -groups[i][1] * sum(r for _, r in groups[i][2]))
-        evs = []
-
-        def chain(si, gi, helper=False):
-            name = groups[gi][0]
-            st = ops.stream(si % args.overlap)
-            st.wait_stream(cur)
-            # one stream per chain and no internal helper streams: measured 94.5 ms/step, against 96.3 with a helper for
-            # the longest chain and 108 without overlap (more streams than hardware queues start to serialise)
-            with torch.cuda.stream(st), ops.helper_streams(helper):
-                outs.append(ops.quantize(name, weights[name], Hs[name]))
-            evs.append(st)
-
-        if args.order == 'shadow':
-            # the narrow subsets first: their Hessians (3 x 3.3 ms), then their chains on streams 1.., and BEHIND them the
-            # widest subset's Hessian (39 ms) with --reserve CUs left free: the narrow chains run in its shadow on those
-            # CUs, and the widest chain has the device to itself afterwards
-            for gi in order[1:]:
-                Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs)
-            for si, gi in enumerate(order[1:]):
-                chain(si + 1, gi)
-            g0 = groups[order[0]]
-            with ops.cu_reserve(args.reserve):
-                Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
-            chain(0, order[0], helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
-        else:
-            if args.order == 'k1first':
-                for name, K, layers in groups:
-                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-            for si, gi in enumerate(order):
-                name, K = groups[gi][0], groups[gi][1]
-                if args.order != 'k1first':
-                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-                # one stream per chain, internal helper streams off (--wide-helper 1 gives the widest chain its helper:
-                # measured 94.5 against 93.7 ms per step, gpurun_out/r03g: the other chains already fill its gaps)
-                chain(si, gi, helper=(args.helpers == 'all') or ((args.helpers == 'wide' or bool(args.wide_helper)) and si == 0))
-        for st in set(evs):
-            cur.wait_stream(st)
-        return outs
-
-    def step_cooperative(record):
-        ops.timing = timing if record else None
-        outs = []
-        for name, K, layers in groups:
-            shape = (args.n_seq, args.seq_len, K)
+    def prepare(mode):
+        """Resident synthetic data and the step function of one mode. independent / handoff: every rank owns different
+        blocks (different seeds). cooperative: one block; rank 0 holds the full activations of the broadcast subsets, every
+        rank holds its own sequences (rank::world) of the sample-sharded ones; weights are the same on every rank."""
+        coop = mode == 'cooperative' and world > 1
+        handoff = mode == 'handoff' and world > 1
+        acts, weights, plan = {}, {}, {}
+        for gi, (name, K, layers) in enumerate(groups):
+            seed_r = 0 if coop else rank
+            plan[name] = ('sample' if K > 8192 else 'broadcast') if coop else 'local'
             if plan[name] == 'sample':
-                outs.append(LS.run_subset_sample_sharded(
-                    acts[name], weights[name],
-                    hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs),
-                    quantize_rows_fn=lambda ws, H, rows, n=name: ops.quantize(n, ws, H, rows=rows)))
+                n_mine = len(range(rank, args.n_seq, world))
+                acts[name] = synth_acts(n_mine, args.seq_len, K, 64 * rank + gi, dev, dtype)
+            elif plan[name] == 'broadcast':
+                acts[name] = synth_acts(args.n_seq, args.seq_len, K, gi, dev, dtype) if rank == 0 else None
             else:
-                ids = list(range(len(layers)))
-                share = 'hessian' if len(layers) > 1 else 'activations'
-                outs.append(LS.run_block_cooperative(
-                    ids, acts[name], 0,
-                    lambda li, shared, n=name, k=K, sh=share: ops.quantize(
-                        n + str(li), [weights[n][li]],
-                        shared if sh == 'hessian' else ops.hessian(n, k, shared, args.calib_bs)),
-                    (shape, dtype, dev), share=share,
-                    hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=None, to_cpu=False))   # results stay with their owners: the gather for saving is not on the step's path
-        return outs
+                acts[name] = synth_acts(args.n_seq, args.seq_len, K, seed_r * 64 + gi, dev, dtype)
+                # the block's first input arrives as ONE tensor from the previous owner under the hand-off
+                if not (handoff and gi == 0) and args.calib_bs < args.n_seq and not args.dry:
+                    # the hook calls' tensors: one allocation per call (calib.bs sequences each), nothing contiguous across calls
+                    x = acts[name]
+                    acts[name] = [x[i:i + args.calib_bs].clone() for i in range(0, args.n_seq, args.calib_bs)]
+                    del x
+            weights[name] = [synth_weight(R, K, seed_r * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
 
-    # ---- handoff: block-sharded ownership with the activations of a block's first input handed from owner to owner.
-    # In a model run with quant_out off the inputs of block b are the float outputs of block b - 1
-    # (base_blockwise_quantization.py:367-402): whoever owns block b - 1 produces them and sends them on. Here every rank
-    # sends the [n_seq, seq, K] tensor it has just consumed to its ring successor and receives the one its NEXT step
-    # consumes from its predecessor: the transfer of step t + 1's input runs on its own stream under step t's kernels.
-    handoff = args.mode == 'handoff' and world > 1
-    hand = {}
-    if handoff:
-        name0 = groups[0][0]
-        hand['cur'] = acts[name0]
-        hand['nxt'] = torch.empty_like(acts[name0])
-        hand['bytes'] = acts[name0].numel() * acts[name0].element_size()
-        hand['stream'] = None if args.dry else torch.cuda.Stream(device=dev)
+        def step_independent(record):
+            ops.timing = timing if record else None
+            outs = []
+            Hs = {}
+            if args.overlap <= 1 or args.dry:
+                for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
+                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+                for name, K, layers in groups:
+                    outs.append(ops.quantize(name, weights[name], Hs[name]))
+                return outs
+            # the four subsets' factorisations and column loops are independent latency-bound chains: one stream each.
+            # --order k1first (default): all four Hessians, then the four chains, widest first.
+            # --order chain: the subset with the longest K1 -> K3 -> K4 chain (down: 39 + 22 + 11 ms) goes first and its
+            # chain starts the moment its Hessian is done, the other Hessians and chains behind it. Measured on one box:
+            # 99.2 ms/step against 98.0 for k1first (K1 drops from 0.564 to 0.535 of peak): a k_syrk4 block owns its CU
+            # (512 VGPRs, 128 KiB LDS) and its tile list is static, so every CU a chain kernel holds when a Hessian starts
+            # delays that Hessian's tail, and the chain in turn waits for whole Hessians to retire.
+            cur = torch.cuda.current_stream()
+            order = sorted(range(len(groups)), key=lambda i: -groups[i][1] * sum(r for _, r in groups[i][2]))
+            evs = []
+            slot = {}
 
-    def handoff_start():
-        import torch.distributed as dist
-        nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
-        p2p = [dist.P2POp(dist.isend, hand['cur'], nxt_rank), dist.P2POp(dist.irecv, hand['nxt'], prv_rank)]
-        if hand['stream'] is None:
-            hand['reqs'] = dist.batch_isend_irecv(p2p)
-            return
-        hand['stream'].wait_stream(torch.cuda.current_stream())      # the buffers are ready
-        with torch.cuda.stream(hand['stream']):
-            hand['reqs'] = dist.batch_isend_irecv(p2p)
+            def chain(si, gi, helper=False):
+                name = groups[gi][0]
+                st = ops.stream(si % args.overlap)
+                st.wait_stream(cur)
+                # one stream per chain and no internal helper streams: measured 94.5 ms/step, against 96.3 with a helper for
+                # the longest chain and 108 without overlap (more streams than hardware queues start to serialise)
+                with torch.cuda.stream(st), ops.helper_streams(helper):
+                    slot[gi] = ops.quantize(name, weights[name], Hs[name])
+                evs.append(st)
 
-    def handoff_finish():
-        if hand['stream'] is None:
-            for r in hand['reqs']:
-                r.wait()
-        else:
+            if args.order == 'shadow':
+                # the narrow subsets first: their Hessians (3 x 3.3 ms), then their chains on streams 1.., and BEHIND them the
+                # widest subset's Hessian (39 ms) with --reserve CUs left free: the narrow chains run in its shadow on those
+                # CUs, and the widest chain has the device to itself afterwards
+                for gi in order[1:]:
+                    Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs)
+                for si, gi in enumerate(order[1:]):
+                    chain(si + 1, gi)
+                g0 = groups[order[0]]
+                with ops.cu_reserve(args.reserve):
+                    Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
+                chain(0, order[0], helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
+            else:
+                if args.order == 'k1first':
+                    for name, K, layers in groups:
+                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+                for si, gi in enumerate(order):
+                    name, K = groups[gi][0], groups[gi][1]
+                    if args.order != 'k1first':
+                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+                    # one stream per chain, internal helper streams off (--helpers wide gives the widest chain its helper:
+                    # measured 94.5 against 93.7 ms per step, gpurun_out/r03g: the other chains already fill its gaps)
+                    chain(si, gi, helper=(args.helpers == 'all') or ((args.helpers == 'wide' or bool(args.wide_helper)) and si == 0))
+            for st in set(evs):
+                cur.wait_stream(st)
+            return [slot[gi] for gi in range(len(groups))]      # in block order (o_proj's result is outs[1])
+
+        def step_cooperative(record):
+            ops.timing = timing if record else None
+            outs = []
+            for name, K, layers in groups:
+                shape = (args.n_seq, args.seq_len, K)
+                if plan[name] == 'sample':
+                    outs.append(LS.run_subset_sample_sharded(
+                        acts[name], weights[name],
+                        hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs),
+                        quantize_rows_fn=lambda ws, H, rows, n=name: ops.quantize(n, ws, H, rows=rows)))
+                else:
+                    ids = list(range(len(layers)))
+                    share = 'hessian' if len(layers) > 1 else 'activations'
+                    outs.append(LS.run_block_cooperative(
+                        ids, acts[name], 0,
+                        lambda li, shared, n=name, k=K, sh=share: ops.quantize(
+                            n + str(li), [weights[n][li]],
+                            shared if sh == 'hessian' else ops.hessian(n, k, shared, args.calib_bs)),
+                        (shape, dtype, dev), share=share,
+                        hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=None, to_cpu=False))   # results stay with their owners: the gather for saving is not on the step's path
+            return outs
+
+        # ---- handoff: block-sharded ownership with a block's OUTPUT handed to the owner of the next block. In a model run the
+        # inputs of block b are the outputs of block b - 1 (base_blockwise_quantization.py:367-402; with quant_out the outputs
+        # of the QUANTIZED block): whoever owns block b - 1 produces them and sends them on. Here every rank sends a tensor it
+        # has just computed from this step's result — o_proj's quantized weights applied to o_proj's calibration input,
+        # [n_seq, seq, hidden] in the model dtype (ops.block_output: the HIP GEMM of FakeQuantLinear.forward) — to its ring
+        # successor and receives what its step after next consumes from its predecessor: the transfer of step t's output runs
+        # on its own stream under step t + 1's kernels (double-buffered). The payload is produced by the step, so it cannot
+        # be elided, and it changes every step.
+        hand = {}
+        if handoff:
+            name0 = groups[0][0]
+            hand['cur'] = acts[name0]
+            hand['nxt'] = torch.empty_like(acts[name0])
+            hand['out'] = acts[name0]              # what the first transfer sends: the synthetic input itself
+            hand['bytes'] = acts[name0].numel() * acts[name0].element_size()
+            hand['stream'] = None if args.dry else torch.cuda.Stream(device=dev)
+
+        def handoff_start():
+            import torch.distributed as dist
+            nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+            p2p = [dist.P2POp(dist.isend, hand['out'], nxt_rank), dist.P2POp(dist.irecv, hand['nxt'], prv_rank)]
+            if hand['stream'] is None:
+                hand['reqs'] = dist.batch_isend_irecv(p2p)
+                return
+            hand['stream'].wait_stream(torch.cuda.current_stream())      # the buffers are ready
             with torch.cuda.stream(hand['stream']):
+                hand['reqs'] = dist.batch_isend_irecv(p2p)
+
+        def handoff_finish(new_out):
+            if hand['stream'] is None:
                 for r in hand['reqs']:
                     r.wait()
-            torch.cuda.current_stream().wait_stream(hand['stream'])   # the next step reads what arrived
-        hand['cur'], hand['nxt'] = hand['nxt'], hand['cur']
-        acts[groups[0][0]] = hand['cur']
+            else:
+                with torch.cuda.stream(hand['stream']):
+                    for r in hand['reqs']:
+                        r.wait()
+                torch.cuda.current_stream().wait_stream(hand['stream'])   # the next step reads what arrived
+            hand['cur'], hand['nxt'] = hand['nxt'], hand['cur']
+            hand['out'] = new_out
+            acts[groups[0][0]] = hand['cur']
 
-    def step_handoff(record):
-        if args.dry and os.environ.get('LLMC_BENCH_DRY_FAIL_HANDOFF') == '1':
-            raise RuntimeError('injected hand-off failure (dry-run test of the fallback)')
-        handoff_start()
-        out = step_independent(record)
-        handoff_finish()
-        return out
+        def step_handoff(record):
+            if args.dry and os.environ.get('LLMC_BENCH_DRY_FAIL_HANDOFF') == '1':
+                raise RuntimeError('injected hand-off failure (dry-run test of the fallback)')
+            handoff_start()
+            out = step_independent(record)
+            x_o = acts[groups[1][0]]
+            y = ops.block_output(x_o, out[1][0]['weight'], dtype)         # this step's block output: sent during the next step
+            handoff_finish(y.reshape(hand['cur'].shape))
+            return out
 
-    step = step_cooperative if coop else (step_handoff if handoff else step_independent)
+        step = step_cooperative if coop else (step_handoff if handoff else step_independent)
+        return step, {'coop': coop, 'handoff': handoff, 'hand': hand, 'acts': acts, 'weights': weights, 'plan': plan,
+                      'step_independent': step_independent}
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(group=ctl)
         ops.sync()
 
+    def release(ctx):
+        for k in ('acts', 'weights', 'hand', 'plan'):
+            ctx[k].clear()
+        ops.accs.clear() if hasattr(ops, 'accs') else None
+        ops.hwork.clear() if hasattr(ops, 'hwork') else None
+        import gc
+        gc.collect()
+        if not args.dry:
+            torch.cuda.empty_cache()
+
+    step, ctx = prepare(args.mode)
+    coop, handoff, hand = ctx['coop'], ctx['handoff'], ctx['hand']
     last = None
     handoff_error = None
     if handoff:
-        # Safety net for the first multi-GPU run on hardware: if the owner-to-owner transfer raises (on every rank, as an
-        # unavailable peer-to-peer path would: a rank that fails alone leaves its ring neighbours waiting until the process
-        # group's 180 s timeout), all ranks agree to fall back to the same ownership without the hand-off, and the line says so —
-        # better than no scaling line at all.
+        # Safety net for an explicit --mode handoff: if the owner-to-owner transfer raises, all ranks agree (over the control
+        # group) to fall back to the same ownership without the hand-off, and the line says so.
         ok = 1
         try:
-            step_handoff(False)
+            step(False)
             ops.sync()
         except Exception as e:      # noqa: BLE001
             ok, handoff_error = 0, f'{type(e).__name__}: {str(e)[:200]}'
-        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        if ctl_reduce(ok, torch.distributed.ReduceOp.MIN) == 0:
             handoff_error = handoff_error or 'the hand-off failed on another rank'
             handoff = False
-            step = step_independent
+            step = ctx['step_independent']
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -829,19 +878,6 @@ def main():
         last = step(True)
     barrier()
     dt = time.perf_counter() - t0
-    independent_value = None
-    if handoff:
-        # the same ownership without the hand-off, a few steps outside the contract's timed region, for comparison
-        k2 = max(2, min(4, args.steps))
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            step_independent(False)
-        barrier()
-        dt2 = time.perf_counter() - t1
-        t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        independent_value = n_layers_block * world * k2 / float(t.item())
     # deferred positive-definiteness check of the factorisations (the classes check once per subset; here after timing)
     def _infos(o):
         if isinstance(o, dict):
@@ -855,10 +891,46 @@ def main():
     bad = [int(t.item()) for t in _infos(last) if int(t.item()) != 0]
     if bad:
         raise SystemExit(f'bench.py: a Hessian was not positive definite (leading minors {bad}): results invalid')
+    dt = ctl_reduce(dt, torch.distributed.ReduceOp.MAX) if world > 1 else dt
+    primary_parallelism = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        primary_parallelism = (
+            f'cooperative x{world}: Hessian/activation broadcast + sample-sharded all_reduce, row-sharded column loop' if coop else
+            (f'block-sharded x{world}, every block\'s output ({hand["bytes"] / 2**30:.2f} GiB per step and rank: o_proj\'s quantized '
+             f'weights applied to its calibration input) handed owner-to-owner over RCCL send/recv (xGMI ring), overlapped with '
+             f'the next step' if handoff else f'layer-sharded x{world}, no data-path traffic'))
+
+    # ---- secondary values of the N > 1 default, outside the timed region
+    secondary = {}
+    if auto:
+        last = None
+        release(ctx)
+        k2 = max(2, min(4, args.steps))
+        for m in ('handoff', 'cooperative'):
+            val, err = None, None
+            ok = 1
+            try:
+                step2, ctx2 = prepare(m)
+                step2(False)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(k2):
+                    step2(False)
+                barrier()
+                val = time.perf_counter() - t1
+            except Exception as e:      # noqa: BLE001
+                ok, err = 0, f'{type(e).__name__}: {str(e)[:200]}'
+            ok = ctl_reduce(ok, torch.distributed.ReduceOp.MIN)
+            if ok:
+                t = ctl_reduce(val, torch.distributed.ReduceOp.MAX)
+                layers2 = n_layers_block * (1 if m == 'cooperative' else world) * k2
+                secondary[m + '_value'] = layers2 / t
+            else:
+                secondary[m + '_error'] = err or 'failed on another rank'
+            try:
+                release(ctx2)
+            except Exception:           # noqa: BLE001
+                pass
 
     # ---- roofline of the dominant kernel (k_syrk4), HIP events on the launch stream, this rank
     fl = sum(T * K * (K + 1) for (_, _, _, T, K) in timing)
@@ -905,13 +977,7 @@ def main():
                 'packs_codes': args.variant == 'vllm',
                 'symmetric': cfg.symmetric, 'actorder': cfg.actorder, 'static_groups': cfg.static_groups,
                 'subset_overlap_streams': 0 if (args.dry or coop) else args.overlap,
-                'parallelism': ('single GPU' if world == 1 else
-                                (f'cooperative x{world}: Hessian/activation broadcast + sample-sharded all_reduce, '
-                                 'row-sharded column loop' if coop else
-                                 (f'block-sharded x{world}, calibration activations of every block\'s first input '
-                                  f'({hand["bytes"] / 2**30:.2f} GiB per step and rank) handed owner-to-owner over RCCL '
-                                  'send/recv (xGMI ring), overlapped with compute' if handoff else
-                                  f'layer-sharded x{world}, no data-path traffic'))),
+                'parallelism': 'single GPU' if world == 1 else primary_parallelism,
             },
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
@@ -922,16 +988,17 @@ def main():
                 'achieved_incl_fixup': achieved_fix, 'avg_fixup_ms': ms_fix / max(1, n_launch),
             },
         }
-        if independent_value is not None:
-            out['independent_value'] = independent_value      # layers/s of the same ownership without the hand-off
+        if world > 1:
+            # No number of this script has been measured on more than one GPU yet (no multi-GPU box in rounds 1-4): the modes
+            # are covered by Gloo runs at world sizes 2, 4 and 8 (tests/test_bench_spawn.py) and a 2-GPU RCCL test.
+            out['config']['multi_gpu_status'] = 'unmeasured on hardware before this run'
+            out.update(secondary)    # handoff_value / cooperative_value (layers/s, a few steps each, outside the timed region) or *_error
         if handoff_error is not None:
             out['handoff_error'] = handoff_error              # the run fell back to the ownership without the hand-off
         if world == 1 and not args.no_extras and not args.dry and args.model == 'llama3-8b' and args.variant == 'w_only':
             # free this run's tensors first: the secondary workloads are child processes on the same GPU
-            acts.clear(); weights.clear(); ops.accs.clear(); ops.hwork.clear(); last = None
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
+            last = None
+            release(ctx)
             out['extra'] = run_extras(args)
         if world == 1 and not args.no_cpu_baseline and not args.dry:
             try:
@@ -941,7 +1008,10 @@ def main():
                                        'sample': f'failed: {type(e).__name__}: {e}'}
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.destroy_process_group()
+        try:
+            torch.distributed.destroy_process_group()
+        except Exception:      # noqa: BLE001 (a communicator aborted by a failed secondary measurement)
+            pass
 
 
 if __name__ == '__main__':

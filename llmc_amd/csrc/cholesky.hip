@@ -581,15 +581,12 @@ static size_t gemm6_bytes(int64_t K) {
     return align256(mx);
 }
 
-static constexpr int NBO_ = 4 * NB;     // outer block of the factorisation
-static size_t panel_bytes(int64_t K) { return align256((size_t)NBO_ * (size_t)((K + 3) / 4 * 4) * 4); }
-
 extern "C" size_t llmc_chol_inv_upper_ws_bytes(int64_t K) {
     if (K <= 0) return 0;
     size_t work = align256((size_t)K * K * 4);
     size_t vbuf = align256((size_t)ceil_div64(K, NB) * NB * NB * 4);
     size_t xbuf = align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
-    return work + vbuf + xbuf + gemm6_bytes(K) + panel_bytes(K);     // + the far panel of one outer block (round 4)
+    return work + vbuf + xbuf + gemm6_bytes(K);
 }
 
 extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
@@ -610,24 +607,26 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
     LLMC_LAUNCH_CHECK();
 
-    float* Pbuf = (float*)((char*)G6buf + gemm6_bytes(K));
+    const int nblk = (K + NB - 1) / NB;
     // ---- blocked upper Cholesky Wk = U'^T U', two-level: 128-wide factor steps inside 512-wide outer blocks.
-    // Inside an outer block every step touches only the block's OWN 512 columns (potrf, a 128 x <= 384 panel solve, a
-    // <= 384 x <= 384 update). The rows beyond the block receive ONE symmetric update with Kd = 512 per outer block, which
-    // is where the flops are.
-    // Round 4, the far panel LEFT-LOOKING: the factor rows of the block right of its diagonal, P = U'_bb^-T A[b, far], are
-    // ONE product with the inverse of the block's 512 x 512 factor instead of four panel solves and four in-block updates
-    // over all far columns (eight wide, short-K launches per block at 32-50 TFLOP/s: 10 ms of kernel time per benchmark
-    // step, profiles/r03_kernel_stats.txt). That inverse is the first two doubling levels of the triangular inverse on the
-    // block's diagonal — work the inverse phase did anyway, now done when the block is finished. The product is not done
-    // in place (every output row needs every input row of its column): it goes to a panel buffer and is copied back.
-    const int NBO = NBO_;
+    // Inside an outer block every step updates only the rows of that block (Kd = 128, few rows); the rows
+    // beyond it receive ONE symmetric update with Kd = 512 per outer block, which is where the flops are and
+    // runs the fp32-MFMA GEMM at its long-K efficiency instead of its short-K one (tools/bench_sgemm.py).
+    const int NBO = 4 * NB;
     SideStream* side = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : side_stream_for(st);
     bool pending_side = false;
-    // The large products of K3 (far panels, far updates, triangular-inverse levels >= 512) run as split-bf16 products on the
-    // 16-bit MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
+    // The large products of K3 (far updates, triangular-inverse levels >= 512) run as split-bf16 products on the 16-bit
+    // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
     // the fp32 MFMA path.
     const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
+    const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
+    // Inside an outer block the columns split into NEAR (the block's own, which the next factor step needs) and FAR (all
+    // the columns to its right, needed by the later far panel solves and by the block's far update). The near panel solve
+    // and near update stay on the caller's stream between the diagonal factorisations — three small latency-bound
+    // kernels per step; the far panel solve and far in-block update of the same step (128 x nfar products: the bulk of a
+    // step's work) run on the helper stream behind an event, concurrently with the next steps' chain. Same kernels, same
+    // arithmetic per element and the same order of the updates an element receives (all of step c before step c + 1 on
+    // either stream), so the factor is bit-identical with or without the helper stream.
     auto panel_solve = [&](const float* Vb, int c0, int nb, int col0, int ncols, hipStream_t s_) -> int {
         if (ncols <= 0) return LLMC_OK;
         float* P = Wk + (size_t)c0 * K + col0;     // rows c0..c0+nb, cols col0..col0+ncols
@@ -650,70 +649,6 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         u.epilogue = SG_SUB; u.c_upper_only = col0 == c0 + nb ? 1 : 0; u.batch = 1;   // the far columns lie right of every row
         return sgemm_launch(u, true, false, s_);
     };
-    // pairs [z0, z1) of doubling level h of the triangular inverse, in place in Wk (X through Xbuf):
-    //   [[A, C], [0, B]]^-1 = [[A^-1, -A^-1 C B^-1], [0, B^-1]] with A^-1, B^-1 already in place
-    int launched[32] = {};                 // pairs of level li (h = NB << li) done so far
-    auto pair_count = [&](int64_t h) { return (int)((K - h + 2 * h - 1) / (2 * h)); };
-    auto launch_pairs = [&](int64_t h, int z0, int z1, hipStream_t s_) -> int {
-        const int npairs = pair_count(h);
-        const int64_t o_last = (int64_t)(npairs - 1) * 2 * h;
-        const int n2_last = (int)((K - o_last - h) < h ? (K - o_last - h) : h);
-        const int64_t stride = 2 * h * ((int64_t)K + 1);
-        const bool has_last = z1 == npairs;
-        const int n2b = has_last ? n2_last : (int)h;
-        const int cnt = z1 - z0;
-        // X is [h x n2]: with one pair its leading dimension shrinks to n2 (keeps X within K^2/4 floats)
-        const int64_t ldX = (cnt == 1 && has_last) ? ((n2_last + 3) / 4) * 4 : h;
-        const bool lvl_x3 = k3_x3 && h >= 512;   // small levels are latency-bound: the fp32 kernels stay
-        // large, deep levels: operands split once into stacked bf16 planes, product on the one-wave-per-SIMD GEMM
-        const bool lvl_g6 = lvl_x3 && use_g6 && h >= GEMM6_MIN_H && h % 256 == 0 && n2_last % 256 == 0;
-        if (lvl_g6) {
-            for (int z = z0; z < z1; ++z) {
-                const int n2 = z == npairs - 1 ? n2_last : (int)h;
-                int rc = gemm6_launch(Wk + z * stride, K, Wk + h + z * stride, K, Xbuf, ldX, (int)h, n2, (int)h, 1, 0, 1.0f,
-                                      G6buf, s_);
-                if (rc) return rc;
-                rc = gemm6_launch(Xbuf, ldX, Wk + h * ((int64_t)K + 1) + z * stride, K, Wk + h + z * stride, K, (int)h, n2,
-                                  n2, 0, 1, -1.0f, G6buf, s_);
-                if (rc) return rc;
-            }
-            return LLMC_OK;
-        }
-        SgemmArgs x{};
-        x.A = Wk + z0 * stride; x.lda = K; x.sA = stride;                 // A^-1 at (o, o), upper
-        x.B = Wk + h + z0 * stride; x.ldb = K; x.sB = stride;             // C at (o, o+h)
-        x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
-        x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2b; x.Kd = x.Kd_last = (int)h;
-        x.epilogue = SG_SET; x.a_upper = 1; x.batch = cnt;
-        int rc = lvl_x3 ? gemm3_launch(x, false, s_) : sgemm_launch(x, false, false, s_);
-        if (rc) return rc;
-        SgemmArgs y{};                                                    // C = -X B^-1
-        y.A = Xbuf; y.lda = ldX; y.sA = h * h;
-        y.B = Wk + h * ((int64_t)K + 1) + z0 * stride; y.ldb = K; y.sB = stride;   // B^-1 at (o+h, o+h), upper
-        y.C = Wk + h + z0 * stride; y.ldc = K; y.sC = stride;
-        y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2b; y.Kd = (int)h; y.Kd_last = n2b;
-        y.epilogue = SG_NEG; y.b_upper = 1; y.batch = cnt;
-        return lvl_x3 ? gemm3_launch(y, false, s_) : sgemm_launch(y, false, false, s_);
-    };
-    // every pair of level h that lies inside rows [0, upto) and is not done yet
-    auto launch_ready = [&](int64_t h, int li, int upto, hipStream_t s_) -> int {
-        const int npairs = pair_count(h);
-        int z1 = launched[li];
-        while (z1 < npairs) {
-            const int64_t o = (int64_t)z1 * 2 * h;
-            if ((o + 2 * h < K ? o + 2 * h : K) > upto) break;
-            ++z1;
-        }
-        if (z1 == launched[li]) return LLMC_OK;
-        int rc = launch_pairs(h, launched[li], z1, s_);
-        launched[li] = z1;
-        return rc;
-    };
-    const bool lvl_zero_subdiag = k3_x3 && use_g6 && K > GEMM6_MIN_H;
-    if (lvl_zero_subdiag) {     // gemm6 reads triangular operands at 256 granularity; nothing below writes under the diagonal
-        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
-        LLMC_LAUNCH_CHECK();
-    }
     for (int k0 = 0; k0 < K; k0 += NBO) {
         const int nbo = K - k0 < NBO ? K - k0 : NBO;
         const int oend = k0 + nbo;
@@ -725,50 +660,46 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
             hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), (NB * PLD + 32 * PLD + 64) * sizeof(float), st, Wk, (int64_t)K, c0,
                                nb, Vb, info_dev);
             LLMC_LAUNCH_CHECK();
-            if (oend - c0 - nb <= 0) break;
-            int rc = panel_solve(Vb, c0, nb, c0 + nb, oend - (c0 + nb), st);
+            if (K - c0 - nb <= 0) break;
+            const int nnear = oend - (c0 + nb);
+            if (!side || nfar <= 0) {
+                // one stream: near and far columns in ONE panel solve and ONE update per step (the split costs two more
+                // launches per step, 1.3 ms over a K = 14336 factorisation, and buys nothing without a second stream)
+                int rc = panel_solve(Vb, c0, nb, c0 + nb, K - c0 - nb, st);
+                if (rc) return rc;
+                rc = inblock_update(c0, nb, oend, c0 + nb, K - c0 - nb, st);
+                if (rc) return rc;
+                continue;
+            }
+            int rc = panel_solve(Vb, c0, nb, c0 + nb, nnear, st);
             if (rc) return rc;
-            if ((rc = inblock_update(c0, nb, oend, c0 + nb, oend - (c0 + nb), st))) return rc;
-        }
-        // the block's diagonal 512 x 512 of the inverse: inverted 128-blocks in place, then the levels inside the block.
-        // (The factor entries they overwrite have no reader left: the far panel below uses the inverse, not the factor.)
-        {
-            const int b0 = k0 / NB, nbk = (nbo + NB - 1) / NB;
-            hipLaunchKernelGGL(k_place_diag_inv, dim3(nbk), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf, b0);
-            LLMC_LAUNCH_CHECK();
-            int li = 0;
-            for (int64_t h = NB; 2 * h <= NBO && h < K; h *= 2, ++li)
-                if (int rc = launch_ready(h, li, oend, st)) return rc;
+            rc = fork_to_side(side, st);      // the far part of this step: behind the near panel, beside the rest of the chain
+            if (rc) return rc;
+            pending_side = true;
+            rc = panel_solve(Vb, c0, nb, oend, nfar, side->side);
+            if (rc) return rc;
+            rc = inblock_update(c0, nb, oend, oend, nfar, side->side);
+            if (rc) return rc;
+            rc = inblock_update(c0, nb, oend, c0 + nb, nnear, st);
+            if (rc) return rc;
         }
         if (nfar > 0) {
-            // far panel P = V_bb^T A[block rows, far cols] (V_bb upper: op(A)[i][k] = V[k][i] is lower triangular)
-            const int64_t ldp = ((int64_t)nfar + 3) / 4 * 4;
-            SgemmArgs g{};
-            g.A = Wk + (size_t)k0 * K + k0; g.lda = K;
-            g.B = Wk + (size_t)k0 * K + oend; g.ldb = K;
-            g.C = Pbuf; g.ldc = ldp;
-            g.M = g.M_last = nbo; g.N = g.N_last = nfar; g.Kd = g.Kd_last = nbo;
-            g.epilogue = SG_SET; g.a_lower = 1; g.batch = 1;
-            int rc = k3_x3 ? gemm3_launch(g, true, st) : sgemm_launch(g, true, false, st);
-            if (rc) return rc;
-            LLMC_HIP_CHECK(hipMemcpy2DAsync(Wk + (size_t)k0 * K + oend, (size_t)K * 4, Pbuf, (size_t)ldp * 4, (size_t)nfar * 4,
-                                            (size_t)nbo, hipMemcpyDeviceToDevice, st));
             // far trailing update T -= P^T P with P = rows k0..oend, cols oend..K (Kd = nbo), in two parts: the rows
             // of the NEXT outer block on the main stream (its factor steps need them), the rows below on the side
             // stream, overlapped with the next outer block's latency-bound diagonal / panel kernels.
             float* P = Wk + (size_t)k0 * K + oend;
             const int m1 = nfar < NBO ? nfar : NBO;
+            if (side && pending_side) {          // the block's far panels (and the previous block's side update) are complete
+                int rc = join_from_side(side, st);
+                if (rc) return rc;
+                pending_side = false;
+            }
             SgemmArgs u{};
             u.A = P; u.lda = K; u.B = P; u.ldb = K;
             u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
             u.M = u.M_last = m1; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
             u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
-            if (side && pending_side) {          // the previous block's side update wrote the rows updated next
-                rc = join_from_side(side, st);
-                if (rc) return rc;
-                pending_side = false;
-            }
-            rc = k3_x3 ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
+            int rc = use_x3u ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
             if (rc) return rc;
             const int m2 = nfar - m1;
             if (m2 > 0) {
@@ -780,11 +711,11 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
                 if (side) {
                     rc = fork_to_side(side, st);   // P is final on main at this point
                     if (rc) return rc;
-                    rc = k3_x3 ? gemm3_tn_launch(v, side->side) : sgemm_launch(v, true, false, side->side);
+                    rc = use_x3 ? gemm3_tn_launch(v, side->side) : sgemm_launch(v, true, false, side->side);
                     if (rc) return rc;
                     pending_side = true;
                 } else {
-                    rc = k3_x3 ? gemm3_tn_launch(v, st) : sgemm_launch(v, true, false, st);
+                    rc = use_x3 ? gemm3_tn_launch(v, st) : sgemm_launch(v, true, false, st);
                     if (rc) return rc;
                 }
             }
@@ -794,11 +725,56 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         int rc = join_from_side(side, st);
         if (rc) return rc;
     }
-    // ---- V = U'^-1: the doubling levels above the outer blocks (the levels inside them are done)
-    {
-        int li = 0;
-        for (int64_t h = NB; h < K; h *= 2, ++li)
-            if (int rc = launch_ready(h, li, K, st)) return rc;
+    (void)nblk;
+    // ---- V = U'^-1: inverted diagonal blocks, then doubling levels
+    hipLaunchKernelGGL(k_place_diag_inv, dim3((K + NB - 1) / NB), dim3(256), 0, st, Wk, (int64_t)K, K, (const float*)Vbuf, 0);
+    LLMC_LAUNCH_CHECK();
+    if (use_x3t && use_g6 && K > GEMM6_MIN_H) {
+        hipLaunchKernelGGL(k_zero_subdiag, dim3((K + 255) / 256), dim3(256), 0, st, Wk, (int64_t)K, K);
+        LLMC_LAUNCH_CHECK();
+    }
+    for (int64_t h = NB; h < K; h *= 2) {
+        const int npairs = (int)((K - h + 2 * h - 1) / (2 * h));  // pairs with a non-empty right block
+        if (npairs <= 0) break;
+        const int64_t o_last = (int64_t)(npairs - 1) * 2 * h;
+        const int n2_last = (int)((K - o_last - h) < h ? (K - o_last - h) : h);
+        const int64_t stride = 2 * h * ((int64_t)K + 1);
+        // X = A^-1 C
+        SgemmArgs x{};
+        x.A = Wk; x.lda = K; x.sA = stride;                 // A^-1 at (o, o), upper
+        x.B = Wk + h; x.ldb = K; x.sB = stride;             // C at (o, o+h)
+        // X is [h x n2]: with one pair its leading dimension shrinks to n2 (keeps X within K^2/4 floats)
+        const int64_t ldX = npairs == 1 ? ((n2_last + 3) / 4) * 4 : h;
+        x.C = Xbuf; x.ldc = ldX; x.sC = h * h;
+        x.M = x.M_last = (int)h; x.N = (int)h; x.N_last = n2_last; x.Kd = x.Kd_last = (int)h;
+        x.epilogue = SG_SET; x.a_upper = 1; x.batch = npairs;
+        const bool lvl_x3 = use_x3t && h >= 512;   // small levels are latency-bound: the fp32 kernels stay
+        // large, deep levels: operands split once into stacked bf16 planes, product on the one-wave-per-SIMD GEMM
+        const bool lvl_g6 = lvl_x3 && use_g6 && h >= GEMM6_MIN_H && h % 256 == 0 && n2_last % 256 == 0;
+        int rc = LLMC_OK;
+        if (lvl_g6) {
+            for (int z = 0; z < npairs && !rc; ++z) {
+                const int n2 = z == npairs - 1 ? n2_last : (int)h;
+                rc = gemm6_launch(x.A + z * stride, K, x.B + z * stride, K, Xbuf + (int64_t)z * h * h, ldX, (int)h, n2, (int)h,
+                                  1, 0, 1.0f, G6buf, st);
+                if (rc) return rc;
+                rc = gemm6_launch(Xbuf + (int64_t)z * h * h, ldX, Wk + h * ((int64_t)K + 1) + z * stride, K,
+                                  Wk + h + z * stride, K, (int)h, n2, n2, 0, 1, -1.0f, G6buf, st);
+            }
+            if (rc) return rc;
+            continue;
+        }
+        rc = lvl_x3 ? gemm3_launch(x, false, st) : sgemm_launch(x, false, false, st);
+        if (rc) return rc;
+        // C = -X B^-1
+        SgemmArgs y{};
+        y.A = Xbuf; y.lda = ldX; y.sA = h * h;
+        y.B = Wk + h * ((int64_t)K + 1); y.ldb = K; y.sB = stride;   // B^-1 at (o+h, o+h), upper
+        y.C = Wk + h; y.ldc = K; y.sC = stride;
+        y.M = y.M_last = (int)h; y.N = (int)h; y.N_last = n2_last; y.Kd = (int)h; y.Kd_last = n2_last;
+        y.epilogue = SG_NEG; y.b_upper = 1; y.batch = npairs;
+        rc = lvl_x3 ? gemm3_launch(y, false, st) : sgemm_launch(y, false, false, st);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);
     LLMC_LAUNCH_CHECK();

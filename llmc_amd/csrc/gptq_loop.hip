@@ -428,18 +428,11 @@ __global__ __launch_bounds__(NT) void k_gptq_block(GptqBlockArgs a) {
 
 using namespace llmc;
 
-static constexpr int GRP_MAX = 8;
-// 128-column blocks per outer group (far updates are applied once per group). LLMC_K4_GRP=8: half as many, twice as deep
-// far updates (fewer passes over the far columns) against wider near updates; the arithmetic per element is the same.
-static inline int k4_grp() {
-    const char* e = getenv("LLMC_K4_GRP");
-    const int g = e ? atoi(e) : 4;
-    return g == 8 ? 8 : g == 2 ? 2 : 4;
-}
+static constexpr int GRP = 4;  // 128-column blocks per outer group (far updates are applied once per group; 8 measured the same: 12.4 vs 12.6 ms)
 
 extern "C" size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K) {
     if (R <= 0 || K <= 0) return 0;
-    return 3 * (size_t)R * BS * GRP_MAX * sizeof(float);   // err columns of three groups in flight (pipelined far updates)
+    return 3 * (size_t)R * BS * GRP * sizeof(float);   // err columns of three groups in flight (pipelined far updates)
 }
 
 extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
@@ -477,7 +470,6 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
         LLMC_REQUIRE(col_group != nullptr, "gptq_quantize: col_group required with static groups");
     }
     hipStream_t caller = (hipStream_t)stream;
-    const int GRP = k4_grp();
     const int ELD = BS * GRP;
     float* ErrBuf[3] = {(float*)ws, (float*)ws + (size_t)R * ELD, (float*)ws + 2 * (size_t)R * ELD};   // [R, GRP*128] x 3
     // Round 4 schedule. The caller's stream carries the CHAIN: per 128-column block the in-block kernel and the update of the

@@ -189,3 +189,38 @@ def _to_cpu(p):
     if isinstance(p, (list, tuple)):
         return type(p)(_to_cpu(v) for v in p)
     return p
+
+
+def plan_memory(groups, n_seq, seq_len, world, mode, act_bytes=2):
+    """Per-rank device memory (bytes, the worst rank) of one bench / quantization step, by item. `groups` = [(input name, K,
+    [(layer, R), ...]), ...] as bench.block_groups; mode: 'independent' | 'handoff' | 'cooperative'. Workspace sizes come from
+    the library's own `*_ws_bytes` queries (pure host calls), so this runs without a GPU: the check that BASELINE configs[3]
+    (Llama-3-70B shapes, 8 x MI355X) fits 288 GB per GPU before anyone has an 8-GPU node to try it on.
+      activations   the resident calibration input of every distinct subset input (sample-sharded subsets hold n_seq / world)
+      hessians      H [K, K] fp32 per subset + the permuted / damped work copy
+      syrk partial  k_syrk4's partial tiles of the widest launch
+      factor ws     llmc_chol_inv_upper workspace of the widest subset (one per concurrently factored subset)
+      loop ws       llmc_gptq_quantize workspace + fp32 stacked weights in / out + losses
+      hand-off      the three [n_seq, seq, hidden] buffers of --mode handoff"""
+    from llmc_amd import _ffi
+    L = _ffi.lib()
+    T = n_seq * seq_len
+    items = {'activations': 0, 'hessians': 0, 'syrk_partials': 0, 'factor_ws': 0, 'loop_ws': 0, 'weights': 0, 'handoff': 0}
+    coop = mode == 'cooperative' and world > 1
+    for name, K, layers in groups:
+        R = sum(r for _, r in layers)
+        sample = coop and K > 8192
+        n_mine = -(-n_seq // world) if sample else n_seq
+        holds = (not coop) or sample or True        # rank 0 holds the broadcast inputs; receivers allocate the same size
+        if holds:
+            items['activations'] += n_mine * seq_len * K * act_bytes
+        items['hessians'] += 2 * K * K * 4
+        items['syrk_partials'] = max(items['syrk_partials'], int(L.llmc_hessian_accum_ws_bytes(n_mine * seq_len, K, K)))
+        items['factor_ws'] += int(L.llmc_chol_inv_upper_ws_bytes(K)) + K * K * 4       # the four subsets' chains run side by side
+        rows = -(-R // world) if sample else R
+        items['loop_ws'] += int(L.llmc_gptq_quantize_ws_bytes(rows, K)) + 3 * rows * K * 4
+        items['weights'] += R * K * act_bytes
+    if mode == 'handoff' and world > 1:
+        items['handoff'] = 3 * T * groups[0][1] * act_bytes
+    items['total'] = sum(items.values())
+    return items

@@ -1,5 +1,5 @@
-"""bench.py's multi-rank plumbing without a GPU: `--gpus 2 --dry` self-spawns two ranks (gloo), runs the independent, hand-off and
-cooperative steps with CPU stand-ins, and prints the contract's JSON line with n_gpus = 2."""
+"""bench.py's multi-rank plumbing without a GPU: `--gpus N --dry` self-spawns N ranks (Gloo; N = 2, 4, 8), runs the independent,
+hand-off and cooperative steps with CPU stand-ins, and prints the contract's JSON line with n_gpus = N."""
 import json
 import os
 import subprocess
@@ -10,44 +10,72 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(extra, env_extra=None):
+def run(extra, env_extra=None, gpus=2):
     env = dict(os.environ)
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry', '--steps', '2',
-                        '--warmup', '1'] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--dry', '--steps', '2',
+                        '--warmup', '1'] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize('mode', ['independent', 'cooperative', 'handoff', None])
-def test_self_spawn_two_ranks_dry(mode):
-    j = run(['--mode', mode] if mode else [])            # no flag: the N > 1 default = handoff
-    assert j['n_gpus'] == 2 and j['steps'] == 2 and j['warmup'] == 1
+def check_contract(j, gpus):
+    assert j['n_gpus'] == gpus and j['steps'] == 2 and j['warmup'] == 1
     assert j['unit'] == 'layers/s' and j['value'] > 0 and j['higher_is_better'] is True
-    assert j['scaling'] == ('strong' if mode == 'cooperative' else 'weak')
     assert 'dry-run' in j['data']
     for k in ('metric', 'ms_per_step', 'vs_baseline', 'dtype', 'config', 'roofline'):
         assert k in j
+    assert 'unmeasured on hardware' in j['config']['multi_gpu_status']
+
+
+@pytest.mark.parametrize('mode', ['independent', 'cooperative', 'handoff'])
+def test_self_spawn_two_ranks_dry(mode):
+    j = run(['--mode', mode])
+    check_contract(j, 2)
+    assert j['scaling'] == ('strong' if mode == 'cooperative' else 'weak')
     if mode == 'cooperative':
         assert 'cooperative x2' in j['config']['parallelism']
-    if mode in ('handoff', None):
-        # block-sharded with the owner-to-owner hand-off of the calibration activations over send/recv, plus the same
-        # ownership without the hand-off measured after the timed region
-        assert 'handed owner-to-owner' in j['config']['parallelism'] and j['independent_value'] > 0
+    if mode == 'handoff':
+        # block-sharded with the owner-to-owner hand-off of a block's output over send/recv
+        assert 'handed owner-to-owner' in j['config']['parallelism']
     if mode == 'independent':
-        assert 'independent_value' not in j
+        assert 'no data-path traffic' in j['config']['parallelism']
+    assert 'handoff_value' not in j and 'cooperative_value' not in j        # an explicit mode measures that mode only
 
 
-def test_handoff_failure_falls_back_to_the_same_ownership_without_it():
-    """The safety net of the first multi-GPU run: the transfer raising (on every rank, like an unavailable peer-to-peer path)
-    makes the ranks agree to continue with the same ownership without the hand-off; the line carries the reason."""
+@pytest.mark.parametrize('gpus', [2, 4, 8])
+def test_default_mode_carries_the_contract_value_and_both_partitions(gpus):
+    """No --mode with N > 1 (what the driver's scaling run launches): `value` comes from block-sharded ownership without
+    data-path traffic (it cannot wedge), and ONE line also carries handoff_value (block outputs handed owner-to-owner) and
+    cooperative_value (north_star's partition: one block shared by all ranks) measured outside the timed region. World sizes
+    4 and 8 run the same collectives the 8-GPU node will (Gloo here): broadcast, all_reduce, batched send/recv, ring."""
+    j = run([], gpus=gpus)
+    check_contract(j, gpus)
+    assert j['scaling'] == 'weak' and 'no data-path traffic' in j['config']['parallelism']
+    assert j['handoff_value'] > 0 and j['cooperative_value'] > 0
+    assert 'handoff_error' not in j and 'cooperative_error' not in j
+
+
+@pytest.mark.parametrize('gpus', [4, 8])
+def test_cooperative_mode_at_node_world_sizes(gpus):
+    j = run(['--mode', 'cooperative'], gpus=gpus)
+    check_contract(j, gpus)
+    assert j['scaling'] == 'strong' and f'cooperative x{gpus}' in j['config']['parallelism']
+
+
+def test_failing_handoff_is_recorded_and_does_not_take_the_line_down():
+    """The safety net of the first multi-GPU run. Default mode: the hand-off raising (on every rank, like an unavailable
+    peer-to-peer path) costs only `handoff_value`: the contract value and cooperative_value are still there, the reason is
+    in handoff_error. Explicit --mode handoff: the ranks agree (over the Gloo control group) to continue with the same
+    ownership without the hand-off."""
     j = run([], {'LLMC_BENCH_DRY_FAIL_HANDOFF': '1'})
     assert j['n_gpus'] == 2 and j['value'] > 0 and j['scaling'] == 'weak'
-    assert 'handoff_error' in j and 'no data-path traffic' in j['config']['parallelism']
-    assert 'independent_value' not in j
+    assert 'handoff_error' in j and 'handoff_value' not in j and j['cooperative_value'] > 0
+    j = run(['--mode', 'handoff'], {'LLMC_BENCH_DRY_FAIL_HANDOFF': '1'})
+    assert j['value'] > 0 and 'handoff_error' in j and 'no data-path traffic' in j['config']['parallelism']
 
 
 def test_single_rank_needs_a_gpu_or_dry():

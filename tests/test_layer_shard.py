@@ -1,5 +1,6 @@
 """Multi-rank orchestration of the layer-sharded path, world_size 2 over Gloo on CPU. The compute callback is a
 stand-in (the product's kernels need a GPU); what is checked is ownership, the broadcast and the ordered gather."""
+import pytest
 import os
 import socket
 
@@ -95,3 +96,20 @@ def test_ownership_is_a_partition():
             assert all(owner_of(u, world) == r for r in range(world) for u in units_of(r, n, world))
             sizes = [len(units_of(r, n, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('model', ['llama3-8b', 'llama3-70b'])
+@pytest.mark.parametrize('mode', ['independent', 'handoff', 'cooperative'])
+def test_per_rank_memory_plan_fits_an_mi355x(model, mode):
+    """BASELINE configs[3] before there is an 8-GPU node to run it on: per-rank memory of a step from the library's own
+    workspace queries (70B down_proj: 14 GiB of activations, a 3.1-GiB Hessian, its factor workspace, the partial tiles)."""
+    import bench
+    from llmc_amd.dist.layer_shard import plan_memory
+    groups = bench.block_groups(model)
+    plan = plan_memory(groups, 128, 2048, 8, mode)
+    gib = {k: v / 2 ** 30 for k, v in plan.items()}
+    assert plan['total'] < 0.85 * 288e9, gib
+    if model == 'llama3-70b':
+        assert gib['activations'] > (10 if mode != 'cooperative' else 4) and gib['hessians'] > 7, gib
+    one = plan_memory(groups, 128, 2048, 1, 'independent')
+    assert one['total'] >= plan['total'] - plan['handoff'] - 1 or mode != 'cooperative'
