@@ -346,17 +346,6 @@ int llmc_clamp_groups(void* W, int dt, int64_t R, int64_t K, int64_t g, const vo
                       const void* max_val, llmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Test hooks (tests/test_gptq_gpu.py only): the internal fp32-MFMA GEMM used by K3/K4, and the split-bf16 GEMM
- * (C (op) op(A) B, TA / epilogue / hints as in llmc_test_sgemm, three bf16 terms per operand, six products) used by K3.
- * C (op) op(A)[M x Kd] . op(B)[Kd x N]; epilogue 0: C -= AB, 1: C = AB, 2: C = -AB.
- * ---------------------------------------------------------------------------------------------- */
-int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M,
-                    int N, int Kd, int TA, int TB, int epilogue, int a_upper, int a_lower, int b_upper,
-                    int c_upper_only, llmc_stream_t stream);
-int llmc_test_gemm3(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
-                    int Kd, int TA, int epilogue, int a_upper, int b_upper, int c_upper_only, llmc_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------
  * FP8 block-wise (DeepSeek-V3 style): llmc/compression/quantization/kernel.py (Triton) and FloatQuantizer `per_block`
  * ------------------------------------------------------------------------------------------------ */
 /* weight_cast_to_fp8 (kernel.py:58-86; quant.py:33-43) and FloatQuantizer per_block fake / real quant

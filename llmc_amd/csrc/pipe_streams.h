@@ -1,16 +1,20 @@
-// pipe_streams.h — helper streams of the pipelined K3 / K4 schedules (round 4).
+// pipe_streams.h — helper streams of the pipelined K4 schedule (round 4).
 //
-// K3 and K4 are a latency-bound CHAIN (diagonal-block factor / in-block column kernel, a few small kernels per step) plus
-// throughput-bound BULK products (far updates, triangular-inverse levels) that depend on the chain only block by block.
-// Three helper streams per caller stream:
-//   fast   medium-sized work the chain needs within a block time (far panel solves, the next block's rows of a far update)
-//   bulk   the large far updates
-//   inv    the triangular-inverse levels (K3), run behind the factorisation instead of after it
-// The helpers are created with a CU MASK (hipExtStreamCreateWithCUMask) that leaves two compute units of every XCD out, so
-// the chain's small kernels on the caller's stream always find a free CU instead of queueing behind a far update's
-// workgroups (round 3 measured a chain kernel waiting 515 us for a slot: profiles/r03_k3k4_timeline.txt). LLMC_SIDE_CU_MASK=0
-// creates plain lowest-priority streams instead. Everything is fenced back into the caller's stream before the entry point
-// returns: the C ABI contract (complete, in stream order, on the stream passed in) is unchanged.
+// K4 is a latency-bound CHAIN (the in-block column kernel and the update of its group's columns, per 128-column block) plus a
+// throughput-bound BULK product (the far update of everything beyond the next group) that depends on the chain only group
+// by group. The bulk product runs on a helper stream of its own, the columns the chain needs next first.
+// Measured on MI355X (gpurun_out/r04c, r04e; profiles/r04_stream_experiments.txt):
+//   * plain non-blocking helper streams: K4 of down_proj 12.1 -> 10.9-11.4 ms; the same structure for K3 (three helper
+//     streams, the inverse behind the factorisation) measured EQUAL to the single-stream schedule (21.9 ms) and was removed:
+//     K3's "latency-bound" steps are wide, inefficient kernels that already occupy every CU;
+//   * CU-MASKED helpers (hipExtStreamCreateWithCUMask leaving two CUs per XCD to the chain; LLMC_SIDE_CU_MASK=1): the mask
+//     works (240 of 256 CUs used; a small kernel beside a saturating one starts in 10 us instead of 21 us) but buys nothing
+//     end to end, and masked streams are BLOCKING streams — their mere existence slows every launch on the NULL stream
+//     (PyTorch's default stream): K3 called there went from 21 to 32 ms. Off by default;
+//   * a HIGH-priority chain stream makes everything slower (21.9 -> 32.1 ms): the bulk product's waves are evicted for
+//     every small chain kernel.
+// Everything is fenced back into the caller's stream before the entry point returns: the C ABI contract (complete, in stream
+// order, on the stream passed in) is unchanged.
 #pragma once
 #include <stdlib.h>
 #include <map>
@@ -27,6 +31,7 @@ struct PipeStreams {
     hipEvent_t ev[NEV] = {};
     int next = 0;
     bool ok = false;
+    bool masked = false;
 
     // a fresh event recorded on `s`. The pool is a ring: an event is re-recorded NEV records later; every wait on it is
     // enqueued within a few outer blocks (< 64 records), and a wait captures the record that precedes it.
@@ -82,7 +87,8 @@ inline PipeStreams* pipe_streams_for(hipStream_t main_st) {
     PipeStreams* p = new PipeStreams();
     pool[key] = p;
     const char* e = getenv("LLMC_SIDE_CU_MASK");
-    const bool masked = !(e && e[0] == '0');
+    const bool masked = e && e[0] == '1';
+    p->masked = masked;
     if (!pipe_make_stream(&p->fast, masked) || !pipe_make_stream(&p->bulk, masked) || !pipe_make_stream(&p->inv, masked))
         return nullptr;
     // NORMAL priority: a high-priority chain stream made everything slower (K3 32.1 ms against 21.9 with the chain on the
@@ -95,10 +101,9 @@ inline PipeStreams* pipe_streams_for(hipStream_t main_st) {
     return p;
 }
 
-// The stream the chain runs on. CU-masked streams are created without hipStreamNonBlocking (the API has no flags), i.e.
-// they synchronise implicitly with the NULL stream: every launch on the NULL stream would wait for the helpers' queued
-// work and the pipeline would collapse into issue order. A caller on the NULL stream (PyTorch's default stream) therefore
-// gets the chain on an internal non-blocking stream, fenced in at the start and back out at the end by events.
-inline hipStream_t pipe_chain_stream(PipeStreams* ps, hipStream_t st) { return st == nullptr ? ps->chain : st; }
+// The stream the chain runs on: the caller's. Only with CU-masked helpers (blocking streams, see above) a caller on the NULL
+// stream gets the chain on an internal non-blocking stream, fenced in at the start and back out at the end by events —
+// otherwise every chain launch would wait for the helpers' queued work and the pipeline would collapse into issue order.
+inline hipStream_t pipe_chain_stream(PipeStreams* ps, hipStream_t st) { return (st == nullptr && ps->masked) ? ps->chain : st; }
 
 }  // namespace llmc

@@ -9,6 +9,8 @@ from conftest import ROOT
 
 def header_symbols():
     txt = open(os.path.join(ROOT, 'include', 'llmc_hip.h')).read()
+    assert 'llmc_test_' not in txt                      # test hooks live in include/llmc_hip_test.h, not in the product header
+    txt += open(os.path.join(ROOT, 'include', 'llmc_hip_test.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(llmc_[a-z0-9_]+)\s*\(', txt)))
 
