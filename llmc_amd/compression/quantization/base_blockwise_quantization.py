@@ -6,7 +6,7 @@ In scope: quantizer selection, collect_block_qparams, the block
 true_sequential re-hooking and quant_out, apply_scale (LN->fc and fc->fc), scaling_input/update_input_feat,
 static per-tensor activation qparams, deploy to fake / real-quant wrappers. Out of scope and rejected loudly:
 rotations (QuaRot), KV-cache quantization, quantized attention / act-fn modules, token reduction, FP8
-block-wise checkpoints (DeepSeek), mixed-precision ignored_layers.
+block-wise checkpoints (DeepSeek). Mixed precision (`ignored_layers`) is in since round 4.
 """
 import copy
 import functools
@@ -74,9 +74,17 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
     # ---- configuration (base_…:133-300) ------------------------------------------------------------
     def set_quant_config(self):
         qc = self.quant_config
+        # mixed precision (base_blockwise_quantization.py:137-144): layers named here stay in floating point at deploy time
+        # (set_no_quant_layer marks them `no_quant`, the model adapter's replace_module_subset skips marked modules,
+        # models/base_model.py:433-435). They are still calibrated / transformed like the reference does.
         if 'ignored_layers' in self.config:
-            raise NotImplementedError('mixed precision (ignored_layers) is outside the hot path')
-        self.mixed_precision = False
+            il = self.config['ignored_layers']
+            self.mixed_precision = True
+            self.ignored_block_ids = _get(il, 'block_ids', []) or []
+            self.ignored_layer_names = _get(il, 'layer_names', []) or []
+            self.ignored_speical_names = _get(il, 'speical_names', []) or []      # (spelling as in the reference)
+        else:
+            self.mixed_precision = False
         self.quant_out = _get(qc, 'quant_out', False)
         self.tp = _get(qc, 'tp', 1)
 
@@ -371,6 +379,26 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
                 input_feat[name][i] = done[key]
 
     # ---- deploy / save (base_…:933-1038) ---------------------------------------------------------------
+    def set_no_quant_layer(self):
+        """base_blockwise_quantization.py:910-932: `block_ids` (ints or 'a-b' ranges) x `layer_names` inside a block, or full
+        names `<block_name_prefix>.<idx>.<name>` in `speical_names`, get a `no_quant` buffer."""
+        import re
+        if self.ignored_speical_names:
+            assert hasattr(self.model, 'block_name_prefix'), 'block_name_prefix missing in model'
+        ids = []
+        for item in self.ignored_block_ids:
+            m = re.match(r'(\d+)-(\d+)', str(item))
+            if m:
+                ids.extend(range(int(m.group(1)), int(m.group(2)) + 1))
+            else:
+                ids.append(int(item))
+        for idx, block in enumerate(self.blocks):
+            for n, m in block.named_modules():
+                if idx in ids and n in self.ignored_layer_names:
+                    m.register_buffer('no_quant', torch.tensor(True))
+                elif self.ignored_speical_names and f'{self.model.block_name_prefix}.{idx}.{n}' in self.ignored_speical_names:
+                    m.register_buffer('no_quant', torch.tensor(True))
+
     @torch.no_grad()
     def deploy(self, quant_format, keep_device=False):
         mapping = {'origin_float': OriginFloatLinear, 'fake_quant': EffcientFakeQuantLinear,
@@ -378,6 +406,8 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
         mapping.update(_REALQUANT_LINEAR_MAP_)
         if quant_format not in mapping:
             raise NotImplementedError(f"Quant format '{quant_format}' is not implemented.")
+        if self.mixed_precision and 'quant' in quant_format:
+            self.set_no_quant_layer()
         self.model.replace_language_module_all(mapping[quant_format],
                                                self.get_replacement_params(quant_format, self.w_only),
                                                keep_device=keep_device)

@@ -28,12 +28,25 @@ __device__ __forceinline__ void fp8_one(float w, float s, int tdt, int mode, int
 // two elements: one hardware conversion (fp8_math.h) on the e4m3 cast path
 template <typename T>
 __device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, int mode, T* of, uint8_t* ob) {
+    const int fake = mode & FP8_FAKE;
+    if ((mode & ~FP8_FAKE) == FP8_QTORCH) {      // e4m3 with qtorch's rounding: the quantized values are exact e4m3fn numbers,
+        const float v0 = qtorch_quantize<4, 3>(rnd(rnd(w0 / s, tdt) + 0.0f, tdt));     // so the hardware conversion is exact
+        const float v1 = qtorch_quantize<4, 3>(rnd(rnd(w1 / s, tdt) + 0.0f, tdt));
+        if (fake) {
+            of[0] = from_f32<T>(opaque_f32(v0 * s));
+            of[1] = from_f32<T>(opaque_f32(v1 * s));
+        } else {
+            const uint32_t c = f32x2_to_e4m3fn(v0, v1);
+            ob[0] = (uint8_t)c;
+            ob[1] = (uint8_t)(c >> 8);
+        }
+        return;
+    }
     if (mode & ~FP8_FAKE) {
         fp8_one<T>(w0, s, tdt, mode, 0, &of[0], &ob[0]);
         fp8_one<T>(w1, s, tdt, mode, 0, &of[1], &ob[1]);
         return;
     }
-    const int fake = mode & FP8_FAKE;
     const float t0 = rnd(rnd(w0 / s, tdt) + 0.0f, tdt), t1 = rnd(rnd(w1 / s, tdt) + 0.0f, tdt);
     const uint32_t c = f32x2_to_e4m3fn(t0, t1);
     const uint8_t q0 = (uint8_t)c, q1 = (uint8_t)(c >> 8);

@@ -40,6 +40,8 @@ class _HFAdapter:
         for name, m in subset['layers'].items():
             if not isinstance(m, _linear_types()):
                 continue
+            if hasattr(m, 'no_quant') and m.no_quant:          # models/base_model.py:433-435
+                continue
             parent_name, _, child = name.rpartition('.')
             parent = block.get_submodule(parent_name) if parent_name else block
             setattr(parent, child, cls.new(m, **params))

@@ -48,8 +48,11 @@ def compare(tag, ref, ours):
     assert names == layer_names(ours) and int(ref['n_linear']) == int(ours['n_linear']) == len(names) > 0
     stats = {}
     for n in names:
-        assert str(ref[n + '/type']).endswith('EffcientFakeQuantLinear') and str(ours[n + '/type']).endswith('EffcientFakeQuantLinear'), n
-        assert str(ours[n + '/type']).startswith('llmc_amd.'), n
+        ta, tb = str(ref[n + '/type']), str(ours[n + '/type'])
+        assert ta.rsplit('.', 1)[-1] == tb.rsplit('.', 1)[-1], (n, ta, tb)        # same wrapper (or the same untouched nn.Linear)
+        assert ta.endswith('EffcientFakeQuantLinear') or ta.endswith('.Linear'), (n, ta)
+        if tb.endswith('EffcientFakeQuantLinear'):
+            assert tb.startswith('llmc_amd.'), n
         a, b = ref[n + '/weight'], ours[n + '/weight']
         assert a.shape == b.shape, n
         tol = 1e-3 * float(np.abs(a).max())
@@ -64,6 +67,7 @@ def compare(tag, ref, ours):
             st['z_equal'] = float((ref[n + '/buf_zeros'].reshape(-1) == ours[n + '/buf_zeros'].reshape(-1)).mean())
         if n + '/buf_perm' in ref:
             st['perm_equal'] = float((ref[n + '/buf_perm'] == ours[n + '/buf_perm']).mean())
+        st['float_layer'] = float(ta.endswith('.Linear'))
         stats[n] = st
         report(f'ref_pipeline/{tag}/{n}', **st)
     pa, pb = float(ref['ppl'][-1]), float(ours['ppl'][-1])
@@ -107,8 +111,17 @@ def is_first_subset(n):
 
 @needs_ref
 def test_llama_gptq_and_awq_through_the_reference_main(tmp_path):
-    res = run_arms(tmp_path, 'llama', ['gptq', 'awq'])
+    res = run_arms(tmp_path, 'llama', ['gptq', 'awq', 'rtn_mixed'])
     w0 = original_weights(tmp_path, 'llama')
+    # ---- mixed precision (ignored_layers: block 0's q_proj / v_proj by block id + layer name, block 1's k_proj by full
+    # name): the named layers stay untouched nn.Linear in BOTH arms, the others are quantized (W4 g128 RTN: bit-identical)
+    m_stats, m_pa, m_pb = compare('llama_rtn_mixed', *res['rtn_mixed'])
+    floats = sorted(n for n, st in m_stats.items() if st['float_layer'])
+    assert floats == ['model.layers.0.self_attn.q_proj', 'model.layers.0.self_attn.v_proj', 'model.layers.1.self_attn.k_proj'], floats
+    for n, st in m_stats.items():
+        assert st['w_equal'] == 1.0, (n, st)
+    for n in floats:
+        assert np.array_equal(res['rtn_mixed'][1][n + '/weight'], w0[n])       # really the original weights
     g_stats, g_pa, g_pb = compare('llama_gptq', *res['gptq'])
     a_stats, a_pa, a_pb = compare('llama_awq', *res['awq'])
     g_ratio = quant_error_ratio('llama_gptq', w0, *res['gptq'])

@@ -91,6 +91,11 @@ CONFIGS = {
     'rtn': dict(
         quant=dict(method='RTN', weight=dict(bit=8, symmetric=True, granularity='per_channel')),
         calib=None),
+    # mixed precision (base_blockwise_quantization.py:137-144, 910-932): two layers of block 0 and one full name stay float
+    'rtn_mixed': dict(
+        quant=dict(method='RTN', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128)),
+        calib=None,
+        ignored_layers=dict(block_ids=[0], layer_names=['self_attn.q_proj', 'self_attn.v_proj'], speical_names=['@PREFIX@.1.self_attn.k_proj'])),
 }
 
 
@@ -104,6 +109,11 @@ def build_config(method, arch, mdir, ddir, save_path):
            'save': {'save_fake': False, 'save_path': save_path}}
     if c['calib']:
         cfg['calib'] = dict(c['calib'], path=ddir, seed=0)
+    if c.get('ignored_layers'):
+        il = c['ignored_layers']
+        prefix = 'model.layers' if arch == 'llama' else 'model.decoder.layers'
+        il['speical_names'] = [n.replace('@PREFIX@', prefix) for n in il['speical_names']]
+        cfg['ignored_layers'] = il
     return cfg
 
 
