@@ -456,28 +456,56 @@ template <> __device__ __forceinline__ float4 load4_f32<bf16_t>(const bf16_t* p)
 // MODE 0: out[r][j] = in[r][idx[j]]                                   (column gather)
 // MODE 1: out[r][j] = dead[idx[j]] ? 0 : in[r][idx[j]]                (k_gather_w)
 // MODE 2: out[r][j] = in[idx[r]][idx[j]] + (r == j) * damp            (k_gather_h)
+// A workgroup handles GATHER_ROWS consecutive output rows and keeps the column indices of its threads in registers across
+// them (round 4: with one row per workgroup every row re-read the whole int64 index vector, twice the bytes of the row itself).
+static constexpr int GATHER_ROWS = 8;
+static constexpr int GATHER_MAXJ = 7;     // 4 * 512 * 7 = 14336 columns per register pass (28 index registers); wider rows take more passes
 template <typename T, int MODE>
 __global__ __launch_bounds__(512) void k_gather_lds(const T* __restrict__ in, int K, const int64_t* __restrict__ idx,
                                                    const uint8_t* __restrict__ dead, float percdamp,
-                                                   const float* __restrict__ diag_mean, float* __restrict__ out) {
+                                                   const float* __restrict__ diag_mean, float* __restrict__ out, int64_t R) {
     extern __shared__ __attribute__((aligned(16))) float grow[];
-    const int64_t r = blockIdx.x;
-    const int64_t sr = (MODE == 2 && idx) ? idx[r] : r;
-    const T* src = in + sr * K;
-    for (int c = 4 * threadIdx.x; c < K; c += 4 * 512) *reinterpret_cast<float4*>(grow + c) = load4_f32<T>(src + c);
-    __syncthreads();
     const float damp = MODE == 2 ? percdamp * (*diag_mean) : 0.0f;
-    for (int c = 4 * threadIdx.x; c < K; c += 4 * 512) {
-        float v[4];
+    const int64_t r_begin = (int64_t)blockIdx.x * GATHER_ROWS;
+    const int64_t r_end = r_begin + GATHER_ROWS < R ? r_begin + GATHER_ROWS : R;
+    for (int c_pass = 0; c_pass < K; c_pass += 4 * 512 * GATHER_MAXJ) {
+        // this thread's columns of the pass: c = c_pass + 4 * tid + 2048 * j
+        int pj[GATHER_MAXJ][4];
+        uint32_t deadbits = 0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int64_t pj = idx ? idx[c + t] : c + t;
-            float x = grow[pj];
-            if (MODE == 1 && dead[pj]) x = 0.0f;
-            if (MODE == 2 && r == c + t) x += damp;
-            v[t] = x;
+        for (int j = 0; j < GATHER_MAXJ; ++j) {
+            const int c = c_pass + 4 * (int)threadIdx.x + 4 * 512 * j;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int v = 0;
+                if (c < K) {
+                    v = idx ? (int)idx[c + t] : c + t;
+                    if (MODE == 1 && dead[v]) deadbits |= 1u << (4 * j + t);
+                }
+                pj[j][t] = v;
+            }
         }
-        *reinterpret_cast<float4*>(out + r * K + c) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int64_t r = r_begin; r < r_end; ++r) {
+            const int64_t sr = (MODE == 2 && idx) ? idx[r] : r;
+            const T* src = in + sr * K;
+            __syncthreads();          // the previous row's gathers are done with the LDS row
+            for (int c = 4 * threadIdx.x; c < K; c += 4 * 512) *reinterpret_cast<float4*>(grow + c) = load4_f32<T>(src + c);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < GATHER_MAXJ; ++j) {
+                const int c = c_pass + 4 * (int)threadIdx.x + 4 * 512 * j;
+                if (c >= K) break;
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float x = grow[pj[j][t]];
+                    if (MODE == 1 && ((deadbits >> (4 * j + t)) & 1u)) x = 0.0f;
+                    if (MODE == 2 && r == c + t) x += damp;
+                    v[t] = x;
+                }
+                *reinterpret_cast<float4*>(out + r * K + c) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
     }
 }
 
@@ -489,8 +517,8 @@ static int gather_lds_launch(const T* in, int64_t R, int64_t K, const int64_t* i
     // rows above 64 KB need the kernel's dynamic-LDS ceiling raised once (per device and instantiation)
     if (K * 4 > 65536)
         if (int rc = ensure_dynamic_lds((const void*)k_gather_lds<T, MODE>, GATHER_LDS_MAX)) return rc;
-    hipLaunchKernelGGL((k_gather_lds<T, MODE>), dim3((unsigned)R), dim3(512), (size_t)K * 4, st, in, (int)K, idx, dead,
-                       percdamp, diag_mean, out);
+    hipLaunchKernelGGL((k_gather_lds<T, MODE>), dim3((unsigned)ceil_div64(R, GATHER_ROWS)), dim3(512), (size_t)K * 4, st, in,
+                       (int)K, idx, dead, percdamp, diag_mean, out, R);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }
