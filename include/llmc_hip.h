@@ -340,6 +340,17 @@ int llmc_awq_clip_search(const void* W, const void* X, int dt, int64_t R, int64_
 int llmc_awq_clip_errs(const void* W, const void* X, int dt, int64_t R, int64_t K, int64_t g, int64_t n_tok,
                        int n_grid, int n_shrink, int clip_sym, int sym, float qmin, float qmax, void* errs,
                        llmc_stream_t stream);
+/* The error table from GIVEN candidates — every group width (per_channel / per_tensor: g = K), every quantizer (integer,
+ * FP8, learnable ranges of clip_version v2), optionally quantized activations (auto_clip.py:150-170 with
+ * fake_quantize_weight :258-274 and fake_quantize_input :276-281 evaluated by the caller):
+ *   Q [n_shrink, R, K] dt = the fake-quantized weights of every shrink level; XT [K, ldt] dt = the sampled tokens
+ *   TRANSPOSED (token t of column k at XT[k * ldt + t], ldt % 8 == 0, 16-byte aligned, zero padded); XQT = the same
+ *   layout of their fake-quantized form, or XT itself for weight-only;
+ *   errs[s, r, j] = mean_tok((sum_g xq * Q[s] - sum_g x * W)^2) in dt, the sums in ATen's CPU orders
+ *   (vectorized_inner_sum with its level cascade over g <= 262144 elements; the token mean as llmc_awq_clip_errs). */
+int llmc_awq_clip_errs_cand(const void* W, const void* Q, const void* XT, const void* XQT, int dt, int64_t R,
+                            int64_t K, int64_t g, int64_t n_tok, int64_t ldt, int n_shrink, void* errs,
+                            llmc_stream_t stream);
 
 /* apply_clip v1 (auto_clip.py:194-212): W = clamp(W, min, max) per (row, group). */
 int llmc_clamp_groups(void* W, int dt, int64_t R, int64_t K, int64_t g, const void* min_val,

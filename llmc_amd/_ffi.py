@@ -78,6 +78,7 @@ SIGNATURES = {
     'llmc_awq_clip_search': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _f32,
                                     _vp, _vp, _vp, _vp]),
     'llmc_awq_clip_errs': (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp]),
+    'llmc_awq_clip_errs_cand': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     'llmc_fp8_quant_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_fp8_quant': (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'llmc_fp8_block_quant': (_i32, [_vp, _i32, _i64, _i64, _i32, _f32, _i32, _vp, _vp, _vp]),

@@ -1,6 +1,13 @@
-"""AutoClipper with llmc's surface (llmc/compression/quantization/auto_clip.py:22-281), weight-only: clip_version v1
-(search + clamp the weights to the searched range); of v2 the part that outlives the search: `apply_clip` / `get_clip_factor`
-store a range as logit factors (`buf_upbound_factor` / `buf_lowbound_factor`) for a quantizer with `calib_algo: learnable`."""
+"""AutoClipper with llmc's surface (llmc/compression/quantization/auto_clip.py:22-281): clip_version v1 (search + clamp the
+weights to the searched range) and v2 (search over learnable-range factors; `apply_clip` / `get_clip_factor` store the range
+as logit factors `buf_upbound_factor` / `buf_lowbound_factor` for a quantizer with `calib_algo: learnable`), weight-only or
+with quantized activations. Two routes, same arithmetic:
+  * W4A16-style (v1, weight-only, integer min/max quantizer, groups <= 128): one kernel builds the candidates of every
+    shrink level, evaluates them and takes the argmin (llmc_awq_clip_search);
+  * everything else (per_channel / per_tensor ranges, FP8 quantizers, quantized activations, v2): the candidates of every
+    shrink level come from the quantizer's own kernels exactly as fake_quantize_weight forms them (auto_clip.py:258-274,
+    in the reference's output-channel batches of 256 / 64 rows, which is what a per_tensor range spans), the error table
+    from llmc_awq_clip_errs_cand, the strict-< argmin over the ten levels on [R, ng] tensors."""
 import os
 
 import torch
@@ -15,16 +22,15 @@ class AutoClipper:
                  external_ranges=False):
         if clip_version not in ('v1', 'v2'):
             raise Exception('Not support other clip version')
-        if clip_version == 'v2' and not external_ranges:
-            # fail where the configuration is read, not after block 0's calibration forward: the v2 range SEARCH
-            # (auto_clip.py:262-272) is not built — see _auto_clip_layer_v2. Callers that bring their own ranges (llmc's
-            # two-stage pipelines load clips.pth) ask for the durable half explicitly: apply_clip / get_clip_factor.
-            raise NotImplementedError('AutoClipper clip_version v2: the range search is outside the hot path (per_channel + '
-                                      'activation-quantized pipelines). Pass external_ranges=True (quant.special.'
+        if clip_version == 'v2' and not external_ranges and getattr(wquantizer, 'granularity', None) == 'per_group':
+            # fail where the configuration is read, not after block 0's calibration forward: with per_group
+            # weights the reference's v2 search raises inside its own quantizer (the [oc, 1, ng, 1] scales do not broadcast
+            # against the [-1, g] view, quant.py:701; reproduced by oracle/make_golden.py). Callers that bring their own
+            # ranges (llmc's two-stage pipelines load clips.pth) use apply_clip / get_clip_factor: external_ranges=True.
+            raise NotImplementedError('AutoClipper clip_version v2 searches per_channel / per_tensor ranges only (per_group '
+                                      'fails in the reference too). Pass external_ranges=True (quant.special.'
                                       'clip_external_ranges: True) to use apply_clip / get_clip_factor with ranges of your own')
-        if not w_only:
-            raise NotImplementedError('AutoClipper with activation quantization (fake_quantize_input, auto_clip.py:276-281) '
-                                      'is outside the hot path')
+        self.external_ranges = external_ranges
         self.wquantizer = wquantizer
         self.aquantizer = aquantizer
         self.clip_version = clip_version
@@ -68,8 +74,8 @@ class AutoClipper:
     def auto_clip_layer(self, block_idx, layer_name, w, inputs, n_grid=20, max_shrink=0.5, n_sample_token=512,
                         eps=0.0):
         assert w.dim() == 2
-        if self.clip_version == 'v2':
-            return self._auto_clip_layer_v2(w, inputs, n_grid, max_shrink, n_sample_token)
+        if not self._fused_route():
+            return self._auto_clip_layer_general(w, inputs, n_grid, max_shrink, n_sample_token, eps)
         if len(inputs) == 1:                    # what run() always passes (it concatenates the batches, auto_clip.py:63-67)
             x, _ = self._sample_tokens(inputs[0], 0, w, n_sample_token)
             return awq_ops.clip_search(w.data, x, self.wquantizer, self.clip_sym, n_grid, max_shrink)
@@ -107,16 +113,67 @@ class AutoClipper:
             best_min = torch.where(better, min_val, best_min)
         return best_max, best_min
 
-    def _auto_clip_layer_v2(self, w, inputs, n_grid, max_shrink, n_sample_token):
-        """The v2 SEARCH (fake_quantize_weight's v2 branch, auto_clip.py:262-272) is not built: in the reference it only
-        runs with per_channel weights — with per_group it raises inside its own quantizer (the [oc, 1, ng, 1] scales do not
-        broadcast against the [-1, g] view, quant.py:701; reproduced by oracle/make_golden.py) — and every shipped config
-        that selects it (awq_comb_omni/*/step_1_awq.yml, tesseraq_w4a16.yml) is per_channel with activation quantization
-        or TesseraQ: outside the W4A16 hot path, and a 4096-wide group is beyond the clip kernel. What v2 leaves behind IS
-        supported: apply_clip / get_clip_factor store the factors, the learnable-range quantizer and w_qdq consume them."""
-        raise NotImplementedError('AutoClipper clip_version v2: the range search is outside the hot path (per_channel + '
-                                  'activation-quantized pipelines); apply_clip / get_clip_factor and the learnable-range '
-                                  'quantizer are available')
+    def _fused_route(self):
+        from .quant import IntegerQuantizer
+        wq = self.wquantizer
+        return (self.clip_version == 'v1' and self.w_only and isinstance(wq, IntegerQuantizer) and wq.calib_algo == 'minmax'
+                and wq.round_zp and wq.granularity == 'per_group' and wq.group_size <= 128)
+
+    def fake_quantize_weight(self, w, min_val, max_val, org_min_val, org_max_val):
+        """auto_clip.py:258-274 for one output-channel batch: w [oc, K], ranges [oc, ng, 1]."""
+        wq = self.wquantizer
+        oc, K = w.shape
+        if self.clip_version == 'v1':
+            g = K // max_val.shape[1]
+            return wq.fake_quant_weight_dynamic(awq_ops.clamp_groups_(w.clone(), min_val, max_val, g))
+        if wq.granularity == 'per_group':
+            raise NotImplementedError('AutoClipper clip_version v2 with per_group weights: the reference raises here too '
+                                      '(quant.py:701: [oc, 1, ng, 1] scales against the [-1, g] view)')
+        low_factor = self.logit(min_val / org_min_val)
+        up_factor = self.logit(max_val / org_max_val)
+        tensor_range = wq.get_learnable_range(w.reshape(oc, max_val.shape[1], -1), low_factor, up_factor)
+        scales, zeros, qmax, qmin = wq.get_qparams(tensor_range, w.device)
+        return wq.fake_quant_weight_static(w, {'scales': scales, 'zeros': zeros, 'qmax': qmax, 'qmin': qmin})
+
+    def fake_quantize_input(self, block_idx, x, layer_name):
+        """auto_clip.py:276-281; x is the [1, tok, ng, g] view the reference quantizes (a per_token range is per token AND
+        group there)."""
+        return x if self.w_only else self.aquantizer.fake_quant_act_dynamic(x)
+
+    def _auto_clip_layer_general(self, w, inputs, n_grid, max_shrink, n_sample_token, eps=0.0):
+        """auto_clip.py:84-191 for every quantizer / granularity / clip version (see the module docstring)."""
+        wq = self.wquantizer
+        wd = w.data.contiguous()
+        R, K = wd.shape
+        g = wq.group_size if wq.granularity == 'per_group' else K
+        if K % g != 0:
+            raise NotImplementedError('AutoClipper: group size must divide the row (the padded view of auto_clip.py:103-105 '
+                                      'is outside the hot path)')
+        ng = K // g
+        oc = 256 if R % 256 == 0 else 64                                   # auto_clip.py:106-107
+        assert R % oc == 0
+        wg = wd.reshape(R, ng, g)
+        org_max = (wg.abs() if self.clip_sym else wg).amax(dim=-1, keepdim=True)
+        org_min = wg.amin(dim=-1, keepdim=True)
+        ns = int(max_shrink * n_grid)
+        cands = torch.empty((ns, R, K), dtype=wd.dtype, device=wd.device)
+        for i_s in range(ns):
+            lev = i_s + eps if (i_s == 0 and self.clip_version == 'v2' and not self.w_only) else i_s     # :128-130
+            max_val, min_val = self._levels(org_max, org_min, lev, n_grid)
+            for b0 in range(0, R, oc):
+                sl = slice(b0, b0 + oc)
+                cands[i_s, sl] = self.fake_quantize_weight(wd[sl], min_val[sl], max_val[sl], org_min[sl], org_max[sl])
+        errs = None
+        for i in range(len(inputs)):
+            x, n_sample_token = self._sample_tokens(inputs[i], i, w, n_sample_token)
+            xq = None
+            if not self.w_only:
+                xq = self.fake_quantize_input(None, x.reshape(1, x.shape[0], ng, g), None).reshape(x.shape)
+            e = awq_ops.clip_errs_cand(wd, cands, x, xq, g)
+            errs = e if errs is None else errs.add_(e)
+        if len(inputs) > 1:
+            errs /= len(inputs)
+        return self._argmin_levels(errs, org_max, org_min, n_grid)
 
     def get_clip_factor(self, block_idx, layer, min_val, max_val, layer_name):
         """auto_clip.py:233-256."""

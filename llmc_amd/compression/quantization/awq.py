@@ -21,6 +21,7 @@ from .awq_pipeline import search_scale_stacked
 from .base_blockwise_quantization import BaseBlockwiseQuantization, _world
 from .module_utils import (_LLMC_LINEAR_TYPES_, _LLMC_LN_TYPES_, _TRANSFORMERS_LINEAR_TYPES_,
                            _TRANSFORMERS_LN_TYPES_, FakeQuantLinear)
+from .quant import IntegerQuantizer
 
 
 class _hip_linear_forward:
@@ -64,10 +65,29 @@ class Awq(BaseBlockwiseQuantization):
         self.save_scale = special.get('save_scale', False)
         self.awq_bs = special.get('awq_bs', None)
         self.save_mem = special.get('save_mem', True)
-        if not self.w_only:
-            raise NotImplementedError('Awq with activation quantization is outside the hot path')
-        if self.wquantizer.calib_algo != 'minmax':
-            raise NotImplementedError('Awq: the fused scale/clip search kernels take min/max ranges (calib_algo=minmax)')
+
+    def _fusable_wquantizer(self):
+        """llmc_awq_scale_fakequant / search_scale_stacked evaluate integer min/max quantizers with one range per row
+        or per group; every other weight quantizer (FP8 e4m3 / e5m2, per_tensor, mse ranges) takes the two-kernel form
+        mul_cols + fake_quant_weight_dynamic — same arithmetic as awq.py:155-156, one more HBM pass."""
+        wq = self.wquantizer
+        return (isinstance(wq, IntegerQuantizer) and wq.granularity in ('per_group', 'per_channel')
+                and wq.calib_algo == 'minmax' and wq.round_zp)
+
+    def _fake_quantize_weight(self, w0, cols):
+        """fake_quantize_weight (awq.py:147-164) of one layer from its original weights; w0 is not modified."""
+        if w0.dtype == torch.float8_e4m3fn:
+            raise NotImplementedError('Awq on block-wise FP8 checkpoints (weight_scale_inv, awq.py:148-161) is outside the hot path')
+        if self._fusable_wquantizer():
+            return awq_ops.scale_fakequant(w0, cols, self.wquantizer)
+        return self.wquantizer.fake_quant_weight_dynamic(awq_ops.mul_cols_(w0.clone(), cols))
+
+    def fake_quantize_input(self, x_tmp, layers_dict=None):
+        """awq.py:166-177: dynamic activation fake-quant of the scaled input — the whole batch when it is one awq_bs
+        batch, else sample by sample (a per_tensor range is then per sample)."""
+        if self._bs == x_tmp.shape[0]:
+            return self.aquantizer.fake_quant_act_dynamic(x_tmp)
+        return torch.stack([self.aquantizer.fake_quant_act_dynamic(x_tmp[i]) for i in range(x_tmp.shape[0])])
 
     @torch.no_grad()
     def get_weight_scale(self, layers_dict):
@@ -128,6 +148,8 @@ class Awq(BaseBlockwiseQuantization):
         layers = list(layers_dict.values())
         if len(input) != 1 or len(layers) != 1 or inspect_module is not layers[0]:
             return False
+        if not self.w_only or not self._fusable_wquantizer():
+            return False
         if self.padding_mask or (isinstance(subset_kwargs, dict) and subset_kwargs) or isinstance(subset_kwargs, list):
             return False
         if getattr(layers[0], 'bias', None) is not None:
@@ -187,8 +209,10 @@ class Awq(BaseBlockwiseQuantization):
                         scales = awq_ops.awq_scales(self._act_scale_batched(x), w_max, ratio, self.trans_version)
                         cols = scales
                     for fc, w0 in zip(layers, org_w):      # fake_quantize_weight (awq.py:147-164)
-                        fc.weight.data = awq_ops.scale_fakequant(w0, cols, self.wquantizer)
+                        fc.weight.data = self._fake_quantize_weight(w0, cols)
                     x_tmp = awq_ops.div_cols(x, cols)     # scaling_input (base_blockwise_quantization.py:877-889)
+                    if not self.w_only:
+                        x_tmp = self.fake_quantize_input(x_tmp, layers_dict)      # awq.py:223-224
                     out = self.inspect_module_forward(x_tmp, inspect_module, kwargs)
                     if self.padding_mask and org_out.shape[1] == self.padding_mask[i].shape[-1]:
                         m = self.padding_mask[i].unsqueeze(dim=-1).to(org_out.device)

@@ -246,3 +246,30 @@ def clip_errs(w, x, wquantizer, clip_sym, n_grid=20, max_shrink=0.5):
                                     int(bool(clip_sym)), int(wquantizer.sym), float(wquantizer.qmin),
                                     float(wquantizer.qmax), _ffi.ptr(errs), _ffi.stream()), 'llmc_awq_clip_errs')
     return errs
+
+
+def clip_errs_cand(w, cands, x, xq, group_size):
+    """The error table of auto_clip_layer from given candidates (llmc_awq_clip_errs_cand): w [R, K]; cands [ns, R, K] the
+    fake-quantized weights of every shrink level; x [n_tok, K] the sampled tokens, xq their fake-quantized form (None:
+    weight-only). Returns errs [ns, R, K / g] in the model dtype. The transposition of the token block ([K, n_tok], padded
+    to 8 tokens) is the only data movement done here."""
+    _ffi.require_gpu(w, cands, x, xq)
+    L = _ffi.lib()
+    w, cands = w.contiguous(), cands.contiguous()
+    R, K = w.shape
+    g = int(group_size or K)
+    ns = cands.shape[0]
+    x = x.reshape(-1, K)
+    n_tok = x.shape[0]
+    ldt = (n_tok + 7) // 8 * 8
+
+    def transposed(t):
+        out = torch.zeros((K, ldt), dtype=w.dtype, device=w.device)
+        out[:, :n_tok] = t.reshape(-1, K).to(w.dtype).t()
+        return out
+    xt = transposed(x)
+    xqt = xt if xq is None else transposed(xq)
+    errs = torch.empty((ns, R, K // g), dtype=w.dtype, device=w.device)
+    _ffi.check(L.llmc_awq_clip_errs_cand(_ffi.ptr(w), _ffi.ptr(cands), _ffi.ptr(xt), _ffi.ptr(xqt), _ffi.dt(w), R, K, g,
+                                         n_tok, ldt, ns, _ffi.ptr(errs), _ffi.stream()), 'llmc_awq_clip_errs_cand')
+    return errs

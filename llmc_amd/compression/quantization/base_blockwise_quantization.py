@@ -279,7 +279,7 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             for a, b in zip(smn, smx):
                 mn, mx = (a, b) if mn is None else (mn + alpha * (a - mn), mx + alpha * (b - mx))
             mn, mx = mn.to(samples[0].device), mx.to(samples[0].device)
-        elif algo in ('static_minmax', 'minmax'):
+        elif algo == 'static_minmax':
             # quant.py:253-263: mean over samples of per-sample min / max (fp32), then get_qparams on the means
             from .hist_range import sample_minmax
             smn, smx = sample_minmax(samples)
@@ -293,7 +293,7 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             mn = torch.tensor(lo, dtype=torch.float32, device=samples[0].device)
             mx = torch.tensor(hi, dtype=torch.float32, device=samples[0].device)
         else:
-            raise NotImplementedError(f'static activation calibration {algo}')
+            raise ValueError(f'Unsupported calibration algorithm: {algo}')      # quant.py:573-574, 'minmax' (the default) included
         qmax, qmin = aq.qmax.to(mx.device), aq.qmin.to(mx.device)
         abs_max = torch.max(mx.abs(), mn.abs()).clamp(min=1e-5)
         if aq.sym:

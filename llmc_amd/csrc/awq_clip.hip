@@ -295,6 +295,241 @@ __global__ __launch_bounds__(256) void k_clip_search(ClipArgs a) {
     }
 }
 
+
+// ---- K10w: error table from GIVEN candidates — every group width, every quantizer ----------------------------------
+// k_clip_search builds its candidates in the kernel (integer min/max quantizer, group <= 128, weight-only). The wide
+// form takes them from memory: Q [ns][R][K] = the fake-quantized clamped weights of every shrink level, produced by the
+// host with the quantizer's own kernels (integer or FP8, per_group / per_channel / per_tensor, v1 clamp or v2 learnable
+// range), and the activations twice: XT for the reference output (x * w) and XQT for the candidates' (q_x * q_w) — the
+// same buffer when activations are not quantized (auto_clip.py:150,161-166). Both are TRANSPOSED [K][ldt] so that a
+// column block lands in LDS by straight 16-byte copies.
+// A (row, group) dot product is ATen's vectorized_inner_sum over g elements: 16-element vectors, lo + hi, four
+// interleaved streams each a multi_row_sum (16 vectors per stream into level 0, level sums cascaded 16 at a time into
+// levels 1 and 2: g <= 262144), the vectors past the last four onto stream 0 AFTER its levels were folded, the trailing
+// g % 16 elements first in the final lane sum (oracle/aten_sum.py: inner_sum_16bit, pinned against torch up to
+// g = 14336). One wave per row, a lane owns two tokens: its 4 x 8 x 3 x 2 partial sums live in registers while the
+// group's columns stream through LDS 128 at a time (the next block's global loads are issued before the current one is
+// evaluated); the squared errors of a row go through the same token-sum order as k_clip_search.
+template <typename T> __device__ __forceinline__ float bits16_to_f32(uint16_t u) {
+    T v;
+    v.u = u;
+    return to_f32<T>(v);
+}
+static constexpr int WTOK = 128;      // tokens per pass (2 per lane)
+static constexpr int WCOL = 128;      // columns per LDS block
+static constexpr int WROWS = 4;       // rows per workgroup (one per wave)
+
+struct ClipCandArgs {
+    const void* W;    // [R, K]
+    const void* Q;    // [ns, R, K]
+    const void* XT;   // [K, ldt]
+    const void* XQT;  // [K, ldt]
+    int64_t R, K, ldt;
+    int g, ng, n_tok, ns;
+    void* errs;       // [ns, R, ng]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_clip_errs_cand(ClipCandArgs a) {
+    constexpr int DT = dt_of<T>::value;
+    __shared__ __attribute__((aligned(16))) T xt[WCOL * WTOK];         // [k][token]
+    __shared__ __attribute__((aligned(16))) T tab[WROWS * WCOL];       // this block's weights, one row per wave
+    __shared__ float sqbuf[WROWS * CTOK];
+    __shared__ float esum[WROWS * CMAXS];
+    const int gi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row_raw = (int64_t)blockIdx.y * WROWS + wv;
+    const bool row_ok = row_raw < a.R;
+    const int64_t row = row_ok ? row_raw : a.R - 1;
+    const int g = a.g, ns = a.ns;
+    const int nblk = (g + WCOL - 1) / WCOL;
+    const int nv = g >> 4, nv4 = nv & ~3;
+    const bool exact_tok = a.n_tok <= CTOK;
+    const bool mode_b = aten_outer_mode_b(a.ng, gi);
+    T* mytab = tab + wv * WCOL;
+    float* mysq = sqbuf + wv * CTOK;
+    const int64_t col0 = (int64_t)gi * g;
+    if (tid < WROWS * CMAXS) esum[tid] = 0.f;
+    // staging: thread t copies 16 bytes (8 tokens) of column t / 16 + 16 m, m = 0..7
+    const int sc = tid >> 4, stok = (tid & 15) * 8;
+
+    for (int t0 = 0; t0 < a.n_tok; t0 += CTOK) {
+        const int nt = a.n_tok - t0 < CTOK ? a.n_tok - t0 : CTOK;
+        float o0[CTOK / WTOK][2];
+        for (int s = 0; s <= ns; ++s) {
+            const T* xsrc = (const T*)(s == 0 ? a.XT : a.XQT);
+            const T* wsrc = s == 0 ? (const T*)a.W + row * a.K + col0
+                                   : (const T*)a.Q + ((int64_t)(s - 1) * a.R + row) * a.K + col0;
+            float es_lane = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < CTOK / WTOK; ++pass) {
+                const int tb = pass * WTOK;
+                if (tb >= nt) break;                                     // uniform
+                const int tl = tb + lane * 2;
+                float acc[3][4][2][8];
+#pragma unroll
+                for (int lv = 0; lv < 3; ++lv)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int l = 0; l < 8; ++l) acc[lv][st][j][l] = 0.f;
+                float fin[2] = {0.f, 0.f};
+                // prefetch of block 0
+                uint4 pre[8];
+                uint32_t wpre;
+                auto fetch = [&](int b) {
+                    const int kb = b * WCOL;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int k = sc + 16 * m;
+                        uint4 v = {0u, 0u, 0u, 0u};
+                        if (kb + k < g && t0 + tb + stok < a.ldt)
+                            v = *(const uint4*)(xsrc + (col0 + kb + k) * a.ldt + t0 + tb + stok);
+                        pre[m] = v;
+                    }
+                    const int k2 = kb + 2 * lane;
+                    uint32_t lo = 0u, hi = 0u;
+                    if (k2 < g) lo = ((const uint16_t*)wsrc)[k2];
+                    if (k2 + 1 < g) hi = ((const uint16_t*)wsrc)[k2 + 1];
+                    wpre = lo | (hi << 16);
+                };
+                fetch(0);
+#pragma unroll 1
+                for (int b = 0; b < nblk; ++b) {
+                    __syncthreads();                                     // block b - 1 fully consumed
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) *(uint4*)(xt + (sc + 16 * m) * WTOK + stok) = pre[m];
+                    ((uint32_t*)mytab)[lane] = wpre;
+                    __syncthreads();
+                    if (b + 1 < nblk) fetch(b + 1);
+                    const int kb = b * WCOL;
+                    const int nvb = (g - kb >= WCOL) ? 8 : ((g - kb) >> 4);          // full vectors in this block
+                    const int nst = nv4 - 8 * b >= 8 ? 8 : (nv4 - 8 * b > 0 ? nv4 - 8 * b : 0);   // of them on the streams: 0 / 4 / 8
+                    auto vec = [&](int i, float (&dst)[2][8]) {
+#pragma unroll
+                        for (int l = 0; l < 8; ++l) {
+                            const int k1 = 16 * i + l, k2 = k1 + 8;
+                            const float wa = to_f32<T>(mytab[k1]), wb = to_f32<T>(mytab[k2]);
+                            const uint32_t xa = *(const uint32_t*)(xt + k1 * WTOK + lane * 2);
+                            const uint32_t xb = *(const uint32_t*)(xt + k2 * WTOK + lane * 2);
+                            float p[4];
+                            p[0] = bits16_to_f32<T>((uint16_t)(xa & 0xffffu)) * wa;
+                            p[1] = bits16_to_f32<T>((uint16_t)(xa >> 16)) * wa;
+                            p[2] = bits16_to_f32<T>((uint16_t)(xb & 0xffffu)) * wb;
+                            p[3] = bits16_to_f32<T>((uint16_t)(xb >> 16)) * wb;
+                            rfast4<DT>(p);
+                            dst[0][l] += p[0] + p[2];
+                            dst[1][l] += p[1] + p[3];
+                        }
+                    };
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i < nst) vec(i, acc[0][i & 3]);                              // uniform
+                    if (nst == 8) {
+                        const int rows_done = 2 * (b + 1);                               // vectors per stream so far
+                        if ((rows_done & 15) == 0) {
+#pragma unroll
+                            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                    for (int l = 0; l < 8; ++l) {
+                                        acc[1][st][j][l] += acc[0][st][j][l];
+                                        acc[0][st][j][l] = 0.f;
+                                    }
+                            if ((rows_done & 255) == 0) {
+#pragma unroll
+                                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                        for (int l = 0; l < 8; ++l) {
+                                            acc[2][st][j][l] += acc[1][st][j][l];
+                                            acc[1][st][j][l] = 0.f;
+                                        }
+                            }
+                        }
+                    }
+                    if (b == nblk - 1) {
+                        // fold the levels (acc[0] += acc[1]; acc[0] += acc[2]), then the vectors past the last four
+                        // onto stream 0, one by one; then the trailing elements, then the lanes
+#pragma unroll
+                        for (int st = 0; st < 4; ++st)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int l = 0; l < 8; ++l)
+                                    acc[0][st][j][l] = (acc[0][st][j][l] + acc[1][st][j][l]) + acc[2][st][j][l];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (i >= nst && i < nvb) {                                   // at most three
+                                float one[2][8];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                    for (int l = 0; l < 8; ++l) one[j][l] = 0.f;
+                                vec(i, one);
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                    for (int l = 0; l < 8; ++l) acc[0][0][j][l] += one[j][l];
+                            }
+                        for (int k = nvb * 16; k < g - kb; ++k) {
+                            const float wk = to_f32<T>(mytab[k]);
+                            const uint32_t xk = *(const uint32_t*)(xt + k * WTOK + lane * 2);
+                            fin[0] += rfast<DT>(bits16_to_f32<T>((uint16_t)(xk & 0xffffu)) * wk);
+                            fin[1] += rfast<DT>(bits16_to_f32<T>((uint16_t)(xk >> 16)) * wk);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        fin[j] += ((acc[0][0][j][l] + acc[0][1][j][l]) + acc[0][2][j][l]) + acc[0][3][j][l];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float o = rfast<DT>(fin[j]);
+                    if (s == 0) {
+                        o0[pass][j] = o;
+                    } else {
+                        const float d = rfast<DT>(o - o0[pass][j]);
+                        const float sq = rfast<DT>(d * d);
+                        if (tl + j < nt) {
+                            mysq[tl + j] = sq;
+                            es_lane += sq;
+                        }
+                    }
+                }
+            }
+            if (s == 0) continue;
+            float tot;
+            if (exact_tok) {
+                if (!mode_b) {
+                    tot = aten_cascade_sum(mysq, 0, 1, nt, lane);
+                } else {
+                    const int rows4 = nt >> 2;
+                    float part[4];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) part[k4] = aten_cascade_sum(mysq, k4, 4, rows4, lane);
+                    for (int i = rows4 * 4; i < nt; ++i) part[0] += mysq[i];
+                    tot = ((part[0] + part[1]) + part[2]) + part[3];
+                }
+                if (lane == 0) esum[wv * CMAXS + s] = tot;
+            } else {
+                tot = wave_sum(es_lane, 64);
+                if (lane == 0) esum[wv * CMAXS + s] += tot;
+            }
+        }
+    }
+    if (lane == 0 && row_ok)
+        for (int s = 1; s <= ns; ++s)
+            ((T*)a.errs)[((int64_t)(s - 1) * a.R + row) * a.ng + gi] =
+                from_f32<T>(rndc<DT>(esum[wv * CMAXS + s] / (float)a.n_tok));
+}
+
 }  // namespace llmc
 
 using namespace llmc;
@@ -345,6 +580,27 @@ static int clip_launch(const void* W, const void* X, int dt, int64_t R, int64_t 
         if (int rc = ensure_dynamic_lds((const void*)k_clip_search<bf16_t>, (int)lds)) return rc;
         hipLaunchKernelGGL((k_clip_search<bf16_t>), grid, dim3(256), lds, st, a);
     }
+    LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+extern "C" int llmc_awq_clip_errs_cand(const void* W, const void* Q, const void* XT, const void* XQT, int dt, int64_t R,
+                                       int64_t K, int64_t g, int64_t n_tok, int64_t ldt, int n_shrink, void* errs,
+                                       llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "awq_clip_errs_cand: dtype must be f16 or bf16");
+    LLMC_REQUIRE(W && Q && XT && XQT && errs && R > 0 && K > 0 && n_tok > 0, "awq_clip_errs_cand: null/empty argument");
+    if (g <= 0) g = K;
+    LLMC_REQUIRE(K % g == 0 && g >= 16 && g <= 262144, "awq_clip_errs_cand: group size must divide K, 16 <= g <= 262144");
+    LLMC_REQUIRE(n_shrink >= 1 && n_shrink <= CMAXS - 1, "awq_clip_errs_cand: 1..11 shrink steps");
+    LLMC_REQUIRE(ldt >= n_tok && ldt % 8 == 0, "awq_clip_errs_cand: ldt must be a multiple of 8 tokens >= n_tok");
+    LLMC_REQUIRE(((uintptr_t)XT | (uintptr_t)XQT) % 16 == 0, "awq_clip_errs_cand: XT / XQT must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    ClipCandArgs a;
+    a.W = W; a.Q = Q; a.XT = XT; a.XQT = XQT; a.R = R; a.K = K; a.ldt = ldt; a.g = (int)g; a.ng = (int)(K / g);
+    a.n_tok = (int)n_tok; a.ns = n_shrink; a.errs = errs;
+    dim3 grid((unsigned)a.ng, (unsigned)ceil_div64(R, WROWS));
+    if (dt == LLMC_F16) hipLaunchKernelGGL((k_clip_errs_cand<f16_t>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_clip_errs_cand<bf16_t>), grid, dim3(256), 0, st, a);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }

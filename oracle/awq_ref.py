@@ -158,3 +158,54 @@ def auto_clip_layer(w, x, dt, sym, qmin, qmax, group_size, clip_sym=True, n_grid
         best_max = np.where(better, max_val, best_max)
         best_min = np.where(better, min_val, best_min)
     return best_max, best_min
+
+
+# ---- AutoClipper from given candidates (auto_clip.py:150-184 with any quantizer / granularity / clip version) ---------
+def clip_errs_from_candidates(w, cands, x, xq, dt, g):
+    """The error table of auto_clip_layer when the candidates are given: w [R, K]; cands [ns, R, K] = the fake-quantized
+    weights of every shrink level (v1: fakequant(clamp(w)), v2: static fake-quant with the learnable range); x [tok, K] the
+    sampled tokens, xq their fake-quantized form (x itself when activations are not quantized, auto_clip.py:276-281).
+    errs[s, r, j] = mean_tok(((xq * cands[s]).sum_g - (x * w).sum_g)^2), every op in dt, sums in ATen's CPU orders
+    (oracle/aten_sum.py). What llmc_awq_clip_errs_cand computes."""
+    w = np.asarray(w, dtype=np.float32)
+    R, K = w.shape
+    ng = K // g
+    xg = np.asarray(x, dtype=np.float32).reshape(-1, ng, g)
+    xqg = np.asarray(xq, dtype=np.float32).reshape(-1, ng, g)
+
+    def out_of(xv, wv):
+        o = np.empty((R, xv.shape[0], ng), dtype=np.float32)
+        for r in range(R):
+            o[r] = rnd(aten_sum.inner_sum_16bit(rnd(xv * wv[r][None], dt)), dt)
+        return o
+
+    org = out_of(xg, w.reshape(R, ng, g))
+    errs = []
+    for s in range(len(cands)):
+        cur = out_of(xqg, np.asarray(cands[s], dtype=np.float32).reshape(R, ng, g))
+        d = rnd(cur - org, dt)
+        sq = rnd(d * d, dt)
+        errs.append(rnd(aten_sum.outer_sum_fp32(sq) / np.float32(sq.shape[1]), dt))
+    return np.stack(errs)                                   # [ns, R, ng]
+
+
+def clip_argmin_levels(errs, w, g, dt, clip_sym, n_grid=20):
+    """auto_clip.py:126-127, 152-158, 176-184: strict-< argmin over the shrink levels -> (best_max, best_min) [R, ng, 1]."""
+    w = np.asarray(w, dtype=np.float32)
+    R, K = w.shape
+    wg = w.reshape(R, K // g, g)
+    org_max = np.abs(wg).max(axis=-1, keepdims=True) if clip_sym else wg.max(axis=-1, keepdims=True)
+    org_min = wg.min(axis=-1, keepdims=True)
+    best_max, best_min = org_max.copy(), org_min.copy()
+    with np.errstate(over='ignore'):
+        min_errs = rnd(np.full_like(org_max, 1e9), dt)
+    for i_s in range(errs.shape[0]):
+        f = np.float32(1 - i_s / n_grid)
+        max_val = rnd(org_max * f, dt)
+        min_val = -max_val if clip_sym else rnd(org_min * f, dt)
+        e = errs[i_s][..., None]
+        better = e < min_errs
+        min_errs = np.where(better, e, min_errs)
+        best_max = np.where(better, max_val, best_max)
+        best_min = np.where(better, min_val, best_min)
+    return best_max, best_min

@@ -682,6 +682,99 @@ def suite_awq_inspect():
     save('awq_inspect', **out)
 
 
+def suite_awq_wa():
+    """Awq.search_scale_subset with ACTIVATION quantization (`not self.w_only`: fake_quantize_input, awq.py:166-177,
+    223-224) and with weight quantizers the W4A16 goldens do not touch: integer per_channel / per_tensor, FP8 e4m3 / e5m2
+    with float_quantize = the restated qtorch (suite_fp8_qtorch). The configuration awq_fp8_static.yml describes
+    (BASELINE configs[4]'s parent: FP8 per_tensor weights and activations) is the third case. awq_bs = 1 on a two-sample
+    batch takes the per-sample branch of fake_quantize_input, where a per_tensor activation range is per sample."""
+    import torch.distributed as dist
+    import llmc.compression.quantization.quant as qmod
+    from llmc.compression.quantization.awq import Awq
+    qmod.float_quantize = _qtorch_stub
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29594', rank=0, world_size=1)
+
+    class MLP(torch.nn.Module):
+        def __init__(self, K, R, dt):
+            super().__init__()
+            self.gate_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.up_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.down_proj = torch.nn.Linear(R, K, bias=False).to(dt)
+
+        def forward(self, x):
+            return self.down_proj(torch.nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+
+    torch.Tensor.cpu = lambda self, *a, **k: self.clone()      # GPU semantics of `org_sd = {k: v.cpu()}` (see suite_awq)
+    out = {}
+    gen = torch.Generator().manual_seed(4711)
+    # name, dtype, weight quantizer (kind, bit, sym, granularity, group), act quantizer (kind, bit, sym, granularity), inspect, awq_bs, batches
+    cfgs = [('w8a8_int_pc_pt_mlp', 'bf16', ('int', 8, True, 'per_channel', 0), ('int', 8, True, 'per_token'), 'mlp', None, 1),
+            ('w4a8_int_g64_asym_ptensor_bs1', 'f16', ('int', 4, False, 'per_group', 64), ('int', 8, True, 'per_tensor'), 'mlp', 1, 2),
+            ('fp8_e4m3_ptensor_static_yml', 'bf16', ('float', 'e4m3', True, 'per_tensor', 0), ('float', 'e4m3', True, 'per_tensor'), 'linear', None, 1),
+            ('fp8_e5m2_pc_pt', 'bf16', ('float', 'e5m2', True, 'per_channel', 0), ('float', 'e5m2', True, 'per_token'), 'mlp', None, 1),
+            ('w8a8_int_ptensor_weights', 'bf16', ('int', 8, True, 'per_tensor', 0), ('int', 8, False, 'per_token'), 'linear', None, 1)]
+
+    def make(kind, bit, sym, gran, gs=0):
+        if kind == 'int':
+            return IntegerQuantizer(bit, sym, gran, group_size=gs) if gs else IntegerQuantizer(bit, sym, gran)
+        return qmod.FloatQuantizer(bit, sym, gran, use_qtorch=True)
+
+    for name, dt, wcfg, acfg, inspect, awq_bs, nb in cfgs:
+        K, R, B, S = 256, 192, 2, 48
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.aquantizer, a.w_only, a.awq_bs, a.save_mem = make(*wcfg), make(*acfg), False, awq_bs, False
+        a.trans_version, a.n_samples, a.has_gqa, a.do_gqa_trans, a.padding_mask = 'v2', nb * B, False, False, None
+        mlp = MLP(K, R, DT[dt])
+        for l in (mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+            wt = torch.randn(l.weight.shape, generator=gen) * 0.05
+            if l is not mlp.down_proj:
+                wt[:, torch.randperm(K, generator=gen)[:4]] *= 10
+            l.weight.data = wt.to(DT[dt])
+        c = torch.exp(0.5 * torch.randn(K, generator=gen))
+        c[torch.randperm(K, generator=gen)[:8]] *= 30.0
+        xs = [(torch.randn(B, S, K, generator=gen) * c).to(DT[dt]) for _ in range(nb)]
+        losses = []
+        orig = a.calculate_loss
+
+        def rec(org_out, o, _orig=orig):
+            v = _orig(org_out, o)
+            losses.append(v)
+            return v
+        a.calculate_loss = rec
+        if inspect == 'mlp':
+            layers_dict, module = {'gate_proj': mlp.gate_proj, 'up_proj': mlp.up_proj}, mlp
+        else:
+            layers_dict, module = {'gate_proj': mlp.gate_proj}, mlp.gate_proj
+        w0 = {n: l.weight.data.clone() for n, l in mlp.named_modules() if isinstance(l, torch.nn.Linear)}
+        best = a.search_scale_subset(None, layers_dict, [x.clone() for x in xs], module, False, {})
+        for n, l in mlp.named_modules():
+            if isinstance(l, torch.nn.Linear):
+                assert torch.equal(l.weight.data, w0[n]), 'reference must restore the weights'
+        # one explicit grid point of the chain: scaled + fake-quantized weight and input
+        a._bs = xs[0].shape[0] if awq_bs is None else awq_bs
+        sc = a.get_scales(None, xs[0], a.get_weight_scale(layers_dict), False, 0.4)
+        wq04 = a.wquantizer.fake_quant_weight_dynamic(w0['gate_proj'].clone().mul_(sc.view(1, -1)))
+        xq04 = a.fake_quantize_input(xs[0] / sc.view(1, -1), layers_dict)
+        p = name + '/'
+        for n, w in w0.items():
+            out[p + 'w_' + n] = f32(w)
+        for i, x in enumerate(xs):
+            out[p + f'x{i}'] = f32(x)
+        out[p + 'best_scales'] = f32(best)
+        out[p + 'scales_r040'] = f32(sc)
+        out[p + 'wq_r040'] = f32(wq04)
+        out[p + 'xq_r040'] = f32(xq04)
+        out[p + 'losses'] = np.array(losses, dtype=np.float64)
+        out[p + 'wcfg'] = np.array([str(v) for v in wcfg])
+        out[p + 'acfg'] = np.array([str(v) for v in acfg])
+        out[p + 'meta'] = np.array([K, R, nb, 0 if awq_bs is None else awq_bs], dtype=np.int64)
+        out[p + 'inspect'] = np.array(inspect)
+        out[p + 'dt'] = np.array(dt)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('awq_wa', **out)
+
+
 def suite_awq_gqa():
     """special.do_gqa_trans (awq.py:88-108, 338-365; base_blockwise_quantization.py:591-595, 678-685, 877-897): the v_proj -> o_proj
     subset of a GQA attention (fewer key/value heads than query heads). The scales live on v_proj's output channels and are
@@ -814,6 +907,85 @@ def suite_clip_mb():
         out[p + 'dt'] = np.array(dt)
     out['names'] = np.array([c[0] for c in cfgs])
     save('clip_mb', **out)
+
+
+def suite_clip_wide():
+    """AutoClipper.auto_clip_layer beyond W4A16 per_group: per_channel and per_tensor ranges (one group as wide as the
+    row), activation quantization (`fake_quantize_input`, auto_clip.py:276-281: the [1, tok, ng, g] VIEW is what the
+    activation quantizer sees, so per_token ranges are per token AND group), FP8 quantizers (float_quantize = the restated
+    qtorch) and clip_version v2 (learnable range by logit factors, auto_clip.py:262-272). Besides the searched ranges the
+    candidates the reference formed are recorded (fake-quantized weights of every shrink level, quantized input): they pin
+    the error-table kernel separately from the host's candidate construction. K = 1152 makes the per-stream cascade of
+    ATen's row sum flush (18 vectors per stream); K = 488 has vectors past the last four and trailing elements."""
+    import llmc.compression.quantization.quant as qmod
+    from llmc.compression.quantization.auto_clip import AutoClipper
+    qmod.float_quantize = _qtorch_stub
+    out = {}
+    gen = torch.Generator().manual_seed(2024)
+    # name, dtype, R, K, weight (kind, bit, sym, gran, gs, calib), act (kind, bit, sym, gran) | None, version, clip_sym, tokens, n_sample_token
+    cfgs = [('bf16_w4_pc_sym_v1_k1152', 'bf16', 64, 1152, ('int', 4, True, 'per_channel', 0, 'minmax'), None, 'v1', True, 154, 77),
+            ('f16_w8a8_pc_pt_v1', 'f16', 64, 640, ('int', 8, True, 'per_channel', 0, 'minmax'), ('int', 8, True, 'per_token'), 'v1', True, 96, 32),
+            ('bf16_fp8_e4m3_ptensor_wa_v1', 'bf16', 128, 512, ('float', 'e4m3', True, 'per_tensor', 0, 'minmax'), ('float', 'e4m3', True, 'per_tensor'), 'v1', True, 96, 32),
+            ('bf16_w4a8_pc_learnable_v2_sym', 'bf16', 64, 512, ('int', 4, True, 'per_channel', 0, 'learnable'), ('int', 8, True, 'per_token'), 'v2', True, 96, 32),
+            ('f16_w4_pc_learnable_v2_asym', 'f16', 64, 256, ('int', 4, False, 'per_channel', 0, 'learnable'), None, 'v2', False, 96, 32),
+            ('bf16_w4a8_g64_pt_v1', 'bf16', 64, 256, ('int', 4, False, 'per_group', 64, 'minmax'), ('int', 8, True, 'per_token'), 'v1', False, 96, 32),
+            ('f16_w3_pc_asym_v1_k488', 'f16', 64, 488, ('int', 3, False, 'per_channel', 0, 'minmax'), None, 'v1', False, 200, 100)]
+
+    def make(kind, bit, sym, gran, gs=0, calib='minmax'):
+        if kind == 'int':
+            kw = dict(calib_algo=calib)
+            if gs:
+                kw['group_size'] = gs
+            return IntegerQuantizer(bit, sym, gran, **kw)
+        return qmod.FloatQuantizer(bit, sym, gran, use_qtorch=True)
+
+    for name, dt, R, K, wcfg, acfg, ver, clip_sym, T, nst in cfgs:
+        wq = make(*wcfg)
+        aq = make(*acfg) if acfg else None
+        ac = AutoClipper(w_only=aq is None, wquantizer=wq, aquantizer=aq, clip_version=ver, clip_sym=clip_sym,
+                         save_clip=False, padding_mask=None)
+        wt = torch.randn(R, K, generator=gen) * 0.02
+        wt[torch.rand(R, K, generator=gen) < 0.01] *= 8
+        w = wt.to(DT[dt])
+        x = (torch.randn(2, T // 2, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(DT[dt])
+        cands, qxs = [], []
+        fw, fx = ac.fake_quantize_weight, ac.fake_quantize_input
+
+        def rec_w(*a, _f=fw, **k):
+            q = _f(*a, **k)
+            cands.append(q.clone())
+            return q
+
+        def rec_x(*a, _f=fx, **k):
+            q = _f(*a, **k)
+            qxs.append(q.clone())
+            return q
+        ac.fake_quantize_weight, ac.fake_quantize_input = rec_w, rec_x
+        mx, mn = ac.auto_clip_layer(0, 'fc', w, [x.clone()], n_sample_token=nst)
+        oc = 256 if R % 256 == 0 else 64
+        nb, nsh = R // oc, 10
+        assert len(cands) == nb * nsh
+        g = wq.group_size if wcfg[3] == 'per_group' else K
+        # [oc batch][level] -> [level, R, K]
+        Q = torch.stack([torch.cat([cands[b * nsh + s_].reshape(oc, K) for b in range(nb)], dim=0) for s_ in range(nsh)])
+        for q in qxs[1:]:
+            assert torch.equal(q, qxs[0])
+        p = name + '/'
+        out[p + 'w'], out[p + 'x'] = f32(w), f32(x)
+        out[p + 'cands_bits'] = Q.contiguous().view(torch.int16).numpy().view(np.uint16)     # 16-bit patterns of dtype dt
+        out[p + 'qx_bits'] = qxs[0].reshape(-1, K).contiguous().view(torch.int16).numpy().view(np.uint16)   # the sampled tokens, quantized: [n_tok, K]
+        out[p + 'best_max'], out[p + 'best_min'] = f32(mx), f32(mn)
+        if ver == 'v1':
+            layer = torch.nn.Linear(K, R, bias=False).to(DT[dt])
+            layer.weight.data = w.clone()
+            ac.apply_clip(0, layer, mn, mx, 'fc')
+            out[p + 'clipped'] = f32(layer.weight.data)
+        out[p + 'wcfg'] = np.array([str(v) for v in wcfg])
+        out[p + 'acfg'] = np.array([str(v) for v in acfg]) if acfg else np.array([], dtype=str)
+        out[p + 'meta'] = np.array([R, K, g, int(clip_sym), nst], dtype=np.int64)
+        out[p + 'ver'], out[p + 'dt'] = np.array(ver), np.array(dt)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('clip_wide', **out)
 
 
 def suite_clip_v2():
@@ -1236,7 +1408,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'awq_wa': suite_awq_wa, 'clip_wide': suite_clip_wide, 'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'fp8_qtorch': suite_fp8_qtorch, 'fp8_block_qtorch': suite_fp8_block_qtorch, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

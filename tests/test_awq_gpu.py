@@ -358,10 +358,18 @@ def test_gqa_v_to_o_transformation_matches_reference_golden():
 def test_fused_route_only_for_single_inspected_linear():
     from llmc_amd.compression.quantization.awq import Awq
     a = Awq.__new__(Awq)
-    a.padding_mask, a.awq_bs = None, None
+    a.padding_mask, a.awq_bs, a.w_only, a.wquantizer = None, None, True, make_q(True, 128)
     l1, l2 = torch.nn.Linear(64, 64, bias=False), torch.nn.Linear(64, 64, bias=False)
     x = [torch.zeros(2, 4, 64)]
     assert a._fused_route_ok({'o': l1}, x, l1, {})
+    a.w_only = False                                                                     # quantized activations: general route
+    assert not a._fused_route_ok({'o': l1}, x, l1, {})
+    from llmc_amd.compression.quantization import FloatQuantizer, IntegerQuantizer
+    a.w_only = True
+    for wq in (FloatQuantizer('e4m3', True, 'per_tensor'), IntegerQuantizer(8, True, 'per_tensor')):   # not an integer row / group range
+        a.wquantizer = wq
+        assert not a._fused_route_ok({'o': l1}, x, l1, {})
+    a.wquantizer = make_q(True, 128)
     assert not a._fused_route_ok({'q': l1, 'k': l2}, x, torch.nn.Sequential(l1), {})   # inspect = larger module
     assert not a._fused_route_ok({'o': l1}, x + x, l1, {})                              # several batches
     assert not a._fused_route_ok({'o': l1}, x, l1, {'attention_mask': None})            # module kwargs
@@ -474,3 +482,75 @@ def test_small_fake_quant_forward_goes_to_the_framework_gemm_and_says_so(monkeyp
     for x, y in ((xs, ys), (xl, yl)):
         ref = (x.float() @ lin.weight.data.float().T)
         assert ((y.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-5 * ref.abs().max()).all()
+
+
+def _make_quantizer(cfg):
+    from llmc_amd.compression.quantization import FloatQuantizer, IntegerQuantizer
+    kind, bit, sym, gran = cfg[0], cfg[1], cfg[2] == 'True', cfg[3]
+    gs = int(cfg[4]) if len(cfg) > 4 else 0
+    if kind == 'int':
+        return IntegerQuantizer(int(bit), sym, gran, group_size=gs) if gs else IntegerQuantizer(int(bit), sym, gran)
+    return FloatQuantizer(bit, sym, gran, use_qtorch=True)
+
+
+def test_search_with_activation_quantization_matches_reference_golden():
+    """Awq.search_scale_subset with `not w_only` (fake_quantize_input, awq.py:166-177, 223-224) and the weight quantizers
+    outside W4A16: INT8 per_channel / per_tensor, INT4 g64 with per_tensor INT8 activations per sample (awq_bs = 1), FP8
+    e4m3 per_tensor weights AND activations (the arithmetic of awq_fp8_static.yml, BASELINE configs[4]'s parent) and e5m2.
+    One grid point of the chain bit for bit (scaled + fake-quantized weight, scaled + fake-quantized input), the whole
+    loss curve, the same winner."""
+    from conftest import report
+    from llmc_amd.compression.quantization import awq_ops
+    from llmc_amd.compression.quantization.awq import Awq
+
+    class MLP(torch.nn.Module):
+        def __init__(self, K, R, dt):
+            super().__init__()
+            self.gate_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.up_proj = torch.nn.Linear(K, R, bias=False).to(dt)
+            self.down_proj = torch.nn.Linear(R, K, bias=False).to(dt)
+
+        def forward(self, x):
+            return self.down_proj(torch.nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+
+    g = load_golden('awq_wa')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        K, R, nb, awq_bs = [int(v) for v in g[p + 'meta']]
+        dt, inspect = str(g[p + 'dt']), str(g[p + 'inspect'])
+        mlp = MLP(K, R, TD[dt]).cuda()
+        for n in ('gate_proj', 'up_proj', 'down_proj'):
+            getattr(mlp, n).weight.data = dev(g[p + 'w_' + n], dt)
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.aquantizer = _make_quantizer(list(g[p + 'wcfg'])), _make_quantizer(list(g[p + 'acfg']))
+        a.w_only, a.awq_bs, a.save_mem, a.trans_version, a.n_samples, a.padding_mask = False, awq_bs or None, False, 'v2', 2 * nb, None
+        xs = [dev(g[p + f'x{i}'], dt) for i in range(nb)]
+        if inspect == 'mlp':
+            layers, module = {'gate_proj': mlp.gate_proj, 'up_proj': mlp.up_proj}, mlp
+        else:
+            layers, module = {'gate_proj': mlp.gate_proj}, mlp.gate_proj
+        # ---- one grid point of the chain, bit for bit
+        a._bs = xs[0].shape[0] if not awq_bs else awq_bs
+        sc = a.get_scales(None, xs[0], a.get_weight_scale(layers), False, 0.4)
+        assert ulps(host(sc), g[p + 'scales_r040'], dt).max() <= 2, name          # pow() of the GPU libm vs the host libm
+        sc_ref = dev(g[p + 'scales_r040'], dt)
+        wq = a._fake_quantize_weight(mlp.gate_proj.weight.data, sc_ref)
+        np.testing.assert_array_equal(bits(host(wq)), bits(g[p + 'wq_r040']), err_msg=name)
+        xq = a.fake_quantize_input(awq_ops.div_cols(xs[0], sc_ref), layers)
+        np.testing.assert_array_equal(bits(host(xq)), bits(g[p + 'xq_r040']), err_msg=name)
+        # ---- the search
+        rec = []
+        orig = Awq.calculate_loss
+        a.calculate_loss = lambda org_out, out, _a=a: rec.append(orig(_a, org_out, out)) or rec[-1]
+        w_before = {n: l.weight.data.clone() for n, l in layers.items()}
+        assert not a._fused_route_ok(layers, xs, module, {}), name      # activation quantization: general route only
+        best = Awq.search_scale_subset(a, None, layers, xs, module, False, {})
+        for n, l in layers.items():
+            assert torch.equal(l.weight.data, w_before[n]), name
+        ours = np.array([float(v) for v in rec])
+        ref = g[p + 'losses']
+        assert ours.shape == ref.shape == (20 * nb,), name
+        report('awq_wa_losses/' + name, max_rel=float((np.abs(ours - ref) / ref).max()))
+        np.testing.assert_allclose(ours, ref, rtol=5e-4, err_msg=name)
+        u = ulps(host(best), g[p + 'best_scales'], dt)
+        assert u.max() <= 2, (name, u.max())

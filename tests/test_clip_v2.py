@@ -43,14 +43,22 @@ def test_clip_factors_match_reference_cpu(name):
         assert torch.equal(low.float(), t('low_factor').float())
 
 
-def test_v2_search_is_declared_out_of_scope():
-    ac, wq, layer, t, _ = case(NAMES[0], 'cpu')
-    with pytest.raises(NotImplementedError, match='v2'):
-        ac.auto_clip_layer(0, 'fc', layer.weight, [torch.zeros(1, 4, layer.weight.shape[1], dtype=layer.weight.dtype)], 20, 0.5, 4)
+def test_v2_search_refuses_per_group_like_the_reference():
+    """The v2 range search runs for per_channel / per_tensor weights (GPU: test_clip_wide_gpu.py). With per_group weights the
+    reference raises inside its own quantizer (quant.py:701); here the configuration is refused where it is read, and the
+    search itself refuses when a caller with external ranges asks for it anyway."""
     from llmc_amd.compression.quantization.auto_clip import AutoClipper
-    with pytest.raises(NotImplementedError, match='external_ranges'):       # v2 without ranges of the caller's own: at construction
+    from llmc_amd.compression.quantization.quant import IntegerQuantizer
+    pg = [n for n in NAMES if '_g' in n][0]
+    ac, wq, layer, t, _ = case(pg, 'cpu')
+    with pytest.raises(NotImplementedError, match='per_group'):
+        ac.auto_clip_layer(0, 'fc', layer.weight, [torch.zeros(1, 4, layer.weight.shape[1], dtype=layer.weight.dtype)], 20, 0.5, 4)
+    with pytest.raises(NotImplementedError, match='external_ranges'):       # v2 + per_group without ranges of the caller's own
         AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v2', clip_sym=True, save_clip=False,
                     padding_mask=None)
+    pc = IntegerQuantizer(4, True, 'per_channel', calib_algo='learnable')
+    AutoClipper(w_only=True, wquantizer=pc, aquantizer=None, clip_version='v2', clip_sym=True, save_clip=False,
+                padding_mask=None)                                           # per_channel: the search is available
     with pytest.raises(Exception, match='clip version'):
         AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v3', clip_sym=True, save_clip=False,
                     padding_mask=None)

@@ -341,6 +341,40 @@ def test_auto_clip_matches_reference():
         np.testing.assert_array_equal(mn.reshape(g[p + 'best_min'].shape), g[p + 'best_min'], err_msg=name)
 
 
+def bits16_to_f32(bits, dt):
+    """uint16 patterns of a 16-bit dtype (how clip_wide.npz stores the candidates) -> fp32 values."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(bits).view(np.int16))
+    return t.view(torch.bfloat16 if dt == 'bf16' else torch.float16).float().numpy()
+
+
+def sampled_tokens(x, nst):
+    """auto_clip.py:133-147 without a padding mask: flatten, every step-th token."""
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2[0::max(1, x2.shape[0] // nst)]
+
+
+def test_auto_clip_from_candidates_matches_reference_for_wide_groups_act_quant_fp8_and_v2():
+    """clip_wide.npz: per_channel / per_tensor ranges (one group = the row: ATen's cascaded inner sum, K = 1152 flushes a
+    level, K = 488 has tail vectors and trailing elements), quantized activations, FP8 quantizers, clip_version v2. From the
+    candidates the reference formed, the restated error table picks the reference's level for EVERY (row, group)."""
+    g = load_golden('clip_wide')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        R, K, gs, clip_sym, nst = [int(v) for v in g[p + 'meta']]
+        dt = str(g[p + 'dt'])
+        x = sampled_tokens(g[p + 'x'], nst)
+        xq = bits16_to_f32(g[p + 'qx_bits'], dt)
+        assert xq.shape == x.shape, name
+        if g[p + 'acfg'].size == 0:
+            np.testing.assert_array_equal(xq, x, err_msg=name)            # w_only: fake_quantize_input is the identity
+        cands = bits16_to_f32(g[p + 'cands_bits'], dt)
+        errs = A.clip_errs_from_candidates(g[p + 'w'], cands, x, xq, dt, gs)
+        mx, mn = A.clip_argmin_levels(errs, g[p + 'w'], gs, dt, bool(clip_sym))
+        np.testing.assert_array_equal(mx.reshape(g[p + 'best_max'].shape), g[p + 'best_max'], err_msg=name)
+        np.testing.assert_array_equal(mn.reshape(g[p + 'best_min'].shape), g[p + 'best_min'], err_msg=name)
+
+
 def test_per_tensor_asymmetric_bit_exact():
     """quant_pt.npz: fp32 0-dim qparams, op results in the tensor dtype."""
     g = load_golden('quant_pt')

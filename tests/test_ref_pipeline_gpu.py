@@ -67,6 +67,10 @@ def compare(tag, ref, ours):
             st['z_equal'] = float((ref[n + '/buf_zeros'].reshape(-1) == ours[n + '/buf_zeros'].reshape(-1)).mean())
         if n + '/buf_perm' in ref:
             st['perm_equal'] = float((ref[n + '/buf_perm'] == ours[n + '/buf_perm']).mean())
+        if n + '/buf_act_scales_0' in ref:
+            assert n + '/buf_act_scales_0' in ours, n                 # static activation ranges registered by both arms
+            aa, ab = ref[n + '/buf_act_scales_0'].reshape(-1), ours[n + '/buf_act_scales_0'].reshape(-1)
+            st['act_scale_rel'] = float((np.abs(aa - ab) / np.maximum(np.abs(aa), 1e-30)).max())
         st['float_layer'] = float(ta.endswith('.Linear'))
         stats[n] = st
         report(f'ref_pipeline/{tag}/{n}', **st)
@@ -86,7 +90,7 @@ def original_weights(tmp_path, arch):
     return {k[:-len('.weight')]: v.float().numpy() for k, v in sd.items() if k.endswith('.weight') and v.dim() == 2}
 
 
-def quant_error_ratio(tag, w0, ref, ours):
+def quant_error_ratio(tag, w0, ref, ours, only=None):
     """||Wq - W0||_F of the two arms, layer by layer: where the codes differ because upstream roundings moved an actorder
     permutation or a group range (every layer behind the first subset, with true_sequential + quant_out), both arms must
     still have done the same JOB."""
@@ -100,8 +104,10 @@ def quant_error_ratio(tag, w0, ref, ours):
             key = cands[0]
         ea = float(np.linalg.norm(ref[n + '/weight'] - w0[key]))
         eb = float(np.linalg.norm(ours[n + '/weight'] - w0[key]))
-        worst = max(worst, abs(ea - eb) / ea)
         report(f'ref_pipeline/{tag}/{n}/quant_err', ref=ea, ours=eb)
+        if only is not None and not only(n):
+            continue
+        worst = max(worst, abs(ea - eb) / ea)
     return worst
 
 
@@ -159,3 +165,29 @@ def test_opt_rtn_gptq_through_the_reference_main(tmp_path):
             assert st['w_close'] >= 0.995 and st['perm_equal'] >= 0.98, (n, st)
     assert g_ratio <= 0.10, g_ratio
     assert abs(g_pa - g_pb) <= 2e-2 * g_pa, (g_pa, g_pb)
+
+
+@needs_ref
+def test_llama_awq_with_activation_quantization_through_the_reference_main(tmp_path):
+    """AWQ as the W-A configurations run it (awq.py:166-177, 223-224; auto_clip.py:276-281; base_blockwise_quantization.py:567-588):
+    W8A8 per_channel / per_token with scale search + weight clip on quantized inputs, and awq_fp8_static.yml (BASELINE
+    configs[4]'s parent: FP8 e4m3 per_tensor weights, static per_tensor FP8 activations; the reference arm's float_quantize is
+    the restated qtorch). Both through the reference's main(config), with and without the one-line binding."""
+    res = run_arms(tmp_path, 'llama', ['awq_w8a8', 'awq_fp8'])
+    w0 = original_weights(tmp_path, 'llama')
+    for m in ('awq_w8a8', 'awq_fp8'):
+        stats, pa, pb = compare('llama_' + m, *res[m])
+        # AWQ folds the searched scales into the weights: behind block 0 (inputs produced by quantized layers, quant_out) a
+        # flat loss curve lets the two arms settle on neighbouring grid points, and ||Wq - W0|| then measures the chosen
+        # scales, not the quantizer — block 0 (identical inputs) is compared layer by layer, the model by its perplexity
+        ratio = quant_error_ratio('llama_' + m, w0, *res[m], only=lambda n: block_of(n) == 0)
+        for n, st in stats.items():
+            assert st['float_layer'] == 0.0, n
+            if block_of(n) == 0:
+                assert st['w_close'] >= 0.97, (m, n, st)
+            if m == 'awq_fp8':
+                assert 'act_scale_rel' in st, n
+                if block_of(n) == 0:
+                    assert st['act_scale_rel'] <= 2e-2, (n, st)
+        assert ratio <= 0.10, (m, ratio)
+        assert abs(pa - pb) <= 2e-2 * pa, (m, pa, pb)

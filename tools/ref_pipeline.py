@@ -96,7 +96,39 @@ CONFIGS = {
         quant=dict(method='RTN', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128)),
         calib=None,
         ignored_layers=dict(block_ids=[0], layer_names=['self_attn.q_proj', 'self_attn.v_proj'], speical_names=['@PREFIX@.1.self_attn.k_proj'])),
+    # AWQ with ACTIVATION quantization (awq.py:166-177, 223-224; auto_clip.py:276-281): configs/quantization/methods/Awq/
+    # awq_w_a.yml's shape — W8 per_channel + A8 per_token dynamic, scale search and weight clip with quantized inputs
+    'awq_w8a8': dict(
+        quant=dict(method='Awq', weight=dict(bit=8, symmetric=True, granularity='per_channel'),
+                   act=dict(bit=8, symmetric=True, granularity='per_token'),
+                   special=dict(trans=True, trans_version='v2', weight_clip=True), quant_out=True),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
+    # configs/quantization/backend/vllm/fp8/awq_fp8_static.yml (the parent of BASELINE configs[4]): FP8 e4m3 per_tensor
+    # weights, FP8 e4m3 per_tensor STATIC activations, trans v2 + weight clip. float_quantize of the reference arm is bound
+    # to the restated qtorch (oracle/quant_ref.py) — qtorch itself is not installable here
+    'awq_fp8': dict(
+        quant=dict(method='Awq', weight=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_tensor', use_qtorch=True),
+                   act=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_tensor', use_qtorch=True, static=True,
+                            calib_algo='static_minmax'),   # the shipped yml leaves the default 'minmax', which quant.py:573-574 refuses
+                   special=dict(trans=True, trans_version='v2', weight_clip=True), quant_out=True),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
 }
+
+
+def bind_restated_qtorch():
+    """llmc.compression.quantization.quant.float_quantize := the restatement of QPyTorch's float_quantize (test
+    infrastructure: the reference arm only; tensors take the trip through the host)."""
+    import numpy as np
+    import torch
+    import llmc.compression.quantization.quant as qmod
+    sys.path.insert(0, ROOT)
+    from oracle import quant_ref as QR
+
+    def float_quantize(x, e, m, rounding='nearest'):
+        assert rounding == 'nearest'
+        y = QR.qtorch_float_quantize(x.detach().float().cpu().numpy(), e, m)
+        return torch.from_numpy(np.ascontiguousarray(y)).reshape(x.shape).to(x.device)
+    qmod.float_quantize = float_quantize
 
 
 def build_config(method, arch, mdir, ddir, save_path):
@@ -185,6 +217,8 @@ def run_one(M, arm, method, arch, assets, mdir, ddir, stubbed, ref_classes):
     else:
         for k, c in ref_classes.items():                          # the reference's own classes (undo an earlier 'ours' pass)
             ALGO_REGISTRY[k] = c
+        if CONFIGS[method]['quant'].get('weight', {}).get('quant_type') == 'float-quant':
+            bind_restated_qtorch()
     config = EasyDict(build_config(method, arch, mdir, ddir, os.path.join(assets, f'save_{arm}_{method}')))
     check_config(config)
     seed_all(config.base.seed + 0)          # what `if __name__ == '__main__'` does before main() (llmc/__main__.py:179-300)
@@ -232,7 +266,7 @@ def run_one(M, arm, method, arch, assets, mdir, ddir, stubbed, ref_classes):
         if 'embed' in name or 'lm_head' in name:
             continue
         out[f'{name}/weight'] = w.detach().float().cpu().numpy()
-        for b in ('buf_scales', 'buf_zeros', 'buf_perm', 'buf_qmax', 'buf_qmin'):
+        for b in ('buf_scales', 'buf_zeros', 'buf_perm', 'buf_qmax', 'buf_qmin', 'buf_act_scales_0'):
             t = getattr(mod, b, None)
             if torch.is_tensor(t):
                 out[f'{name}/{b}'] = t.detach().float().cpu().numpy() if t.dtype != torch.int64 else t.cpu().numpy()
