@@ -10,6 +10,16 @@
 namespace llmc {
 
 static constexpr int FB = 256;
+// k_fp8_cast: vectors per thread and turn, and how they are laid out (see the kernel); lab builds override them
+#ifndef FP8_U
+#define FP8_U 1
+#endif
+#ifndef FP8_PATTERN
+#define FP8_PATTERN 1
+#endif
+#ifndef FP8_GRID_CAP
+#define FP8_GRID_CAP 8192
+#endif
 
 // amax[row] = clamp(absmax, 1e-5) in dt (from llmc_minmax_qparams with qmax = 1). scale = amax / 448 in the
 // scales' dtype sdt: ATen promotes the 0-dim per-tensor absmax (dt) / 0-dim fp32 qmax to fp32, but keeps dt for
@@ -59,6 +69,94 @@ __device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, in
     }
 }
 
+// ---- eight 16-bit elements at once, without the division ---------------------------------------------------------------
+// t = rnd_dt(fl32(w / s)) is what the reference's `tensor / scales` leaves (ATen divides in fp32, then rounds to the tensor
+// dtype). q = w * fl32(1 / s) is within 3 fp32 ulps of fl32(w / s), so both round to the same dt value unless q lies within
+// 4 ulps of a dt rounding boundary (9 of 65536 bf16 patterns, 9 of 8192 fp16 patterns) — those lanes, f16 results outside
+// the normal range, non-finite values, values in the 8-bit format's subnormal range (|t| < 2^-6) and, for the dtype cast,
+// |t| > 464 take the division and the general encoder instead (FP8_EXACT_DIV in `mode` sends everything there: the A/B switch
+// of tests/test_fp8_fast_gpu.py). e4m3 only; qtorch semantics on the fast path = (bits + 0x80000) & ~0xfffff, saturated to
+// 240 from 256 upwards (fp8_math.h:qtorch_quantize), then the exact hardware conversion of the on-grid values.
+static constexpr int FP8_EXACT_DIV = 0x200;
+template <typename T>
+__device__ __forceinline__ bool fp8_fast8(const uint4 raw, float s, float rs, int mode, T (&of)[8], uint2* ob) {
+    constexpr int DT = dt_of<T>::value;
+    const bool qt = mode & FP8_QTORCH;
+    const uint32_t word[4] = {raw.x, raw.y, raw.z, raw.w};
+    // guards as running minima / maxima (one v_min3 / v_max3 per pair instead of compare + or per element):
+    //   tie   = min of ((q bits & low mask) - (midpoint - 4)) as unsigned: <= 8 means within 4 ulps of a rounding boundary
+    //   tiny  = min of (|t| bits - 1) as unsigned: a nonzero |t| below 2^-6 (the 8-bit format's subnormal range) [qtorch] /
+    //           a nonzero fp16 quotient below the fp16 normal range
+    //   big   = max of |t| bits: above 464 [cast], at the top of the fp16 range
+    uint32_t special = 0, tie = 0xffffffffu, tiny = 0xffffffffu, tiny16 = 0xffffffffu, big = 0;
+    float v[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        // an all-ones exponent in either half (inf / nan): the general path keeps their special cases
+        constexpr uint32_t EXPM = DT == LLMC_BF16 ? 0x7f807f80u : 0x7c007c00u, EXPL = DT == LLMC_BF16 ? 0x00800080u : 0x04000400u;
+        special |= ((word[p] & EXPM) + EXPL) & 0x80008000u;
+        float q0, q1;                                                     // w * (1 / s) + 0: the `+ zeros` of the reference turns -0 into +0
+        if constexpr (DT == LLMC_BF16) {
+            q0 = __builtin_fmaf(__uint_as_float(word[p] << 16), rs, 0.0f);
+            q1 = __builtin_fmaf(__uint_as_float(word[p] & 0xffff0000u), rs, 0.0f);
+        } else {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 hv = __builtin_bit_cast(h2, word[p]);
+            q0 = __builtin_fmaf((float)hv[0], rs, 0.0f);
+            q1 = __builtin_fmaf((float)hv[1], rs, 0.0f);
+        }
+        const uint32_t b0 = __float_as_uint(q0), b1 = __float_as_uint(q1);
+        float t0, t1;
+        if constexpr (DT == LLMC_BF16) {
+            tie = min(tie, min((b0 & 0xffffu) - 0x7ffcu, (b1 & 0xffffu) - 0x7ffcu));
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 qq = {q0, q1};
+            const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(qq, bf2));     // v_cvt_pk_bf16_f32: RNE
+            t0 = __uint_as_float(pk << 16);
+            t1 = __uint_as_float(pk & 0xffff0000u);
+        } else {
+            tie = min(tie, min((b0 & 0x1fffu) - 0x0ffcu, (b1 & 0x1fffu) - 0x0ffcu));
+            tiny16 = min(tiny16, min((b0 & 0x7fffffffu) - 1u, (b1 & 0x7fffffffu) - 1u));
+            t0 = (float)(_Float16)q0;
+            t1 = (float)(_Float16)q1;
+        }
+        const uint32_t u0 = __float_as_uint(t0), u1 = __float_as_uint(t1);
+        const uint32_t a0 = u0 & 0x7fffffffu, a1 = u1 & 0x7fffffffu;
+        big = max(big, max(a0, a1));
+        if (qt) {
+            tiny = min(tiny, min(a0 - 1u, a1 - 1u));
+            // nearest with ties away on the 3-bit mantissa, then 256 and above -> 240 (nothing lies between)
+            v[2 * p] = __builtin_amdgcn_fmed3f(__uint_as_float((u0 + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
+            v[2 * p + 1] = __builtin_amdgcn_fmed3f(__uint_as_float((u1 + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
+        } else {
+            v[2 * p] = t0;
+            v[2 * p + 1] = t1;
+        }
+    }
+    bool slow = special != 0 || tie <= 8u;
+    if constexpr (DT == LLMC_F16) slow = slow || tiny16 < 0x387fffffu || big >= 0x477fe000u;
+    if (qt) slow = slow || tiny < 0x3c7fffffu;
+    else slow = slow || big > 0x43e80000u;                                // 464
+    if (slow) return false;
+    // four codes per dword straight from the converter (word select: low / high half of the destination)
+    uint32_t lo = 0, hi = 0;
+    lo = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], (int)lo, false);
+    lo = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], (int)lo, true);
+    hi = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], (int)hi, false);
+    hi = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], (int)hi, true);
+    if (mode & FP8_FAKE) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint8_t c = (uint8_t)((k < 4 ? lo : hi) >> (8 * (k & 3)));
+            of[k] = from_f32<T>(opaque_f32((qt ? v[k] : e4m3fn_to_f32(c)) * s));
+        }
+    } else {
+        *ob = make_uint2(lo, hi);
+    }
+    return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const T* __restrict__ amax, int sdt,
                                                  void* __restrict__ scales, int static_scales, int64_t G, int64_t g,
@@ -70,40 +168,106 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
     const int pdt = promote(DT, sdt);
     const int tdt = (G == 1) ? DT : pdt;   // a 0-dim fp32 scale does not promote the [R,K] tensor, a [R,1] one does
     const bool vec = (g % V == 0) && (((uintptr_t)W & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    // the division-free form: 16-bit tensors whose quotient is rounded in their own dtype, e4m3, a scale whose reciprocal is an
+    // ordinary number (checked per row below)
+    const bool fast_kind = (V == 8) && tdt == DT && ((mode >> FP8_FMT_SHIFT) & 3) == 0 && !(mode & FP8_EXACT_DIV);
     const int64_t total = G * g;
     if (vec) {
+        // four vectors per thread and turn, their loads issued together (one 16-byte load in flight per thread left the kernel
+        // at 3.8 TB/s, profiles/r04_fp8_cast_ab.txt); a per_tensor call (G == 1) has no row arithmetic at all
+        constexpr int U = FP8_U;
+        // FP8_PATTERN 1: a workgroup walks U * 256 consecutive vectors per turn (stride between a thread's vectors = 256);
+        // 0: a thread's vectors are a whole grid apart
         const int64_t nv = total / V;
-        for (int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * FB) {
-            const int64_t e0 = i * V;
-            const int64_t row = e0 / g;
-            float s;
-            if (static_scales) {
-                s = load_as_f32(scales, row, sdt);
-            } else {
-                s = rnd(to_f32<T>(amax[row]) / fmax, sdt);
-                if (e0 == row * g) store_from_f32(scales, row, sdt, s);
-            }
-            if (s == 0.0f) s = 1.0f;                              // scales[scales == 0] = 1 (quant.py:1062)
-            uint4 raw = *reinterpret_cast<const uint4*>(W + e0);
-            T wv[V];
-            __builtin_memcpy(wv, &raw, 16);
-            T of[V];
-            uint8_t ob[V];
+        const int64_t stride = FP8_PATTERN ? (int64_t)FB : (int64_t)gridDim.x * FB;
+        const int64_t first = FP8_PATTERN ? (int64_t)blockIdx.x * (U * FB) + threadIdx.x : (int64_t)blockIdx.x * FB + threadIdx.x;
+        const int64_t turn = (int64_t)gridDim.x * FB * U;
+        const int64_t vpr = g / V;                                       // vectors per row
+        for (int64_t i0 = first; i0 < nv; i0 += turn) {
+            uint4 raw[U];
 #pragma unroll
-            for (int k = 0; k < V; k += 2) fp8_two<T>(to_f32<T>(wv[k]), to_f32<T>(wv[k + 1]), s, tdt, mode, &of[k], &ob[k]);
-            if (fake) {
-                uint4 o;
-                __builtin_memcpy(&o, of, 16);
-                *reinterpret_cast<uint4*>((T*)out + e0) = o;
-            } else {
-                if constexpr (V == 8) {
-                    uint2 o;
-                    __builtin_memcpy(&o, ob, 8);
-                    *reinterpret_cast<uint2*>((uint8_t*)out + e0) = o;
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * stride;
+                if (i < nv) raw[u] = *reinterpret_cast<const uint4*>(W + i * V);
+            }
+            auto scale_of = [&](int64_t i) {
+                const int64_t row = (G == 1) ? 0 : (nv < (int64_t)0xffffffffll ? (int64_t)((uint32_t)i / (uint32_t)vpr) : i / vpr);
+                float s;
+                if (static_scales) {
+                    s = load_as_f32(scales, row, sdt);
                 } else {
-                    uint32_t o;
-                    __builtin_memcpy(&o, ob, 4);
-                    *reinterpret_cast<uint32_t*>((uint8_t*)out + e0) = o;
+                    s = rnd(to_f32<T>(amax[row]) / fmax, sdt);
+                    if (i * V == row * g) store_from_f32(scales, row, sdt, s);
+                }
+                return s == 0.0f ? 1.0f : s;                          // scales[scales == 0] = 1 (quant.py:1062)
+            };
+            uint32_t todo = 0;                       // bit u: vector u is left to the general encoder below
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * stride;
+                if (i < nv) {
+                    bool done = false;
+                    if constexpr (V == 8) {
+                        if (fast_kind) {
+                            const float s = scale_of(i);
+                            if (s > 1e-30f && s < 1e30f) {
+                                T of[V];
+                                uint2 ob;
+                                done = fp8_fast8<T>(raw[u], s, 1.0f / s, mode, of, &ob);
+                                if (done) {
+                                    if (fake) {
+                                        uint4 o;
+                                        __builtin_memcpy(&o, of, 16);
+                                        *reinterpret_cast<uint4*>((T*)out + i * V) = o;
+                                    } else {
+                                        *reinterpret_cast<uint2*>((uint8_t*)out + i * V) = ob;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!done) todo |= 1u << u;
+                }
+            }
+            // one copy of the general encoder (inlined four times it pushed the kernel past the instruction cache: 90 us
+            // instead of 61, profiles/r04_fp8_cast_ab.txt)
+#pragma unroll 1
+            for (int u = 0; u < U; ++u) {
+                if (!((todo >> u) & 1u)) continue;
+                uint4 r = raw[0];
+#pragma unroll
+                for (int v = 1; v < U; ++v)
+                    if (u == v) r = raw[v];
+                const int64_t i = i0 + u * stride;
+                const float s = scale_of(i);
+#pragma unroll 1
+                for (int pr = 0; pr < V / 2; ++pr) {                    // a pair of elements at a time, one encoder instance
+                    float w0, w1;
+                    if constexpr (V == 8) {
+                        uint32_t word = r.x;
+                        if (pr == 1) word = r.y;
+                        if (pr == 2) word = r.z;
+                        if (pr == 3) word = r.w;
+                        T a, b;
+                        a.u = (uint16_t)(word & 0xffffu);
+                        b.u = (uint16_t)(word >> 16);
+                        w0 = to_f32<T>(a);
+                        w1 = to_f32<T>(b);
+                    } else {
+                        w0 = __uint_as_float(pr ? r.z : r.x);
+                        w1 = __uint_as_float(pr ? r.w : r.y);
+                    }
+                    T of[2];
+                    uint8_t ob[2];
+                    fp8_two<T>(w0, w1, s, tdt, mode & ~FP8_EXACT_DIV, of, ob);
+                    const int64_t e = i * V + 2 * pr;
+                    if (fake) {
+                        ((T*)out)[e] = of[0];
+                        ((T*)out)[e + 1] = of[1];
+                    } else {
+                        ((uint8_t*)out)[e] = ob[0];
+                        ((uint8_t*)out)[e + 1] = ob[1];
+                    }
                 }
             }
         }
@@ -121,7 +285,7 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
         if (s == 0.0f) s = 1.0f;
         T of;
         uint8_t ob;
-        fp8_one<T>(to_f32<T>(W[i]), s, tdt, mode, DT, &of, &ob);
+        fp8_one<T>(to_f32<T>(W[i]), s, tdt, mode & ~FP8_EXACT_DIV, DT, &of, &ob);
         if (fake) ((T*)out)[i] = of; else ((uint8_t*)out)[i] = ob;
     }
 }
@@ -175,6 +339,11 @@ static inline int grid_fb(int64_t n) {
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+static inline int grid_cast(int64_t n) {
+    int64_t b = ceil_div64(n, FB);
+    return (int)(b > FP8_GRID_CAP ? FP8_GRID_CAP : (b < 1 ? 1 : b));
+}
+
 }  // namespace llmc
 
 using namespace llmc;
@@ -198,15 +367,15 @@ extern "C" int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int f
     hipStream_t st = (hipStream_t)stream;
     switch (dt) {
         case LLMC_F16:
-            hipLaunchKernelGGL((k_fp8_cast<f16_t>), dim3(grid_fb(G * g / 8 + 1)), dim3(FB), 0, st, (const f16_t*)W,
+            hipLaunchKernelGGL((k_fp8_cast<f16_t>), dim3(grid_cast(G * g / (8 * FP8_U) + 1)), dim3(FB), 0, st, (const f16_t*)W,
                                (const f16_t*)amax, sdt, scales, static_scales, G, g, fake, out);
             break;
         case LLMC_BF16:
-            hipLaunchKernelGGL((k_fp8_cast<bf16_t>), dim3(grid_fb(G * g / 8 + 1)), dim3(FB), 0, st, (const bf16_t*)W,
+            hipLaunchKernelGGL((k_fp8_cast<bf16_t>), dim3(grid_cast(G * g / (8 * FP8_U) + 1)), dim3(FB), 0, st, (const bf16_t*)W,
                                (const bf16_t*)amax, sdt, scales, static_scales, G, g, fake, out);
             break;
         default:
-            hipLaunchKernelGGL((k_fp8_cast<float>), dim3(grid_fb(G * g / 4 + 1)), dim3(FB), 0, st, (const float*)W,
+            hipLaunchKernelGGL((k_fp8_cast<float>), dim3(grid_cast(G * g / (4 * FP8_U) + 1)), dim3(FB), 0, st, (const float*)W,
                                (const float*)amax, sdt, scales, static_scales, G, g, fake, out);
     }
     LLMC_LAUNCH_CHECK();
