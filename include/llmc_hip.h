@@ -150,6 +150,9 @@ int llmc_pack_awq_gemm(const void* weight, int wdt, const void* scales, int sdt,
  *              IEEE-style formats, ties away from zero, saturation at 240 / 57344); 0 = torch's dtype cast
  *              (.to(torch.float8_e4m3fn / float8_e5m2): round to nearest even, OCP e4m3fn up to 448), which is what
  *              the reference's real-quant path ends in (quant.py:1183, 1211) and what its Triton kernels compute.
+ *   bit 9      evaluate every element with the IEEE division and the general encoder. Results are identical with and
+ *              without it: 16-bit e4m3 calls otherwise use w * fl(1 / scale) and send only the lanes near a rounding
+ *              boundary (or outside the 8-bit format's normal range) through the division (tests/test_fp8_fast_gpu.py).
  * Codes are OCP e4m3fn / IEEE e5m2 bytes in both cases (every qtorch result is representable). scales [G] in dtype sdt:
  * ATen yields fp32 for the 0-dim per-tensor scale and the tensor dtype for per-channel.
  * static_scales != 0: `scales` is INPUT (fake_quant_act_static / real_quant_weight_static, quant.py:1083-1099). */
