@@ -37,6 +37,12 @@ def run(name, K, Rs, T=65536):
 
 
 if __name__ == '__main__':
+    if '--70b' in sys.argv:                       # Llama-3-70B subset shapes (BASELINE configs[3])
+        run('q|k|v', 8192, [8192, 1024, 1024], T=32768)
+        run('o', 8192, [8192], T=32768)
+        run('gate|up', 8192, [28672, 28672], T=32768)
+        run('down', 28672, [8192], T=16384)
+        sys.exit(0)
     run('q|k|v', 4096, [4096, 1024, 1024])
     run('o', 4096, [4096])
     run('gate|up', 4096, [14336, 14336])
