@@ -4,6 +4,7 @@
 //                       qtorch_quantize; the library is a third-party dependency absent from the reference tree), or
 //                       torch's own dtype cast (float8_e4m3fn / float8_e5m2, RNE) for the callers that end in one.
 //   llmc_pack_awq_gemm  module_utils.py:1004-1065.
+#include <stdlib.h>
 #include "common.h"
 #include "fp8_math.h"
 
@@ -73,8 +74,7 @@ __device__ __forceinline__ void fp8_two(float w0, float w1, float s, int tdt, in
 // t = rnd_dt(fl32(w / s)) is what the reference's `tensor / scales` leaves (ATen divides in fp32, then rounds to the tensor
 // dtype). q = w * fl32(1 / s) is within 3 fp32 ulps of fl32(w / s), so both round to the same dt value unless q lies within
 // 4 ulps of a dt rounding boundary (9 of 65536 bf16 patterns, 9 of 8192 fp16 patterns) — those lanes, f16 results outside
-// the normal range, non-finite values, values in the 8-bit format's subnormal range (|t| < 2^-6) and, for the dtype cast,
-// |t| > 464 take the division and the general encoder instead (FP8_EXACT_DIV in `mode` sends everything there: the A/B switch
+// the normal range, non-finite values and, for the dtype cast, |t| > 464 take the division and the general encoder instead (FP8_EXACT_DIV in `mode` sends everything there: the A/B switch
 // of tests/test_fp8_fast_gpu.py). e4m3 only; qtorch semantics on the fast path = (bits + 0x80000) & ~0xfffff, saturated to
 // 240 from 256 upwards (fp8_math.h:qtorch_quantize), then the exact hardware conversion of the on-grid values.
 static constexpr int FP8_EXACT_DIV = 0x200;
@@ -85,10 +85,9 @@ __device__ __forceinline__ bool fp8_fast8(const uint4 raw, float s, float rs, in
     const uint32_t word[4] = {raw.x, raw.y, raw.z, raw.w};
     // guards as running minima / maxima (one v_min3 / v_max3 per pair instead of compare + or per element):
     //   tie   = min of ((q bits & low mask) - (midpoint - 4)) as unsigned: <= 8 means within 4 ulps of a rounding boundary
-    //   tiny  = min of (|t| bits - 1) as unsigned: a nonzero |t| below 2^-6 (the 8-bit format's subnormal range) [qtorch] /
-    //           a nonzero fp16 quotient below the fp16 normal range
+    //   tiny16 = min of (|q| bits - 1) as unsigned: a nonzero fp16 quotient below the fp16 normal range
     //   big   = max of |t| bits: above 464 [cast], at the top of the fp16 range
-    uint32_t special = 0, tie = 0xffffffffu, tiny = 0xffffffffu, tiny16 = 0xffffffffu, big = 0;
+    uint32_t special = 0, tie = 0xffffffffu, tiny16 = 0xffffffffu, big = 0;
     float v[8];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -125,10 +124,18 @@ __device__ __forceinline__ bool fp8_fast8(const uint4 raw, float s, float rs, in
         const uint32_t a0 = u0 & 0x7fffffffu, a1 = u1 & 0x7fffffffu;
         big = max(big, max(a0, a1));
         if (qt) {
-            tiny = min(tiny, min(a0 - 1u, a1 - 1u));
             // nearest with ties away on the 3-bit mantissa, then 256 and above -> 240 (nothing lies between)
-            v[2 * p] = __builtin_amdgcn_fmed3f(__uint_as_float((u0 + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
-            v[2 * p + 1] = __builtin_amdgcn_fmed3f(__uint_as_float((u1 + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
+            const float n0 = __builtin_amdgcn_fmed3f(__uint_as_float((u0 + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
+            const float n1 = __builtin_amdgcn_fmed3f(__uint_as_float((u1 + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
+            // below 2^-6 (the format's subnormal range) qtorch rounds x + sign * 2^-6 and subtracts the shift again: the
+            // multiples of 2^-9, ties away, and a result of zero is +0 (x - x). Per-tensor scales put a good share of a weight
+            // with outlier channels here, so this is evaluated for every element and selected, not branched to
+            const float d0 = __uint_as_float(__float_as_uint(__builtin_floorf(__builtin_fmaf(__uint_as_float(a0), 512.0f, 0.5f)) * 0.001953125f) |
+                                             (u0 & 0x80000000u)) + 0.0f;
+            const float d1 = __uint_as_float(__float_as_uint(__builtin_floorf(__builtin_fmaf(__uint_as_float(a1), 512.0f, 0.5f)) * 0.001953125f) |
+                                             (u1 & 0x80000000u)) + 0.0f;
+            v[2 * p] = a0 < 0x3c800000u ? d0 : n0;
+            v[2 * p + 1] = a1 < 0x3c800000u ? d1 : n1;
         } else {
             v[2 * p] = t0;
             v[2 * p + 1] = t1;
@@ -136,8 +143,7 @@ __device__ __forceinline__ bool fp8_fast8(const uint4 raw, float s, float rs, in
     }
     bool slow = special != 0 || tie <= 8u;
     if constexpr (DT == LLMC_F16) slow = slow || tiny16 < 0x387fffffu || big >= 0x477fe000u;
-    if (qt) slow = slow || tiny < 0x3c7fffffu;
-    else slow = slow || big > 0x43e80000u;                                // 464
+    if (!qt) slow = slow || big > 0x43e80000u;                                // 464
     if (slow) return false;
     // four codes per dword straight from the converter (word select: low / high half of the destination)
     uint32_t lo = 0, hi = 0;
@@ -364,6 +370,8 @@ extern "C" int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int f
         int rc = llmc_minmax_qparams(W, dt, G, g, /*sym*/ 1, 1, -1.0f, 1.0f, amax, nullptr, ws2, stream);
         if (rc) return rc;
     }
+    static const bool exact_div_env = getenv("LLMC_FP8_EXACT_DIV") != nullptr;      // A/B switch, same results (include/llmc_hip.h)
+    if (exact_div_env) fake |= FP8_EXACT_DIV;
     hipStream_t st = (hipStream_t)stream;
     switch (dt) {
         case LLMC_F16:

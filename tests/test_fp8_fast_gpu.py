@@ -32,6 +32,7 @@ def test_fast_cast_equals_the_exact_division_path(dt, sem):
     R, K = 4096, 4096
     w = torch.randn(R, K, generator=gen) * 0.03
     w[torch.rand(R, K, generator=gen) < 1e-3] *= 6
+    w[:, torch.randperm(K, generator=gen)[:4]] *= 20      # outlier channels: the per-tensor scale pushes ~0.3 % of the elements below 2^-6
     w[0, :64] = 0.0
     w[1, :64] = -0.0
     w[2, :64] = 1e-7                      # the 8-bit format's subnormal range after scaling

@@ -9,7 +9,9 @@ if os.environ.get('LLMC_PROBE_LIB'):
     print('library', _ffi.LIB_PATH)
 
 L = _ffi.lib()
-w = (torch.randn(14336, 4096, device='cuda') * 0.02).to(torch.bfloat16)
+w = torch.randn(14336, 4096, device='cuda') * 0.02
+w[:, torch.randperm(4096, device='cuda')[:4]] *= 20.0          # outlier channels, like bench.py's synth_weight
+w = w.to(torch.bfloat16)
 n = w.numel()
 s = (w.abs().max().float() / 448.0).reshape(1).contiguous()
 codes = torch.empty(w.shape, dtype=torch.uint8, device='cuda')
