@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "fp8_math.h"
+#include "quant_math.h"
 #include "mfma_common.h"
 
 namespace llmc {
@@ -91,6 +92,11 @@ __global__ __launch_bounds__(256) void k_fp8_block_quant128(const T* __restrict_
         if (tid == 0) scales[(int64_t)blockIdx.y * nbn + blockIdx.x] = s;
     }
     if (zero_scale_to_one && s == 0.0f) s = 1.0f;
+    // x / s for the block's 16384 elements: with a plain divisor and plain numerators the IEEE quotient is the five-op tail
+    // of the division sequence on the refined reciprocal, bit for bit (quant_math.h: rcp_refined, div_tail)
+    const bool plain = plain_pos(s) && am < 0x1p40f && !(fake & 0x200);
+    const float yr = rcp_refined(s);
+    auto quot = [&](float x) { return (plain ? div_tail(x, s, yr) : x / s) + 0.0f; };
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int64_t off = (r0 + (tid >> 4) + 16 * j) * N + col;
@@ -98,11 +104,17 @@ __global__ __launch_bounds__(256) void k_fp8_block_quant128(const T* __restrict_
         float dq[8];
         if (fake & 0x100) {          // FloatQuantizer: qtorch.float_quantize (fp8_math.h), not the dtype cast
 #pragma unroll
-            for (int e = 0; e < 8; ++e) q[e] = fp8_encode(v[j][e] / s + 0.0f, 0, 1, &dq[e]);
+            for (int e = 0; e < 8; ++e) dq[e] = qtorch_e4m3_select(quot(v[j][e]));
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {                 // the quantized values are e4m3 numbers: the conversion is exact
+                const uint32_t c = fb_f32x2_to_e4m3fn(dq[e], dq[e + 1]);
+                q[e] = (uint8_t)c;
+                q[e + 1] = (uint8_t)(c >> 8);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                const uint32_t c = fb_f32x2_to_e4m3fn(v[j][e] / s + 0.0f, v[j][e + 1] / s + 0.0f);
+                const uint32_t c = fb_f32x2_to_e4m3fn(quot(v[j][e]), quot(v[j][e + 1]));
                 q[e] = (uint8_t)c;
                 q[e + 1] = (uint8_t)(c >> 8);
             }
@@ -205,10 +217,15 @@ __global__ __launch_bounds__(256) void k_fp8_act_quant128(const T* __restrict__ 
         am = wave_max(am, 16);
         const float s = am / 448.0f;
         if (sub == 0) S[blk0 + h] = s;
+        // plain divisor and numerators: the IEEE quotient from the refined reciprocal (quant_math.h); an all-zero block
+        // (s = 0: the reference's 0 / 0) and anything unusual keep the division
+        const bool plain = plain_pos(s) && am < 0x1p40f;
+        const float yr = rcp_refined(s);
         uint8_t q[8];
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-            const uint32_t c = fb_f32x2_to_e4m3fn(v[h][e] / s, v[h][e + 1] / s);
+            const uint32_t c = plain ? fb_f32x2_to_e4m3fn(div_tail(v[h][e], s, yr), div_tail(v[h][e + 1], s, yr))
+                                     : fb_f32x2_to_e4m3fn(v[h][e] / s, v[h][e + 1] / s);
             q[e] = (uint8_t)c;
             q[e + 1] = (uint8_t)(c >> 8);
         }
