@@ -5,6 +5,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from llmc_amd import _ffi
+if os.environ.get('LLMC_PROBE_LIB'):          # lab builds (tools/probes): A/B of one kernel file
+    _ffi.LIB_PATH = os.environ['LLMC_PROBE_LIB']
 from llmc_amd.compression.quantization import gptq_ops
 from llmc_amd.compression.quantization.hessian import HessianAccumulator
 
