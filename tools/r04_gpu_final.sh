@@ -2,7 +2,7 @@
 # round-4 evidence: full GPU tests, smoke, the default bench line (with extras + the reference on the host cores), kernel
 # stats, PMC traffic of the dominant kernel, stage times, AWQ kernel stats, the full-size down_proj parity envelope.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04final; mkdir -p $O
+O=gpurun_out/r04final2; mkdir -p $O
 rm -f $O/actuals.jsonl
 ( time LLMC_TEST_ACTUALS=$PWD/$O/actuals.jsonl timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider ) > $O/tests.log 2>&1; tail -8 $O/tests.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -22,4 +22,4 @@ bash tools/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log; cp $O/pmc/
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kta -o kta -- python bench.py --workload awq --steps 2 --warmup 1 --no-cpu-baseline > $O/kta.log 2>&1
 F=$(ls $O/kta/*/*kernel_trace.csv $O/kta/*kernel_trace.csv 2>/dev/null | head -1)
 python tools/kernel_stats_csv.py $F 16 > $O/awq_kernel_stats.txt 2>&1; rm -rf $O/kta; head -8 $O/awq_kernel_stats.txt
-( time timeout 1500 python tools/parity_envelope.py --full-down --out $O/parity_envelope_full_down ) > $O/envelope.log 2>&1; tail -30 $O/envelope.log
+[ -n "$SKIP_ENVELOPE" ] || ( time timeout 1500 python tools/parity_envelope.py --full-down --out $O/parity_envelope_full_down ) > $O/envelope.log 2>&1; tail -30 $O/envelope.log
