@@ -80,7 +80,26 @@ __global__ __launch_bounds__(HB) void k_minmax_samples(MinmaxSamplesArgs a) {
     constexpr int V = 16 / sizeof(T);
     if (c0 < n) {
         const int64_t v1 = c0 + ((c1 - c0) / V) * V;      // c0 is a multiple of V (MM_CHUNK is), the base is 16-B aligned
-        for (int64_t i = c0 + (int64_t)threadIdx.x * V; i < v1; i += (int64_t)HB * V) {
+        // four 16-byte loads in flight per thread (one per turn left the kernel at 3.8 TB/s on the 18 inputs of a Mixtral block)
+        int64_t i = c0 + (int64_t)threadIdx.x * V;
+        for (; i + 3 * (int64_t)HB * V < v1; i += 4 * (int64_t)HB * V) {
+            uint4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(x + i + u * (int64_t)HB * V);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                T v[V];
+                __builtin_memcpy(v, &r[u], 16);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float f = to_f32<T>(v[k]);
+                    mn = fminf(mn, f);
+                    mx = fmaxf(mx, f);
+                    bad = f != f ? 1.0f : bad;
+                }
+            }
+        }
+        for (; i < v1; i += (int64_t)HB * V) {
             const uint4 r = *reinterpret_cast<const uint4*>(x + i);
             T v[V];
             __builtin_memcpy(v, &r, 16);
