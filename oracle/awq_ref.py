@@ -209,3 +209,30 @@ def clip_argmin_levels(errs, w, g, dt, clip_sym, n_grid=20):
         best_max = np.where(better, max_val, best_max)
         best_min = np.where(better, min_val, best_min)
     return best_max, best_min
+
+
+# ---- AWQ with activation quantization / other weight quantizers (awq.py:147-177, 223-224) ---------------------------------
+def fake_quant_any(x, dt, kind, bit, sym, granularity, group_size=0):
+    """fake_quant_{weight,act}_dynamic of IntegerQuantizer / FloatQuantizer (use_qtorch) on an array of dt values: ranges over
+    the last dimension (per_channel / per_token), over groups of it (per_group) or over the whole array (per_tensor)."""
+    x = np.asarray(x, dtype=np.float32)
+    rows = Q.reshape_rows(x, 'per_channel' if granularity == 'per_token' else granularity, group_size or None)
+    if kind == 'int':
+        qmin, qmax = Q.int_range(int(bit), bool(sym))
+        if granularity == 'per_tensor' and not sym:
+            return Q.per_tensor_asym_fake_and_codes(x, dt, qmin, qmax)[0].reshape(x.shape)
+        return Q.fake_quant_dynamic(rows, dt, bool(sym), qmin, qmax)[0].reshape(x.shape)
+    return Q.fp8_fake(rows, dt, str(bit), 'qtorch').reshape(x.shape)
+
+
+def wa_chain_point(w, x, s, dt, wcfg, acfg, per_sample=False):
+    """One grid point of the W-A search: fake_quantize_weight = fake-quant of w * s (awq.py:155-156), fake_quantize_input =
+    fake-quant of x / s, the whole batch or sample by sample (awq.py:166-177). wcfg / acfg = (kind, bit, sym, granularity
+    [, group_size])."""
+    wq = fake_quant_any(rnd(np.asarray(w, dtype=np.float32) * np.asarray(s, dtype=np.float32)[None, :], dt), dt, *wcfg)
+    xs = scaling_input(x, s, dt)
+    if per_sample:
+        xq = np.stack([fake_quant_any(xs[i], dt, *acfg) for i in range(xs.shape[0])])
+    else:
+        xq = fake_quant_any(xs, dt, *acfg)
+    return wq, xq

@@ -375,6 +375,32 @@ def test_auto_clip_from_candidates_matches_reference_for_wide_groups_act_quant_f
         np.testing.assert_array_equal(mn.reshape(g[p + 'best_min'].shape), g[p + 'best_min'], err_msg=name)
 
 
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_awq_with_activation_quantization_chain_point_bit_exact():
+    """awq_wa.npz: the scaled + fake-quantized weight and the scaled + fake-quantized input of one grid point, as the
+    reference formed them for W8A8 / W4A8 (per-sample per_tensor activations) / FP8 e4m3 per_tensor (awq_fp8_static.yml) /
+    FP8 e5m2 / per_tensor INT8 weights — restated with the oracle's quantizers (oracle/awq_ref.py:wa_chain_point)."""
+    g = load_golden('awq_wa')
+
+    def cfg(a):
+        a = [str(v) for v in a]
+        out = [a[0], a[1] if a[0] == 'float' else int(a[1]), a[2] == 'True', a[3]]
+        if len(a) > 4:
+            out.append(int(a[4]))
+        return tuple(out)
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        K, R, nb, awq_bs = [int(v) for v in g[p + 'meta']]
+        dt = str(g[p + 'dt'])
+        wq, xq = A.wa_chain_point(g[p + 'w_gate_proj'], g[p + 'x0'], g[p + 'scales_r040'], dt, cfg(g[p + 'wcfg']), cfg(g[p + 'acfg']),
+                                  per_sample=bool(awq_bs) and awq_bs != g[p + 'x0'].shape[0])
+        np.testing.assert_array_equal(bits(wq), bits(g[p + 'wq_r040']), err_msg=name)
+        np.testing.assert_array_equal(bits(xq), bits(g[p + 'xq_r040']), err_msg=name)
+
+
 def test_per_tensor_asymmetric_bit_exact():
     """quant_pt.npz: fp32 0-dim qparams, op results in the tensor dtype."""
     g = load_golden('quant_pt')
