@@ -11,7 +11,9 @@
 namespace llmc {
 
 static constexpr int FB = 256;
-// k_fp8_cast: vectors per thread and turn, and how they are laid out (see the kernel); lab builds override them
+// k_fp8_cast: vectors per thread and turn (U), their layout and the grid cap. Measured on a 14336 x 4096 weight
+// (tools/probes/build_fp8_variants.sh, profiles/r04_fp8_cast_ab.txt): ONE vector per thread is the fastest — the kernel is
+// bound by its VALU work, not by loads in flight (U = 2 equal, U = 4 / 8 and a smaller grid slower). Lab builds override.
 #ifndef FP8_U
 #define FP8_U 1
 #endif
@@ -179,8 +181,7 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
     const bool fast_kind = (V == 8) && tdt == DT && ((mode >> FP8_FMT_SHIFT) & 3) == 0 && !(mode & FP8_EXACT_DIV);
     const int64_t total = G * g;
     if (vec) {
-        // four vectors per thread and turn, their loads issued together (one 16-byte load in flight per thread left the kernel
-        // at 3.8 TB/s, profiles/r04_fp8_cast_ab.txt); a per_tensor call (G == 1) has no row arithmetic at all
+        // U vectors per thread and turn, their loads issued together; a per_tensor call (G == 1) has no row arithmetic at all
         constexpr int U = FP8_U;
         // FP8_PATTERN 1: a workgroup walks U * 256 consecutive vectors per turn (stride between a thread's vectors = 256);
         // 0: a thread's vectors are a whole grid apart
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
                     if (!done) todo |= 1u << u;
                 }
             }
-            // one copy of the general encoder (inlined four times it pushed the kernel past the instruction cache: 90 us
-            // instead of 61, profiles/r04_fp8_cast_ab.txt)
+            // one copy of the general encoder, rolled over pairs (inlined per vector and element it made the kernel 10.6 k
+            // instructions long)
 #pragma unroll 1
             for (int u = 0; u < U; ++u) {
                 if (!((todo >> u) & 1u)) continue;
