@@ -191,3 +191,18 @@ def test_llama_awq_with_activation_quantization_through_the_reference_main(tmp_p
                     assert st['act_scale_rel'] <= 2e-2, (n, st)
         assert ratio <= 0.10, (m, ratio)
         assert abs(pa - pb) <= 2e-2 * pa, (m, pa, pb)
+
+
+@needs_ref
+def test_llama_spqr_through_the_reference_main(tmp_path):
+    """configs/quantization/methods/SpQR/spqr_w_only.yml (W4 g16, 3-bit second-level scale / zero statistics, outliers left in
+    floating point, actorder, true_sequential + quant_out) through the reference's main(config), with and without the binding."""
+    res = run_arms(tmp_path, 'llama', ['spqr'])
+    w0 = original_weights(tmp_path, 'llama')
+    stats, pa, pb = compare('llama_spqr', *res['spqr'])
+    ratio = quant_error_ratio('llama_spqr', w0, *res['spqr'])
+    for n, st in stats.items():
+        if is_first_subset(n):
+            assert st['w_close'] >= 0.99, (n, st)
+    assert ratio <= 0.10, ratio
+    assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)

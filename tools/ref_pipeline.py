@@ -96,6 +96,15 @@ CONFIGS = {
         quant=dict(method='RTN', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128)),
         calib=None,
         ignored_layers=dict(block_ids=[0], layer_names=['self_attn.q_proj', 'self_attn.v_proj'], speical_names=['@PREFIX@.1.self_attn.k_proj'])),
+    # configs/quantization/methods/SpQR/spqr_w_only.yml: W4 g16 with 3-bit second-level statistics, outliers kept in fp
+    'spqr': dict(
+        quant=dict(method='SpQR', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=16, round_zp=False),
+                   special=dict(actorder=True, percdamp=1, blocksize=128, true_sequential=True, relative_threshold=0.2,
+                                simplified_outliers=False,
+                                scale=dict(bit=3, symmetric=False, granularity='per_group', group_size=16, round_zp=False),
+                                zero=dict(bit=3, symmetric=False, granularity='per_group', group_size=16, round_zp=False)),
+                   quant_out=True),
+        calib=dict(name='wikitext2', download=False, n_samples=128, bs=1, seq_len=64, preproc='wikitext2_gptq')),
     # AWQ with ACTIVATION quantization (awq.py:166-177, 223-224; auto_clip.py:276-281): configs/quantization/methods/Awq/
     # awq_w_a.yml's shape — W8 per_channel + A8 per_token dynamic, scale search and weight clip with quantized inputs
     'awq_w8a8': dict(
@@ -307,7 +316,7 @@ def main():
     mdir, ddir = make_assets(a.assets, a.arch, n_layers=a.layers)
     M, stubbed = import_reference_main(ref_dir)
     from llmc.utils.registry_factory import ALGO_REGISTRY
-    ref_classes = {k: ALGO_REGISTRY[k] for k in ('GPTQ', 'Awq', 'RTN')}
+    ref_classes = {k: ALGO_REGISTRY[k] for k in ('GPTQ', 'Awq', 'RTN', 'SpQR')}
     dist.init_process_group(backend='nccl' if gpu else 'gloo', rank=0, world_size=1)     # llmc/__main__.py:191
     if gpu:
         torch.cuda.set_device(0)
