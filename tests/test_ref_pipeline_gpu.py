@@ -206,3 +206,34 @@ def test_llama_spqr_through_the_reference_main(tmp_path):
             assert st['w_close'] >= 0.99, (n, st)
     assert ratio <= 0.10, ratio
     assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)
+
+
+@needs_ref
+def test_export_step_of_the_reference_main_writes_the_same_checkpoints(tmp_path):
+    """main()'s save branch (llmc/__main__.py:95-144) in both arms: RTN W4 sym g128 -> deploy('vllm_quant') + save_model +
+    update_vllm_quant_config (compressed-tensors pack-quantized), AWQ W4 asym g128 -> deploy('autoawq_quant') + save_model +
+    update_autoawq_quant_config (AutoAWQ GEMM layout). The saved tensors of every decoder layer and the quantization config in
+    config.json are compared: RTN bit for bit (packed int32 words, scales, shapes); AWQ's packed words on block 0 (identical
+    inputs) agree like its fake-quantized weights do, the names, shapes, dtypes and the config are identical."""
+    from conftest import report
+    res = run_arms(tmp_path, 'llama', ['rtn_vllm', 'awq_autoawq'])
+    for m in ('rtn_vllm', 'awq_autoawq'):
+        ref, ours = res[m]
+        ka = sorted(k for k in ref if k.startswith('ckpt/'))
+        kb = sorted(k for k in ours if k.startswith('ckpt/'))
+        assert ka == kb and len(ka) > 0, (m, set(ka) ^ set(kb))
+        assert str(ref['ckpt_config']) == str(ours['ckpt_config']) and len(str(ref['ckpt_config'])) > 2, m
+        packed = [k for k in ka if ref[k].dtype.kind in 'iu']
+        assert packed, m                                            # real-quantized layers were written
+        worst = 1.0
+        for k in ka:
+            a, b = ref[k], ours[k]
+            assert a.shape == b.shape and a.dtype == b.dtype, (m, k)
+            eq = float((a == b).mean())
+            report(f'ref_pipeline/{m}/{k}', equal=eq)
+            if m == 'rtn_vllm':
+                assert eq == 1.0, (k, eq)
+            elif '.layers.0.' in k:
+                worst = min(worst, eq)
+        if m == 'awq_autoawq':
+            assert worst >= 0.90, worst

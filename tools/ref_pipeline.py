@@ -96,6 +96,16 @@ CONFIGS = {
         quant=dict(method='RTN', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128)),
         calib=None,
         ignored_layers=dict(block_ids=[0], layer_names=['self_attn.q_proj', 'self_attn.v_proj'], speical_names=['@PREFIX@.1.self_attn.k_proj'])),
+    # the export step of main() (llmc/__main__.py:95-144): deploy('vllm_quant') + save_model + update_vllm_quant_config for the
+    # compressed-tensors layout (configs/quantization/backend/vllm/rtn_w4a16.yml), deploy('autoawq_quant') + save_model +
+    # update_autoawq_quant_config for AutoAWQ's GEMM layout (backend/autoawq/awq_w4a16.yml); the saved checkpoints are compared
+    'rtn_vllm': dict(
+        quant=dict(method='RTN', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128, need_pack=True)),
+        calib=None, save=dict(save_vllm=True)),
+    'awq_autoawq': dict(
+        quant=dict(method='Awq', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=128, pack_version='gemm_pack'),
+                   special=dict(trans=True, trans_version='v2', weight_clip=True, clip_sym=False)),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq'), save=dict(save_autoawq=True)),
     # configs/quantization/methods/SpQR/spqr_w_only.yml: W4 g16 with 3-bit second-level statistics, outliers kept in fp
     'spqr': dict(
         quant=dict(method='SpQR', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=16, round_zp=False),
@@ -150,6 +160,8 @@ def build_config(method, arch, mdir, ddir, save_path):
            'save': {'save_fake': False, 'save_path': save_path}}
     if c['calib']:
         cfg['calib'] = dict(c['calib'], path=ddir, seed=0)
+    if c.get('save'):
+        cfg['save'].update(c['save'])
     if c.get('ignored_layers'):
         il = c['ignored_layers']
         prefix = 'model.layers' if arch == 'llama' else 'model.decoder.layers'
@@ -230,6 +242,12 @@ def run_one(M, arm, method, arch, assets, mdir, ddir, stubbed, ref_classes):
             bind_restated_qtorch()
     config = EasyDict(build_config(method, arch, mdir, ddir, os.path.join(assets, f'save_{arm}_{method}')))
     check_config(config)
+    save_dir = None
+    for flag, sub in (('save_vllm', 'vllm_quant_model'), ('save_autoawq', 'autoawq_quant_model')):
+        if config.save.get(flag, False):           # the module-level global `if __name__ == '__main__'` sets (llmc/__main__.py:226-245)
+            save_dir = os.path.join(config.save.save_path, sub)
+            os.makedirs(save_dir, exist_ok=True)
+            M.save_quant_path = save_dir
     seed_all(config.base.seed + 0)          # what `if __name__ == '__main__'` does before main() (llmc/__main__.py:179-300)
 
     # capture: the algorithm object main() builds, and what the reference's evaluator reports
@@ -282,6 +300,15 @@ def run_one(M, arm, method, arch, assets, mdir, ddir, stubbed, ref_classes):
         out[f'{name}/type'] = np.array(type(mod).__module__ + '.' + type(mod).__name__)
         n += 1
     out['n_linear'] = np.array(n)
+    if save_dir:                                                    # the exported checkpoint, tensor by tensor, and its quantization config
+        from safetensors.torch import load_file
+        for f in sorted(os.listdir(save_dir)):
+            if f.endswith('.safetensors'):
+                for k, v in load_file(os.path.join(save_dir, f)).items():
+                    if 'layers.' in k:
+                        out['ckpt/' + k] = v.float().numpy() if v.is_floating_point() else v.numpy()
+        cj = json.load(open(os.path.join(save_dir, 'config.json')))
+        out['ckpt_config'] = np.array(json.dumps(cj.get('quantization_config', cj.get('compression_config', {})), sort_keys=True))
     print(f'ref_pipeline {arm} {method} {arch}: {n} linear layers, class from {cls.__module__}, ppl {captured["ppl"]}', flush=True)
     del opt, model, captured
     import gc
