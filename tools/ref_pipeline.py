@@ -106,6 +106,17 @@ CONFIGS = {
         quant=dict(method='Awq', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=128, pack_version='gemm_pack'),
                    special=dict(trans=True, trans_version='v2', weight_clip=True, clip_sym=False)),
         calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq'), save=dict(save_autoawq=True)),
+    # configs/quantization/backend/vllm/fp8/rtn_fp8.yml as shipped (per_channel weights, per_token dynamic activations), and the
+    # per-tensor form BASELINE configs[4] names (per_tensor weights, static per_tensor activations) — both exported for vLLM
+    'rtn_fp8': dict(
+        quant=dict(method='RTN', weight=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_channel', use_qtorch=True),
+                   act=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_token', use_qtorch=True)),
+        calib=None),      # no export: update_vllm_quant_config (export_vllm.py:33-42) asks every dynamic FP8 W-A config for weight.block_size
+    'rtn_fp8_tensor': dict(
+        quant=dict(method='RTN', weight=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_tensor', use_qtorch=True),
+                   act=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_tensor', use_qtorch=True, static=True,
+                            calib_algo='static_minmax')),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq'), save=dict(save_vllm=True)),
     # configs/quantization/methods/SpQR/spqr_w_only.yml: W4 g16 with 3-bit second-level statistics, outliers kept in fp
     'spqr': dict(
         quant=dict(method='SpQR', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=16, round_zp=False),
