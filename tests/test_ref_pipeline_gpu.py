@@ -213,12 +213,13 @@ def test_llama_spqr_through_the_reference_main(tmp_path):
 def test_export_step_of_the_reference_main_writes_the_same_checkpoints(tmp_path):
     """main()'s save branch (llmc/__main__.py:95-144) in both arms: RTN W4 sym g128 -> deploy('vllm_quant') + save_model +
     update_vllm_quant_config (compressed-tensors pack-quantized), AWQ W4 asym g128 -> deploy('autoawq_quant') + save_model +
-    update_autoawq_quant_config (AutoAWQ GEMM layout). The saved tensors of every decoder layer and the quantization config in
+    update_autoawq_quant_config (AutoAWQ GEMM layout), GPTQ W4 sym static-groups actorder -> the vLLM export of
+    backend/vllm/gptq_w4a16.yml. The saved tensors of every decoder layer and the quantization config in
     config.json are compared: RTN bit for bit (packed int32 words, scales, shapes); AWQ's packed words on block 0 (identical
     inputs) agree like its fake-quantized weights do, the names, shapes, dtypes and the config are identical."""
     from conftest import report
-    res = run_arms(tmp_path, 'llama', ['rtn_vllm', 'awq_autoawq'])
-    for m in ('rtn_vllm', 'awq_autoawq'):
+    res = run_arms(tmp_path, 'llama', ['rtn_vllm', 'awq_autoawq', 'gptq_vllm'])
+    for m in ('rtn_vllm', 'awq_autoawq', 'gptq_vllm'):
         ref, ours = res[m]
         ka = sorted(k for k in ref if k.startswith('ckpt/'))
         kb = sorted(k for k in ours if k.startswith('ckpt/'))
@@ -234,10 +235,14 @@ def test_export_step_of_the_reference_main_writes_the_same_checkpoints(tmp_path)
             report(f'ref_pipeline/{m}/{k}', equal=eq)
             if m == 'rtn_vllm':
                 assert eq == 1.0, (k, eq)
-            elif '.layers.0.' in k:
+            elif m == 'awq_autoawq' and '.layers.0.' in k:
                 worst = min(worst, eq)
+            elif m == 'gptq_vllm' and '.layers.0.self_attn.' in k and any(t in k for t in ('q_proj', 'k_proj', 'v_proj')):
+                worst = min(worst, eq)       # GPTQ's first subset (identical inputs): packed words, static-group scales
         if m == 'awq_autoawq':
             assert worst >= 0.90, worst
+        if m == 'gptq_vllm':                 # backend/vllm/gptq_w4a16.yml: sym, static groups, actorder (`weight_g_idx` exported too)
+            assert worst >= 0.97, worst
 
 
 @needs_ref

@@ -102,6 +102,11 @@ CONFIGS = {
     'rtn_vllm': dict(
         quant=dict(method='RTN', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128, need_pack=True)),
         calib=None, save=dict(save_vllm=True)),
+    # configs/quantization/backend/vllm/gptq_w4a16.yml: the vLLM-exportable GPTQ variant of SURVEY 8d (sym, static groups, packed)
+    'gptq_vllm': dict(
+        quant=dict(method='GPTQ', weight=dict(bit=4, symmetric=True, granularity='per_group', group_size=128, need_pack=True),
+                   special=dict(actorder=True, static_groups=True, percdamp=0.01, blocksize=128, true_sequential=True), quant_out=True),
+        calib=dict(name='wikitext2', download=False, n_samples=128, bs=1, seq_len=64, preproc='wikitext2_gptq'), save=dict(save_vllm=True)),
     'awq_autoawq': dict(
         quant=dict(method='Awq', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=128, pack_version='gemm_pack'),
                    special=dict(trans=True, trans_version='v2', weight_clip=True, clip_sym=False)),
