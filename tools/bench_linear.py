@@ -4,8 +4,11 @@ import torch
 from llmc_amd.compression.quantization import awq_ops
 
 
-def timed(fn, n=5):
-    fn()
+def timed(fn, n=30, warm=12):
+    # sustained rate: the clock under a long MFMA load differs from the first milliseconds after idle, so the same call warms
+    # the chip for tens of milliseconds before the timed window
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
