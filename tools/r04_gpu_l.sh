@@ -1,11 +1,11 @@
 #!/bin/bash
-# mid-round check: the whole GPU suite + the default bench line after the W-A AWQ / wide clip / FP8 cast work
+# end-of-round check: the whole GPU suite + smoke + the default bench line
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04l; mkdir -p $O
 rm -f $O/actuals.jsonl
-( time LLMC_TEST_ACTUALS=$PWD/$O/actuals.jsonl timeout 1800 python -m pytest tests -q -m gpu -p no:cacheprovider ) > $O/tests.log 2>&1; tail -8 $O/tests.log
+( time LLMC_TEST_ACTUALS=$PWD/$O/actuals.jsonl timeout 1800 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=12 ) > $O/tests.log 2>&1; tail -24 $O/tests.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-timeout 1200 python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err; python - <<PY
+timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; python - <<PY
 import json
 try:
     j=json.load(open('$O/bench.json')); print('bench', j['value'], j['ms_per_step'], j['roofline']['frac'], j.get('cpu_baseline',{}).get('value'))
