@@ -557,6 +557,38 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
+        if (a.mode == 0 && (a.R & 7) == 0 && (((uintptr_t)a.Y) & 15) == 0) {
+            // row-major output through the (now idle) operand ring: a wave lays its 128 x 128 results out row by row in its own
+            // 32 KiB (2-byte LDS writes, the accumulator layout has a column per lane), then stores 16 bytes per lane = four whole
+            // 256-byte row segments per instruction. Two-byte global stores straight from the accumulators cost 0.65 ms on a
+            // 65536 x 4096 output (0.90 against 1.22 PFLOP/s for the tile-blocked form, profiles/r04_linear_paths.txt).
+            LDS_AS char* my = lds + wv * 32768;
+            l4_static_for<0, 16>([&](auto mnc) {
+                constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
+                const int64_t col = (int64_t)tn * LT + wn * 128 + n * 32 + (lane & 31);
+                const float b = (a.Y0 && col < a.R) ? load_as_f32(a.Y0, col, DT) : 0.0f;
+                l4_static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float y = acc[m][n][r] + b;
+                    *(LDS_AS uint16_t*)(my + row * 256 + (n * 32 + (lane & 31)) * 2) =
+                        DT == LLMC_BF16 ? f32_to_bf16_bits(y) : f32_to_f16_bits(y);
+                });
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own writes, before its own reads
+            const int64_t tok0 = (int64_t)tm * LT + wm * 128, col0 = (int64_t)tn * LT + wn * 128;
+#pragma unroll 2
+            for (int i = 0; i < 32; ++i) {
+                const int id = i * 64 + lane, row = id >> 4, c16 = id & 15;
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v = *(LDS_AS u32x4_t*)(my + row * 256 + c16 * 16);
+                const int64_t tok = tok0 + row, col = col0 + c16 * 8;
+                if (tok < a.N && col < a.R) *reinterpret_cast<u32x4_t*>(a.Y + (tok * a.R + col) * 2) = v;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // every wave is done with the ring before the next prologue refills it
+            continue;
+        }
         float lsum = 0.0f;
         l4_static_for<0, 16>([&](auto mnc) {
             constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;

@@ -28,7 +28,8 @@ for (N, K, R) in [(65536, 4096, 4096), (65536, 4096, 14336), (65536, 14336, 4096
     wt = awq_ops.ktile_pack(w)
     t_kt = timed(lambda: awq_ops.linear_out(awq_ops.ktile_pack(x), wt, b, tiled=True))
     t_kt_only = timed(lambda xt=awq_ops.ktile_pack(x): awq_ops.linear_out(xt, wt, b, tiled=True))
+    t_blk = timed(lambda xt=awq_ops.ktile_pack(x): awq_ops.linear_out(xt, wt, b, tiled=True, blocked=True))
     t_blas = timed(lambda: torch.nn.functional.linear(x, w, b))
     print(f'N={N} K={K} R={R}: row-major {t_row:.3f} ms ({fl / t_row / 1e9:.0f} TF) | k-tiled incl. pack(x) {t_kt:.3f} ms '
-          f'({fl / t_kt / 1e9:.0f} TF), GEMM alone {t_kt_only:.3f} ms ({fl / t_kt_only / 1e9:.0f} TF) | '
+          f'({fl / t_kt / 1e9:.0f} TF), GEMM alone {t_kt_only:.3f} ms ({fl / t_kt_only / 1e9:.0f} TF), tile-blocked output {t_blk:.3f} ms ({fl / t_blk / 1e9:.0f} TF) | '
           f'torch F.linear {t_blas:.3f} ms ({fl / t_blas / 1e9:.0f} TF)')
