@@ -295,3 +295,36 @@ def test_fp8_rtn_exports_through_the_reference_main(tmp_path):
         pa, pb = float(ref['ppl'][-1]), float(ours['ppl'][-1])
         report(f'ref_pipeline/{m}/ppl', ref=pa, ours=pb)
         assert abs(pa - pb) <= 2e-3 * pa, (m, pa, pb)
+
+
+@needs_ref
+def test_awq_with_clip_version_v2_and_saved_factors_through_the_reference_main(tmp_path):
+    """configs/quantization/combination/awq_comb_omni/w8a8/step_1_awq.yml — the shipped configuration that selects AutoClipper
+    clip_version v2 (auto_clip.py:129-131, 213-229, 262-272): W8 asymmetric per_channel weights with `calib_algo: learnable`, A8
+    asymmetric per_token, trans v2, the searched ranges stored as logit factors on the layers and, with the AWQ scales, saved for
+    OmniQuant's second step (scales.pth / clips.pth, blockwise_optimization.py:40-52). Both arms through the reference's main()."""
+    from conftest import report
+    res = run_arms(tmp_path, 'llama', ['awq_v2_w8a8'])
+    ref, ours = res['awq_v2_w8a8']
+    stats, pa, pb = compare('llama_awq_v2_w8a8', ref, ours)
+    for n, st in stats.items():
+        if block_of(n) == 0:
+            assert st['w_close'] >= 0.97, (n, st)
+    assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)
+    for prefix in ('saved_scale/', 'saved_clip/'):
+        ka = sorted(k for k in ref if k.startswith(prefix))
+        kb = sorted(k for k in ours if k.startswith(prefix))
+        assert ka == kb and len(ka) > 0, (prefix, set(ka) ^ set(kb))
+    fa = sorted(k for k in ref if k.endswith('buf_upbound_factor') or k.endswith('buf_lowbound_factor'))
+    fb = sorted(k for k in ours if k.endswith('buf_upbound_factor') or k.endswith('buf_lowbound_factor'))
+    assert fa == fb and len(fa) > 0
+    worst = 1.0
+    for k in fa + [k for k in ref if k.startswith('saved_clip/')]:
+        if ('layers.0.' in k) or k.startswith('saved_clip/0/'):
+            a, b = ref[k], ours[k]
+            assert a.shape == b.shape, k
+            fin = np.isfinite(a) & np.isfinite(b)
+            same = float((np.abs(a[fin] - b[fin]) <= 2e-2 * np.maximum(1.0, np.abs(a[fin]))).mean()) if fin.any() else 1.0
+            report(f'ref_pipeline/awq_v2_w8a8/{k}', close=same, inf_equal=float((np.isfinite(a) == np.isfinite(b)).mean()))
+            worst = min(worst, same)
+    assert worst >= 0.95, worst                      # block 0's clip factors: the same searched levels (logit of a 16-bit ratio)

@@ -138,6 +138,14 @@ CONFIGS = {
                    act=dict(bit=8, symmetric=True, granularity='per_token'),
                    special=dict(trans=True, trans_version='v2', weight_clip=True), quant_out=True),
         calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
+    # configs/quantization/combination/awq_comb_omni/w8a8/step_1_awq.yml: the configuration that selects AutoClipper clip_version v2
+    # (learnable-range weights, asymmetric per_channel W8 + per_token A8, scales and clip factors saved for OmniQuant's second step)
+    'awq_v2_w8a8': dict(
+        quant=dict(method='Awq', weight=dict(bit=8, symmetric=False, granularity='per_channel', group_size=-1, calib_algo='learnable'),
+                   act=dict(bit=8, symmetric=False, granularity='per_token', calib_algo='minmax'),
+                   special=dict(trans=True, trans_version='v2', weight_clip=True, clip_version='v2', save_scale=True,
+                                scale_path='@ASSETS@/v2_scale_@ARM@', save_clip=True, clip_path='@ASSETS@/v2_clip_@ARM@')),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
     # configs/quantization/backend/vllm/fp8/awq_fp8_static.yml (the parent of BASELINE configs[4]): FP8 e4m3 per_tensor
     # weights, FP8 e4m3 per_tensor STATIC activations, trans v2 + weight clip. float_quantize of the reference arm is bound
     # to the restated qtorch (oracle/quant_ref.py) — qtorch itself is not installable here
@@ -166,8 +174,8 @@ def bind_restated_qtorch():
     qmod.float_quantize = float_quantize
 
 
-def build_config(method, arch, mdir, ddir, save_path):
-    c = json.loads(json.dumps(CONFIGS[method]))
+def build_config(method, arch, mdir, ddir, save_path, assets='', arm=''):
+    c = json.loads(json.dumps(CONFIGS[method]).replace('@ASSETS@', assets).replace('@ARM@', arm))
     cfg = {'base': {'seed': 0},
            'model': {'type': 'Llama' if arch == 'llama' else 'Opt', 'path': mdir, 'torch_dtype': 'auto'},
            'eval': {'eval_pos': ['fake_quant'], 'name': 'wikitext2', 'download': False, 'path': ddir, 'bs': 1, 'seq_len': 64,
@@ -256,7 +264,11 @@ def run_one(M, arm, method, arch, assets, mdir, ddir, stubbed, ref_classes):
             ALGO_REGISTRY[k] = c
         if CONFIGS[method]['quant'].get('weight', {}).get('quant_type') == 'float-quant':
             bind_restated_qtorch()
-    config = EasyDict(build_config(method, arch, mdir, ddir, os.path.join(assets, f'save_{arm}_{method}')))
+    config = EasyDict(build_config(method, arch, mdir, ddir, os.path.join(assets, f'save_{arm}_{method}'), assets, arm))
+    sp = config.quant.get('special', {})
+    for k in ('scale_path', 'clip_path'):
+        if sp.get(k):
+            os.makedirs(sp[k], exist_ok=True)
     check_config(config)
     save_dir = None
     for flag, sub in (('save_vllm', 'vllm_quant_model'), ('save_autoawq', 'autoawq_quant_model')):
@@ -316,6 +328,19 @@ def run_one(M, arm, method, arch, assets, mdir, ddir, stubbed, ref_classes):
         out[f'{name}/type'] = np.array(type(mod).__module__ + '.' + type(mod).__name__)
         n += 1
     out['n_linear'] = np.array(n)
+    for name, mod in model.named_modules():                        # clip_version v2 leaves its result in these buffers
+        for b in ('buf_upbound_factor', 'buf_lowbound_factor'):
+            t = getattr(mod, b, None)
+            if torch.is_tensor(t):
+                out[f'{name}/{b}'] = t.detach().float().cpu().numpy()
+    if sp.get('scale_path') and os.path.exists(os.path.join(sp['scale_path'], 'scales.pth')):
+        for k, v in torch.load(os.path.join(sp['scale_path'], 'scales.pth'), map_location='cpu').items():
+            out['saved_scale/' + k] = v.float().numpy()
+    if sp.get('clip_path') and os.path.exists(os.path.join(sp['clip_path'], 'clips.pth')):
+        for bi, d in torch.load(os.path.join(sp['clip_path'], 'clips.pth'), map_location='cpu').items():
+            for k, v in d.items():
+                if torch.is_tensor(v):
+                    out[f'saved_clip/{bi}/{k}'] = v.float().numpy()
     if save_dir:                                                    # the exported checkpoint, tensor by tensor, and its quantization config
         from safetensors.torch import load_file
         for f in sorted(os.listdir(save_dir)):
