@@ -459,7 +459,7 @@ class FloatQuantizer(BaseQuantizer):
         if self.bit not in self._FMT:
             raise NotImplementedError(f'FloatQuantizer bit={self.bit}: e4m3 and e5m2 are on the accelerated path '
                                       '(e3m2 / e4m7 / e2m1 of quant.py:988-990 are not 8-bit storage formats)')
-        if self.granularity not in ('per_tensor', 'per_channel', 'per_token', 'per_block'):
+        if self.granularity not in ('per_tensor', 'per_channel', 'per_token', 'per_group', 'per_block'):
             raise NotImplementedError(f'FloatQuantizer granularity={self.granularity}')
         self._fmt, self.e_bits, self.m_bits, self._tdtype = self._FMT[self.bit]
         if self.granularity == 'per_block' and self.bit != 'e4m3':

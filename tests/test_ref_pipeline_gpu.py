@@ -328,3 +328,34 @@ def test_awq_with_clip_version_v2_and_saved_factors_through_the_reference_main(t
             report(f'ref_pipeline/awq_v2_w8a8/{k}', close=same, inf_equal=float((np.isfinite(a) == np.isfinite(b)).mean()))
             worst = min(worst, same)
     assert worst >= 0.95, worst                      # block 0's clip factors: the same searched levels (logit of a 16-bit ratio)
+
+
+@needs_ref
+def test_more_shipped_configurations_through_the_reference_main(tmp_path):
+    """Four more shipped files of the path's families, as they are, in both arms: GPTQ with OWQ (gptq_owq_w_only.yml), RTN W8A8 with
+    static_hist activation ranges (rtn_w_a_pertensor_static.yml), AWQ W4A4 with down_proj at W8A8 through mix_bits and symmetric
+    clipping (awq_w_a_mix_bits.yml), RTN with FP8 block-wise weights and FP8 activations in groups of 128 (rtn_w_a_block.yml)."""
+    res = run_arms(tmp_path, 'llama', ['gptq_owq', 'rtn_static_hist', 'awq_mix_w_a', 'rtn_fp8_block'])
+    w0 = original_weights(tmp_path, 'llama')
+    # RTN: no search, identical inputs everywhere -> every weight identical, static activation scales identical
+    for m in ('rtn_static_hist', 'rtn_fp8_block'):
+        stats, pa, pb = compare('llama_' + m, *res[m])
+        for n, st in stats.items():
+            assert st['w_equal'] == 1.0, (m, n, st)
+            if m == 'rtn_static_hist':
+                assert st.get('act_scale_rel', 1.0) <= 1e-6, (n, st)
+        assert abs(pa - pb) <= 2e-3 * pa, (m, pa, pb)
+    # GPTQ + OWQ: first subset (identical inputs) as in the GPTQ test; same quantization error layer by layer
+    stats, pa, pb = compare('llama_gptq_owq', *res['gptq_owq'])
+    ratio = quant_error_ratio('llama_gptq_owq', w0, *res['gptq_owq'])
+    for n, st in stats.items():
+        if is_first_subset(n):
+            assert st['w_close'] >= 0.99, (n, st)
+    assert ratio <= 0.10, ratio
+    assert abs(pa - pb) <= 2e-2 * pa, (pa, pb)
+    # AWQ W4A4 / W8A8 mixed: block 0
+    stats, pa, pb = compare('llama_awq_mix_w_a', *res['awq_mix_w_a'])
+    for n, st in stats.items():
+        if block_of(n) == 0:
+            assert st['w_close'] >= 0.95, (n, st)
+    assert abs(pa - pb) <= 3e-2 * pa, (pa, pb)

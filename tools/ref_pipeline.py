@@ -138,6 +138,32 @@ CONFIGS = {
                    act=dict(bit=8, symmetric=True, granularity='per_token'),
                    special=dict(trans=True, trans_version='v2', weight_clip=True), quant_out=True),
         calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
+    # more shipped files of the path's families, as they are: methods/GPTQ/gptq_owq_w_only.yml (OWQ: the most sensitive input
+    # channels of every layer stay in floating point), methods/RTN/rtn_w_a_pertensor_static.yml (W8A8 with static_hist activation
+    # ranges), methods/Awq/awq_w_a_mix_bits.yml (W4A4 with down_proj at W8A8 through mix_bits, symmetric clipping),
+    # methods/RTN/rtn_w_a_block.yml (FP8 128 x 128 block-wise weights, FP8 activations in groups of 128)
+    'gptq_owq': dict(
+        quant=dict(method='GPTQ', weight=dict(bit=4, symmetric=False, granularity='per_group', group_size=128),
+                   special=dict(actorder=False, static_groups=False, percdamp=0.01, blocksize=128, true_sequential=True, owq=True,
+                                n_outs=[6, 6, 6, 6, 2, 2, 6]), quant_out=True),
+        calib=dict(name='wikitext2', download=False, n_samples=128, bs=1, seq_len=64, preproc='wikitext2_gptq')),
+    'rtn_static_hist': dict(
+        quant=dict(method='RTN', weight=dict(bit=8, symmetric=True, granularity='per_channel', group_size=-1),
+                   act=dict(bit=8, symmetric=True, granularity='per_tensor', static=True, calib_algo='static_hist')),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
+    'awq_mix_w_a': dict(
+        quant=dict(method='Awq', weight=dict(bit=4, symmetric=False, granularity='per_channel'),
+                   act=dict(bit=4, symmetric=False, granularity='per_token'),
+                   mix_bits=dict(setting_0=dict(layer_name=['down_proj'], do_quant=True,
+                                                weight=dict(bit=8, symmetric=False, granularity='per_channel'),
+                                                act=dict(bit=8, symmetric=False, granularity='per_token'))),
+                   special=dict(trans=True, trans_version='v2', weight_clip=True, clip_sym=True)),
+        calib=dict(name='wikitext2', download=False, n_samples=32, bs=-1, seq_len=64, preproc='wikitext2_gptq')),
+    'rtn_fp8_block': dict(
+        quant=dict(method='RTN', weight=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_block', block_size=128,
+                                              use_qtorch=True),
+                   act=dict(quant_type='float-quant', bit='e4m3', symmetric=True, granularity='per_group', group_size=128, use_qtorch=True)),
+        calib=None),
     # configs/quantization/combination/awq_comb_omni/w8a8/step_1_awq.yml: the configuration that selects AutoClipper clip_version v2
     # (learnable-range weights, asymmetric per_channel W8 + per_token A8, scales and clip factors saved for OmniQuant's second step)
     'awq_v2_w8a8': dict(
