@@ -280,3 +280,41 @@ def test_blocked_output_index_map_without_gpu():
     col = tn * 256 + wn * 128 + n * 32 + (lane & 31)
     buf = ref[tok, col]
     assert torch.equal(unblock_y(buf, N, R), ref[:N, :R])
+
+
+def test_awq_and_autoclipper_route_by_quantizer_kind():
+    """Host-side routing (no GPU): the fused kernels take W4A16-style integer row / group ranges only; quantized activations, FP8
+    and per_tensor weight quantizers, mse ranges and clip_version v2 go to the general routes (awq.py:_fusable_wquantizer,
+    auto_clip.py:_fused_route); clip v2 with per_group weights is refused where the configuration is read."""
+    import pytest
+    import torch
+    from llmc_amd.compression.quantization import FloatQuantizer, IntegerQuantizer
+    from llmc_amd.compression.quantization.auto_clip import AutoClipper
+    from llmc_amd.compression.quantization.awq import Awq
+
+    def awq(wq, w_only=True):
+        a = Awq.__new__(Awq)
+        a.wquantizer, a.w_only, a.padding_mask, a.awq_bs = wq, w_only, None, None
+        return a
+    lin = torch.nn.Linear(64, 64, bias=False)
+    x = [torch.zeros(2, 4, 64)]
+    g128 = IntegerQuantizer(4, True, 'per_group', group_size=128)
+    assert awq(g128)._fused_route_ok({'o': lin}, x, lin, {})
+    assert awq(IntegerQuantizer(8, True, 'per_channel'))._fused_route_ok({'o': lin}, x, lin, {})
+    for wq in (IntegerQuantizer(8, True, 'per_tensor'), IntegerQuantizer(4, True, 'per_group', group_size=128, calib_algo='mse'),
+               FloatQuantizer('e4m3', True, 'per_tensor'), FloatQuantizer('e5m2', True, 'per_channel')):
+        assert not awq(wq)._fused_route_ok({'o': lin}, x, lin, {}), repr(wq)
+    assert not awq(g128, w_only=False)._fused_route_ok({'o': lin}, x, lin, {})
+
+    def clipper(wq, w_only=True, ver='v1', aq=None, **kw):
+        return AutoClipper(w_only=w_only, wquantizer=wq, aquantizer=aq, clip_version=ver, clip_sym=True, save_clip=False,
+                           padding_mask=None, **kw)
+    assert clipper(g128)._fused_route()
+    a8 = IntegerQuantizer(8, True, 'per_token')
+    for c in (clipper(IntegerQuantizer(4, True, 'per_channel')), clipper(IntegerQuantizer(4, True, 'per_group', group_size=256)),
+              clipper(g128, w_only=False, aq=a8), clipper(FloatQuantizer('e4m3', True, 'per_tensor'), w_only=False, aq=a8),
+              clipper(IntegerQuantizer(4, True, 'per_channel', calib_algo='learnable'), ver='v2')):
+        assert not c._fused_route()
+    with pytest.raises(NotImplementedError, match='external_ranges'):
+        clipper(IntegerQuantizer(4, True, 'per_group', group_size=128, calib_algo='learnable'), ver='v2')
+    clipper(IntegerQuantizer(4, True, 'per_group', group_size=128, calib_algo='learnable'), ver='v2', external_ranges=True)
