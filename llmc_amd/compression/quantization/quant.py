@@ -464,9 +464,9 @@ class FloatQuantizer(BaseQuantizer):
         self._fmt, self.e_bits, self.m_bits, self._tdtype = self._FMT[self.bit]
         if self.granularity == 'per_block' and self.bit != 'e4m3':
             raise NotImplementedError('FloatQuantizer per_block: e4m3 only (the DeepSeek-V3 checkpoint format)')
-        self.use_qtorch = self.kwargs.get('use_qtorch', True)
+        self.use_qtorch = self.kwargs.get('use_qtorch')       # quant.py:974: absent means False, like the reference
         if not self.use_qtorch:
-            raise NotImplementedError('FloatQuantizer use_qtorch=False (get_float_qparams, quant.py:1005-1041: hard-coded '
+            raise NotImplementedError('FloatQuantizer without use_qtorch: True (get_float_qparams, quant.py:1005-1041: hard-coded '
                                       '.cuda(), per-element exponent scales) is outside the hot path')
         sem = self.kwargs.get('fp8_semantics', 'qtorch')
         if sem not in ('qtorch', 'cast'):

@@ -366,7 +366,7 @@ def test_fused_route_only_for_single_inspected_linear():
     assert not a._fused_route_ok({'o': l1}, x, l1, {})
     from llmc_amd.compression.quantization import FloatQuantizer, IntegerQuantizer
     a.w_only = True
-    for wq in (FloatQuantizer('e4m3', True, 'per_tensor'), IntegerQuantizer(8, True, 'per_tensor')):   # not an integer row / group range
+    for wq in (FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True), IntegerQuantizer(8, True, 'per_tensor')):   # not an integer row / group range
         a.wquantizer = wq
         assert not a._fused_route_ok({'o': l1}, x, l1, {})
     a.wquantizer = make_q(True, 128)

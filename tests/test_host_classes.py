@@ -302,7 +302,7 @@ def test_awq_and_autoclipper_route_by_quantizer_kind():
     assert awq(g128)._fused_route_ok({'o': lin}, x, lin, {})
     assert awq(IntegerQuantizer(8, True, 'per_channel'))._fused_route_ok({'o': lin}, x, lin, {})
     for wq in (IntegerQuantizer(8, True, 'per_tensor'), IntegerQuantizer(4, True, 'per_group', group_size=128, calib_algo='mse'),
-               FloatQuantizer('e4m3', True, 'per_tensor'), FloatQuantizer('e5m2', True, 'per_channel')):
+               FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True), FloatQuantizer('e5m2', True, 'per_channel', use_qtorch=True)):
         assert not awq(wq)._fused_route_ok({'o': lin}, x, lin, {}), repr(wq)
     assert not awq(g128, w_only=False)._fused_route_ok({'o': lin}, x, lin, {})
 
@@ -312,7 +312,7 @@ def test_awq_and_autoclipper_route_by_quantizer_kind():
     assert clipper(g128)._fused_route()
     a8 = IntegerQuantizer(8, True, 'per_token')
     for c in (clipper(IntegerQuantizer(4, True, 'per_channel')), clipper(IntegerQuantizer(4, True, 'per_group', group_size=256)),
-              clipper(g128, w_only=False, aq=a8), clipper(FloatQuantizer('e4m3', True, 'per_tensor'), w_only=False, aq=a8),
+              clipper(g128, w_only=False, aq=a8), clipper(FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True), w_only=False, aq=a8),
               clipper(IntegerQuantizer(4, True, 'per_channel', calib_algo='learnable'), ver='v2')):
         assert not c._fused_route()
     with pytest.raises(NotImplementedError, match='external_ranges'):
