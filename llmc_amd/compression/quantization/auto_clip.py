@@ -8,8 +8,6 @@ with quantized activations. Two routes, same arithmetic:
     shrink level come from the quantizer's own kernels exactly as fake_quantize_weight forms them (auto_clip.py:258-274,
     in the reference's output-channel batches of 256 / 64 rows, which is what a per_tensor range spans), the error table
     from llmc_awq_clip_errs_cand, the strict-< argmin over the ten levels on [R, ng] tensors."""
-import os
-
 import torch
 import torch.distributed as dist
 

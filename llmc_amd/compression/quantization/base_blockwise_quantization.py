@@ -17,7 +17,6 @@ from functools import partial
 
 import torch
 import torch.distributed as dist
-import torch.nn as nn
 
 from ..blockwise_optimization import BlockwiseOpt
 from . import awq_ops

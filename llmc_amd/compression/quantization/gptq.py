@@ -9,13 +9,11 @@ What is different (mechanics, not arithmetic): layers of a subset that share the
 ONE factorisation and ONE stacked column loop (the reference recomputes identical H and Hinv per layer); no
 per-batch all_reduce of H — with several ranks (data-parallel calibration) H is reduced once per subset
 (`_sync_hessian`), mathematically identical because every rank's running mean covers the same number of
-sequences; no `.item()` sync per layer. OWQ (gptq.py:44-50, 66-83) is outside the hot path.
+sequences; no `.item()` sync per layer. OWQ (gptq.py:44-50, 66-83): the floating-point columns ride through the same
+column loop (`quantize_owq`, llmc_gptq_quantize_cols).
 """
-import math
-
 import torch
 import torch.distributed as dist
-import torch.nn as nn
 
 from llmc_amd.utils.registry_factory import ALGO_REGISTRY
 
@@ -23,7 +21,7 @@ from .base_blockwise_quantization import BaseBlockwiseQuantization, _world
 from . import gptq_ops
 from .gptq_pipeline import GptqConfig, owq_permutation, quantize_owq, quantize_stacked
 from .hessian import HessianAccumulator
-from .module_utils import _LLMC_LINEAR_TYPES_, _TRANSFORMERS_LINEAR_TYPES_, FakeQuantLinear
+from .module_utils import _LLMC_LINEAR_TYPES_, _TRANSFORMERS_LINEAR_TYPES_
 
 
 @ALGO_REGISTRY
