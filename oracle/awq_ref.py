@@ -236,3 +236,65 @@ def wa_chain_point(w, x, s, dt, wcfg, acfg, per_sample=False):
     else:
         xq = fake_quant_any(xs, dt, *acfg)
     return wq, xq
+
+
+def _logit(x, dt):
+    """AutoClipper.logit = log(x / (1 - x)) on a dt tensor: every op rounds to dt (auto_clip.py:41)."""
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        one_minus = rnd(np.float32(1.0) - x, dt)
+        return rnd(np.log(rnd(x / one_minus, dt)).astype(np.float32), dt)
+
+
+def _sigmoid(x, dt):
+    with np.errstate(over='ignore'):
+        return rnd((np.float32(1.0) / (np.float32(1.0) + np.exp(-x.astype(np.float32)))).astype(np.float32), dt)
+
+
+def auto_clip_layer_general(w, x, dt, wcfg, acfg, clip_version='v1', clip_sym=True, n_grid=20, max_shrink=0.5, n_sample_token=512):
+    """auto_clip_layer (auto_clip.py:84-191) for every quantizer kind, candidates included: per output-channel batch of 256 / 64 rows
+    (auto_clip.py:106-107; a per_tensor range spans the batch) and shrink level, fake_quantize_weight (:258-274) =
+      v1: fake_quant_dynamic(clamp(w, min, max));
+      v2: static fake-quant with the learnable range (quant.py:205-224): min / max (or +-absmax) scaled by sigmoid(logit(level ratio))
+    then the error table and the argmin above. wcfg = (kind, bit, sym, granularity[, group_size]); acfg likewise or None (weight-only).
+    Integer weight quantizers for v2 (the only kind the reference's learnable range is used with)."""
+    w = np.asarray(w, dtype=np.float32)
+    R, K = w.shape
+    kind, bit, sym, gran = wcfg[:4]
+    g = int(wcfg[4]) if (gran == 'per_group' and len(wcfg) > 4 and wcfg[4]) else K
+    ng = K // g
+    xs = np.asarray(x, dtype=np.float32).reshape(-1, K)
+    xs = xs[0::max(1, xs.shape[0] // n_sample_token)]
+    xq = xs if acfg is None else fake_quant_any(xs.reshape(1, xs.shape[0], ng, g), dt, *acfg).reshape(xs.shape)
+    wg = w.reshape(R, ng, g)
+    org_max = np.abs(wg).max(axis=-1, keepdims=True) if clip_sym else wg.max(axis=-1, keepdims=True)
+    org_min = wg.min(axis=-1, keepdims=True)
+    oc = 256 if R % 256 == 0 else 64
+    cands = []
+    for i_s in range(int(max_shrink * n_grid)):
+        f = np.float32(1 - i_s / n_grid)
+        max_val = rnd(org_max * f, dt)
+        min_val = -max_val if clip_sym else rnd(org_min * f, dt)
+        rows = []
+        for b0 in range(0, R, oc):
+            sl = slice(b0, b0 + oc)
+            if clip_version == 'v1':
+                cur = np.minimum(np.maximum(wg[sl], min_val[sl]), max_val[sl]).reshape(oc, K)
+                rows.append(fake_quant_any(cur, dt, *wcfg))
+            else:
+                assert kind == 'int' and gran != 'per_group'
+                qmin, qmax = Q.int_range(int(bit), bool(sym))
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    low = _logit(rnd(min_val[sl] / org_min[sl], dt), dt)
+                    up = _logit(rnd(max_val[sl] / org_max[sl], dt), dt)
+                mn, mx = wg[sl].min(axis=-1, keepdims=True), wg[sl].max(axis=-1, keepdims=True)
+                if sym:
+                    a = np.maximum(np.maximum(np.abs(mx), np.abs(mn)), rnd(np.float32(1e-5), dt))
+                    a = rnd(_sigmoid(up, dt) * a, dt)
+                    mn, mx = -a, a
+                else:
+                    mn, mx = rnd(_sigmoid(low, dt) * mn, dt), rnd(_sigmoid(up, dt) * mx, dt)
+                s, z = Q.qparams_from_minmax(mn.reshape(-1, 1), mx.reshape(-1, 1), dt, bool(sym), qmin, qmax)
+                rows.append(Q.fake_quant_static(wg[sl].reshape(-1, g), dt, s, dt, z, dt, qmin, qmax).reshape(oc, K))
+        cands.append(np.concatenate(rows, axis=0))
+    errs = clip_errs_from_candidates(w, np.stack(cands), xs, xq, dt, g)
+    return clip_argmin_levels(errs, w, g, dt, clip_sym, n_grid)

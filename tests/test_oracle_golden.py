@@ -401,6 +401,30 @@ def test_awq_with_activation_quantization_chain_point_bit_exact():
         np.testing.assert_array_equal(bits(xq), bits(g[p + 'xq_r040']), err_msg=name)
 
 
+def test_auto_clip_general_restatement_builds_the_candidates_itself():
+    """clip_wide.npz again, this time with the candidates formed by the oracle's own quantizers (v1: fake-quant of the clamped weights
+    per output-channel batch; v2: learnable range from logit / sigmoid of the level ratios): the reference's level for every row."""
+    g = load_golden('clip_wide')
+
+    def cfg(a):
+        a = [str(v) for v in a]
+        if not a:
+            return None
+        out = [a[0], a[1] if a[0] == 'float' else int(a[1]), a[2] == 'True', a[3]]
+        if len(a) > 4:
+            out.append(int(a[4]))
+        return tuple(out)
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        R, K, gs, clip_sym, nst = [int(v) for v in g[p + 'meta']]
+        dt, ver = str(g[p + 'dt']), str(g[p + 'ver'])
+        mx, mn = A.auto_clip_layer_general(g[p + 'w'], g[p + 'x'], dt, cfg(g[p + 'wcfg']), cfg(g[p + 'acfg']), ver, bool(clip_sym),
+                                           n_sample_token=nst)
+        eq_mx = (mx.reshape(g[p + 'best_max'].shape) == g[p + 'best_max']).mean()
+        eq_mn = (mn.reshape(g[p + 'best_min'].shape) == g[p + 'best_min']).mean()
+        assert eq_mx == 1.0 and eq_mn == 1.0, (name, eq_mx, eq_mn)
+
+
 def test_per_tensor_asymmetric_bit_exact():
     """quant_pt.npz: fp32 0-dim qparams, op results in the tensor dtype."""
     g = load_golden('quant_pt')
