@@ -298,3 +298,34 @@ def auto_clip_layer_general(w, x, dt, wcfg, acfg, clip_version='v1', clip_sym=Tr
         cands.append(np.concatenate(rows, axis=0))
     errs = clip_errs_from_candidates(w, np.stack(cands), xs, xq, dt, g)
     return clip_argmin_levels(errs, w, g, dt, clip_sym, n_grid)
+
+
+def search_scale_wa(w, xs, dt, wcfg, acfg, version='v2', n_grid=20):
+    """Awq.search_scale_subset with activation quantization for ONE layer that is its own inspected module and a list of
+    calibration batches (awq.py:179-253): per grid point and batch, loss = mean((x W^T - fq(x / s) fq(W s)^T)^2); the per-batch
+    bookkeeping of the reference (loss_mean += b / n_samples * loss, best taken inside the batch loop). Returns (best_scales,
+    losses [n_grid * len(xs)])."""
+    w = np.asarray(w, dtype=np.float32)
+    gsz = int(wcfg[4]) if (wcfg[3] == 'per_group' and len(wcfg) > 4) else 0
+    w_max = weight_scale([w], dt, gsz)
+    xs = [np.asarray(x, dtype=np.float32) for x in xs]
+    n_samples = sum(x.shape[0] for x in xs)
+    y0 = [linear(x, w, dt).reshape(*x.shape[:-1], -1) for x in xs]
+    best, best_s, losses = float('inf'), None, []
+    for n in range(n_grid):
+        loss_mean, scales_mean = 0.0, 0.0
+        for i, x in enumerate(xs):
+            s = get_scales(act_mean(x, dt), w_max, n / n_grid, dt, version)
+            wq, xq = wa_chain_point(w, x, s, dt, wcfg, acfg)
+            ls = loss_mean_fn(y0[i], linear(xq, wq, dt).reshape(y0[i].shape), dt)
+            losses.append(ls)
+            frac = x.shape[0] / (x.shape[0] if len(xs) == 1 else n_samples)
+            loss_mean += frac * ls
+            scales_mean = scales_mean + frac * s
+            if loss_mean < best:
+                best, best_s = loss_mean, scales_mean
+    return best_s, np.array(losses, dtype=np.float64)
+
+
+def loss_mean_fn(y0, y, dt):
+    return loss_mean(y0, y, dt)

@@ -425,6 +425,36 @@ def test_auto_clip_general_restatement_builds_the_candidates_itself():
         assert eq_mx == 1.0 and eq_mn == 1.0, (name, eq_mx, eq_mn)
 
 
+def test_awq_with_activation_quantization_search_restated_for_the_single_layer_cases():
+    """awq_wa.npz, the two cases whose inspected module is the layer itself (FP8 e4m3 per_tensor = awq_fp8_static.yml's arithmetic,
+    INT8 per_tensor weights with asymmetric per_token activations): the restated search (oracle/awq_ref.py:search_scale_wa) follows
+    the reference's loss curve within 1e-3 (the GEMMs sum in another order) and returns its scales."""
+    g = load_golden('awq_wa')
+
+    def cfg(a):
+        a = [str(v) for v in a]
+        out = [a[0], a[1] if a[0] == 'float' else int(a[1]), a[2] == 'True', a[3]]
+        if len(a) > 4:
+            out.append(int(a[4]))
+        return tuple(out)
+    n_cases = 0
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        if str(g[p + 'inspect']) != 'linear':
+            continue
+        K, R, nb, awq_bs = [int(v) for v in g[p + 'meta']]
+        dt = str(g[p + 'dt'])
+        best, losses = A.search_scale_wa(g[p + 'w_gate_proj'], [g[p + f'x{i}'] for i in range(nb)], dt, cfg(g[p + 'wcfg']), cfg(g[p + 'acfg']))
+        ref = g[p + 'losses']
+        assert losses.shape == ref.shape
+        np.testing.assert_allclose(losses, ref, rtol=1e-3, err_msg=name)
+        assert int(np.argmin(losses)) == int(np.argmin(ref)), name
+        u = np.abs((bits(best) >> 16).astype(np.int64) - (bits(g[p + 'best_scales']) >> 16).astype(np.int64))
+        assert u.max() <= 2, (name, u.max())
+        n_cases += 1
+    assert n_cases == 2
+
+
 def test_per_tensor_asymmetric_bit_exact():
     """quant_pt.npz: fp32 0-dim qparams, op results in the tensor dtype."""
     g = load_golden('quant_pt')
