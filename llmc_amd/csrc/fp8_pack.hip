@@ -204,9 +204,10 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
                     s = load_as_f32(scales, row, sdt);
                 } else {
                     s = rnd(to_f32<T>(amax[row]) / fmax, sdt);
+                    if (s == 0.0f) s = 1.0f;                          // scales[scales == 0] = 1 IN PLACE (quant.py:1062): the returned scale too
                     if (i * V == row * g) store_from_f32(scales, row, sdt, s);
                 }
-                return s == 0.0f ? 1.0f : s;                          // scales[scales == 0] = 1 (quant.py:1062)
+                return s == 0.0f ? 1.0f : s;                          // (static scales: the caller's tensor is left alone)
             };
             uint32_t todo = 0;                       // bit u: vector u is left to the general encoder below
 #pragma unroll
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(FB) void k_fp8_cast(const T* __restrict__ W, const 
             s = load_as_f32(scales, row, sdt);
         } else {
             s = rnd(to_f32<T>(amax[row]) / fmax, sdt);
+            if (s == 0.0f) s = 1.0f;
             if (i == row * g) store_from_f32(scales, row, sdt, s);
         }
         if (s == 0.0f) s = 1.0f;

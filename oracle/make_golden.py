@@ -1108,6 +1108,33 @@ def suite_fp8_qtorch():
     save('fp8_qtorch', **out)
 
 
+def suite_fp8_group_qtorch():
+    """FloatQuantizer per_group (rtn_w_a_block.yml quantizes activations as FP8 e4m3 in groups of 128; quant.py:612-618 reshapes to
+    [-1, g], the scale of a group stays in the tensor dtype): fake_quant_act_dynamic and fake_quant_weight_dynamic, float_quantize =
+    the restated qtorch."""
+    import llmc.compression.quantization.quant as qmod
+    qmod.float_quantize = _qtorch_stub
+    out = {}
+    gen = torch.Generator().manual_seed(1207)
+    ci = 0
+    for bit in ('e4m3', 'e5m2'):
+        for dt in ('bf16', 'f16'):
+            for gs in (128, 32):
+                q = qmod.FloatQuantizer(bit, True, 'per_group', group_size=gs, use_qtorch=True)
+                x = (torch.randn(3, 10, 256, generator=gen) * torch.exp(0.7 * torch.randn(256, generator=gen))).to(DT[dt])
+                x[0, 0, :gs] = 0.0
+                fa = q.fake_quant_act_dynamic(x)
+                w = (torch.randn(24, 256, generator=gen) * 0.05).to(DT[dt])
+                fw = q.fake_quant_weight_dynamic(w)
+                p = f'c{ci}_'
+                out[p + 'x'], out[p + 'fake_x'] = f32(x), f32(fa)
+                out[p + 'w'], out[p + 'fake_w'] = f32(w), f32(fw)
+                out[p + 'dt'], out[p + 'bit'], out[p + 'gs'] = np.array(dt), np.array(bit), np.array(gs)
+                ci += 1
+    out['n'] = np.array(ci)
+    save('fp8_group_qtorch', **out)
+
+
 def suite_fp8_block_qtorch():
     """suite_fp8_block with float_quantize = the restated qtorch (see suite_fp8_qtorch): FloatQuantizer e4m3 per_block and
     the reference's non-Triton weight_cast_to_fp8 / weight_cast_to_bf16 (quant.py:18-43), which go through the same class."""
@@ -1408,7 +1435,7 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'awq_wa': suite_awq_wa, 'clip_wide': suite_clip_wide, 'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+SUITES = {'fp8_group_qtorch': suite_fp8_group_qtorch, 'awq_wa': suite_awq_wa, 'clip_wide': suite_clip_wide, 'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'fp8_qtorch': suite_fp8_qtorch, 'fp8_block_qtorch': suite_fp8_block_qtorch, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

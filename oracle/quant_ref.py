@@ -311,6 +311,7 @@ def fp8_quant(w2d, dt, fmt='e4m3', sem='cast'):
     sdt = F32 if w2d.shape[0] == 1 else dt
     with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
         s = rnd(a / fmax, sdt)
+        s = np.where(s == 0, np.float32(1.0), s).astype(np.float32)      # scales[scales == 0] = 1 (quant.py:1062): an fp16 group scale below 2^-24 is 0
         t = rnd(rnd(w2d / s, dt) + np.float32(0.0), dt)   # tensor / scales + zeros (0.0): -0 becomes +0
     bits, _ = fp8_encode(t, fmt, sem)           # float_quantize(.float(), e, m) then .to(float8 type)
     return bits, s, sdt
@@ -325,6 +326,7 @@ def fp8_fake(w2d, dt, fmt='e4m3', sem='cast'):
     sdt = F32 if w2d.shape[0] == 1 else dt
     with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
         s = rnd(a / fmax, sdt)
+        s = np.where(s == 0, np.float32(1.0), s).astype(np.float32)      # scales[scales == 0] = 1 (quant.py:1062): an fp16 group scale below 2^-24 is 0
         t = rnd(rnd(w2d / s, dt) + np.float32(0.0), dt)
     _, v = fp8_encode(t, fmt, sem)
     return rnd(v * s, dt)

@@ -205,3 +205,23 @@ def test_fp8_gemm_bit_identical_to_the_reference_triton_kernel_more_shapes():
         eq32 = float((c32.cpu().view(torch.int32) == ref32.view(torch.int32)).float().mean())
         report(f'fp8_triton_more/{M}x{N}x{Kd}', bf16_equal=eq16, f32_equal=eq32)
         assert eq16 == 1.0 and eq32 == 1.0, (M, N, Kd, eq16, eq32)
+
+
+def test_fp8_per_group_matches_reference_golden():
+    """FloatQuantizer per_group (FP8 activations in groups of 128 / 32, e4m3 and e5m2; rtn_w_a_block.yml) against the reference's class."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from llmc_amd.compression.quantization import FloatQuantizer
+    g = load_golden('fp8_group_qtorch')
+    TDT = {'f16': torch.float16, 'bf16': torch.bfloat16}
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        dt, bit, gs = str(g[p + 'dt']), str(g[p + 'bit']), int(g[p + 'gs'])
+        q = FloatQuantizer(bit, True, 'per_group', group_size=gs, use_qtorch=True)
+        x = torch.from_numpy(g[p + 'x']).to(TDT[dt]).cuda()
+        w = torch.from_numpy(g[p + 'w']).to(TDT[dt]).cuda()
+        fa = q.fake_quant_act_dynamic(x).float().cpu().numpy()
+        fw = q.fake_quant_weight_dynamic(w).float().cpu().numpy()
+        np.testing.assert_array_equal(fa.view(np.uint32), g[p + 'fake_x'].view(np.uint32), err_msg=f'{ci} act')
+        np.testing.assert_array_equal(fw.view(np.uint32), g[p + 'fake_w'].view(np.uint32), err_msg=f'{ci} weight')

@@ -455,6 +455,18 @@ def test_awq_with_activation_quantization_search_restated_for_the_single_layer_c
     assert n_cases == 2
 
 
+def test_fp8_per_group_bit_exact():
+    """fp8_group_qtorch.npz: FloatQuantizer per_group (activations of rtn_w_a_block.yml, FP8 in groups of 128) through the oracle."""
+    g = load_golden('fp8_group_qtorch')
+    for ci in range(int(g['n'])):
+        p = f'c{ci}_'
+        dt, bit, gs = str(g[p + 'dt']), str(g[p + 'bit']), int(g[p + 'gs'])
+        for src, ref in (('x', 'fake_x'), ('w', 'fake_w')):
+            x = g[p + src]
+            got = Q.fp8_fake(x.reshape(-1, gs), dt, bit, 'qtorch').reshape(x.shape)
+            np.testing.assert_array_equal(bits(got), bits(g[p + ref]), err_msg=f'{ci} {src}')
+
+
 def test_per_tensor_asymmetric_bit_exact():
     """quant_pt.npz: fp32 0-dim qparams, op results in the tensor dtype."""
     g = load_golden('quant_pt')
