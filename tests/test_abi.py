@@ -54,6 +54,8 @@ def test_invalid_arguments_are_refused_without_touching_the_gpu():
     assert 'dtype' in _ffi.last_error()
     rc = lib.llmc_pack_lsb(None, 1, 4, 4, 4, None, None)
     assert rc == -22
+    rc = lib.llmc_awq_clip_errs_cand(None, None, None, None, 1, 64, 256, 256, 32, 32, 10, None, None)     # null operands
+    assert rc == -22 and 'clip_errs_cand' in _ffi.last_error()
 
 
 def test_product_refuses_cpu_tensors():
