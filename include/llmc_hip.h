@@ -52,6 +52,9 @@ extern "C" {
 typedef void* llmc_stream_t; /* hipStream_t */
 
 int llmc_hip_abi_version(void);
+/* hash (16 hex digits) of the sources and compiler flags the library was built from; the Python loader recomputes it from
+ * the sources next to the .so and refuses a stale library (llmc_amd/build.py:source_digest, llmc_amd/_ffi.py:lib) */
+const char* llmc_hip_build_id(void);
 /* copies the last HIP error string of the calling thread into buf (NUL-terminated); returns its length */
 int llmc_hip_last_error(char* buf_host, size_t n);
 

@@ -22,6 +22,7 @@ _i64, _i32, _f32, _f64, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_double, C.
 # (tests/test_abi.py parses the header and checks both directions).
 SIGNATURES = {
     'llmc_hip_abi_version': (_i32, []),
+    'llmc_hip_build_id': (C.c_char_p, []),
     'llmc_hip_last_error': (_i32, [C.c_char_p, _sz]),
     'llmc_hip_set_helper_streams': (_i32, [_i32]),
     'llmc_hip_set_cu_reserve': (_i32, [_i32]),
@@ -114,6 +115,13 @@ def lib():
         ver = handle.llmc_hip_abi_version()
         if ver != 1:
             raise LlmcHipError(f'libllmc_hip.so ABI version {ver} != 1')
+        # a library built from other sources than the ones lying next to it (a failed or forgotten rebuild) fails loudly
+        if not os.environ.get('LLMC_SKIP_BUILD_ID_CHECK'):
+            from . import build as _build
+            have, want = handle.llmc_hip_build_id().decode(), _build.source_digest()
+            if have != want:
+                raise LlmcHipError(f'{LIB_PATH} is stale: built from sources {have}, csrc/ is {want} '
+                                   '(run `python -m llmc_amd.build`; LLMC_SKIP_BUILD_ID_CHECK=1 skips this check)')
         _lib = handle
     return _lib
 

@@ -74,10 +74,14 @@ class Awq(BaseBlockwiseQuantization):
         return (isinstance(wq, IntegerQuantizer) and wq.granularity in ('per_group', 'per_channel')
                 and wq.calib_algo == 'minmax' and wq.round_zp)
 
-    def _fake_quantize_weight(self, w0, cols):
-        """fake_quantize_weight (awq.py:147-164) of one layer from its original weights; w0 is not modified."""
+    def _fake_quantize_weight(self, w0, cols, s0=None):
+        """fake_quantize_weight (awq.py:147-164) of one layer from its original weights; w0 is not modified. A block-wise
+        FP8 checkpoint weight (w0 float8_e4m3fn, s0 = its weight_scale_inv) is de-blocked to bf16, scaled, fake-quantized and
+        re-blocked: returns (fp8 weight, new weight_scale_inv) then (awq.py:148-161)."""
         if w0.dtype == torch.float8_e4m3fn:
-            raise NotImplementedError('Awq on block-wise FP8 checkpoints (weight_scale_inv, awq.py:148-161) is outside the hot path')
+            tmp = self._fp8_to_bf16(w0, s0)
+            tmp = self.wquantizer.fake_quant_weight_dynamic(awq_ops.mul_cols_(tmp, cols.to(tmp.dtype)))
+            return self._bf16_to_fp8(tmp)
         if self._fusable_wquantizer():
             return awq_ops.scale_fakequant(w0, cols, self.wquantizer)
         return self.wquantizer.fake_quant_weight_dynamic(awq_ops.mul_cols_(w0.clone(), cols))
@@ -94,7 +98,8 @@ class Awq(BaseBlockwiseQuantization):
         g = self.wquantizer.group_size if self.wquantizer.granularity == 'per_group' else 0
         total = None
         for m in layers_dict.values():
-            s = awq_ops.weight_mean(m.weight.data, g)
+            w = self._fp8_to_bf16(m.weight, m.weight_scale_inv) if self._is_fp8(m) else m.weight.data   # awq.py:53-58
+            s = awq_ops.weight_mean(w, g)
             total = s if total is None else total.add_(s)
         return total.div_(len(layers_dict))
 
@@ -154,6 +159,8 @@ class Awq(BaseBlockwiseQuantization):
             return False
         if getattr(layers[0], 'bias', None) is not None:
             return False       # a bias cancels in org - out, but the fused loss kernel takes the bias-free product
+        if any(self._is_fp8(l) for l in layers):
+            return False       # block-wise FP8 checkpoints: the layer's own fp8 forward evaluates the re-blocked weight
         return self.awq_bs is None or self.awq_bs == input[0].shape[0]
 
     @torch.no_grad()
@@ -189,6 +196,7 @@ class Awq(BaseBlockwiseQuantization):
         layers = list(layers_dict.values())
         w_max = self.get_weight_scale(layers_dict)
         org_w = [fc.weight.data.clone() for fc in layers]
+        org_s = [fc.weight_scale_inv.data.clone() if self._is_fp8(fc) else None for fc in layers]
         best_error, best_scales = float('inf'), None
         org_out_dict = {}
         dev = org_w[0].device
@@ -208,8 +216,11 @@ class Awq(BaseBlockwiseQuantization):
                     else:
                         scales = awq_ops.awq_scales(self._act_scale_batched(x), w_max, ratio, self.trans_version)
                         cols = scales
-                    for fc, w0 in zip(layers, org_w):      # fake_quantize_weight (awq.py:147-164)
-                        fc.weight.data = self._fake_quantize_weight(w0, cols)
+                    for fc, w0, s0 in zip(layers, org_w, org_s):      # fake_quantize_weight (awq.py:147-164)
+                        if s0 is not None:
+                            fc.weight.data, fc.weight_scale_inv.data = self._fake_quantize_weight(w0, cols, s0)
+                        else:
+                            fc.weight.data = self._fake_quantize_weight(w0, cols)
                     x_tmp = awq_ops.div_cols(x, cols)     # scaling_input (base_blockwise_quantization.py:877-889)
                     if not self.w_only:
                         x_tmp = self.fake_quantize_input(x_tmp, layers_dict)      # awq.py:223-224
@@ -218,8 +229,10 @@ class Awq(BaseBlockwiseQuantization):
                         m = self.padding_mask[i].unsqueeze(dim=-1).to(org_out.device)
                         org_out, out = org_out * m, out * m
                     loss = self.calculate_loss(org_out, out)
-                    for fc, w0 in zip(layers, org_w):      # inspect_module.load_state_dict(org_sd)
+                    for fc, w0, s0 in zip(layers, org_w, org_s):      # inspect_module.load_state_dict(org_sd)
                         fc.weight.data = w0
+                        if s0 is not None:
+                            fc.weight_scale_inv.data = s0
                     if len(input) == 1:
                         # one batch (the shipped bs: -1): loss_mean = loss, scales_mean = scales; the 20 losses and
                         # the running best stay on the device — no host sync per grid point (the reference's .item())

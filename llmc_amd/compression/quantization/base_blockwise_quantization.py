@@ -43,12 +43,38 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
         self.dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
         self.set_quant_config()
 
+    # ---- block-wise FP8 checkpoints (DeepSeek-V3 layout: `weight` float8_e4m3fn + `weight_scale_inv`) ------------
+    def _fp8_to_bf16(self, weight, scale_inv):
+        """weight_cast_to_bf16(...).to(bfloat16) of the reference's FP8 branches (base_…:53-57, 347-350, 666-670, 763-767;
+        awq.py:53-56, 148-151). The reference binds the Triton kernels on FP8-capable GPUs and the FloatQuantizer spelling
+        elsewhere (awq.py:14-20); gfx950 is FP8-capable, so the kernel arithmetic is the default here and
+        `special.fp8_cast: quantizer` selects the other one (its rounding then follows the quantizer's fp8_semantics)."""
+        from . import kernel, quant
+        if self.fp8_cast == 'quantizer':
+            return quant.weight_cast_to_bf16(weight.data, scale_inv.data, self.fp8_block_size)
+        return kernel.weight_cast_to_bf16(weight.data.contiguous(), scale_inv.data.contiguous(), self.fp8_block_size)
+
+    def _bf16_to_fp8(self, weight):
+        """weight_cast_to_fp8(weight, self.fp8_block_size) -> (float8_e4m3fn weight, fp32 block scales)."""
+        from . import kernel, quant
+        if self.fp8_cast == 'quantizer':
+            return quant.weight_cast_to_fp8(weight, self.fp8_block_size, fp8_semantics=self.fp8_cast_semantics)
+        return kernel.weight_cast_to_fp8(weight.contiguous(), self.fp8_block_size)
+
+    @staticmethod
+    def _is_fp8(module):
+        return module.weight.data.dtype == torch.float8_e4m3fn
+
     # ---- quantizer callbacks handed to the Linear wrappers (base_…:46-83) ---------------------------
     def w_qdq(self, module, wquantizer):
         args = {}                                 # base_blockwise_quantization.py:46-52: clip v2's learnable bounds ride along
         if getattr(module, 'buf_upbound_factor', None) is not None:
             args['upbound_factor'] = module.buf_upbound_factor
             args['lowbound_factor'] = getattr(module, 'buf_lowbound_factor', None)
+        if self._is_fp8(module):                  # base_…:53-67: de-block, fake-quantize, re-block (the scales are replaced)
+            tmp = wquantizer.fake_quant_weight_dynamic(self._fp8_to_bf16(module.weight, module.weight_scale_inv), args)
+            tmp, module.weight_scale_inv.data = self._bf16_to_fp8(tmp)
+            return tmp
         return wquantizer.fake_quant_weight_dynamic(module.weight, args)
 
     def w_q(self, module, wquantizer):
@@ -140,6 +166,12 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             raise NotImplementedError('online rotation is outside the hot path')
         self.online_rotate = False
         self.modality = _get(qc, 'modality', 'language')
+        # base_…:134-135: block size of a block-wise FP8 checkpoint (model.fp8_block_size; DeepSeek-V3: 128)
+        self.fp8_block_size = getattr(self.model, 'fp8_block_size', None) or 128
+        self.fp8_cast = special.get('fp8_cast', 'kernel')
+        if self.fp8_cast not in ('kernel', 'quantizer'):
+            raise ValueError(f"special.fp8_cast must be 'kernel' or 'quantizer', got {self.fp8_cast!r}")
+        self.fp8_cast_semantics = special.get('fp8_cast_semantics', 'qtorch')
         self.do_gqa_trans = special.get('do_gqa_trans', False)
         self.set_model_config()
 
@@ -339,7 +371,12 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
         elif fc1.out_features == fc2.in_features:
             if getattr(fc1, 'bias', None) is not None:
                 fc1.bias.div_(scales.view(-1))
-            fc1.weight.div_(scales.view(-1, 1))
+            if self._is_fp8(fc1):                                      # base_…:666-674
+                tmp = self._fp8_to_bf16(fc1.weight, fc1.weight_scale_inv)
+                tmp.div_(scales.view(-1, 1))
+                fc1.weight.data, fc1.weight_scale_inv.data = self._bf16_to_fp8(tmp)
+            else:
+                fc1.weight.div_(scales.view(-1, 1))
         elif self.has_gqa and self.do_gqa_trans:
             if getattr(fc1, 'bias', None) is not None:
                 fc1.bias.div_(scales.view(-1))
@@ -347,7 +384,17 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             scales = self.repeat_gqa_scales(scales).reshape(-1)
         else:
             raise Exception('Can not scale this fc-fc.')
-        awq_ops.mul_cols_(fc2.weight.data, scales.reshape(-1).to(fc2.weight.dtype))
+        self._mul_cols_weight(fc2, scales.reshape(-1))
+
+    def _mul_cols_weight(self, fc, cols):
+        """fc.weight.mul_(scales.view(1, -1)); a block-wise FP8 weight is de-blocked to bf16 first and re-blocked after
+        (base_…:691-700, 763-772)."""
+        if self._is_fp8(fc):
+            tmp = self._fp8_to_bf16(fc.weight, fc.weight_scale_inv)
+            awq_ops.mul_cols_(tmp, cols.to(tmp.dtype))
+            fc.weight.data, fc.weight_scale_inv.data = self._bf16_to_fp8(tmp)
+        else:
+            awq_ops.mul_cols_(fc.weight.data, cols.to(fc.weight.dtype))
 
     @torch.no_grad()
     def scale_ln_fcs(self, ln, fcs, scales):
@@ -358,9 +405,11 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
         if getattr(ln, 'bias', None) is not None:
             ln.bias.div_(scales)
         for fc in fcs:
-            awq_ops.mul_cols_(fc.weight.data, scales.reshape(-1))
+            self._mul_cols_weight(fc, scales.reshape(-1))
         for p in list(ln.parameters()) + [q for fc in fcs for q in fc.parameters()]:
-            assert torch.isnan(p).sum() == 0
+            # (isnan has no float8 kernel: an e4m3fn NaN is the code 0x7f / 0xff)
+            nan = ((p.view(torch.uint8) & 0x7f) == 0x7f) if p.dtype == torch.float8_e4m3fn else torch.isnan(p)
+            assert nan.sum() == 0
 
     @torch.no_grad()
     def scaling_input(self, x, scales, is_gqa):

@@ -61,6 +61,12 @@ extern "C" int llmc_hip_set_cu_reserve(int n_cus) {
 
 extern "C" int llmc_hip_abi_version(void) { return LLMC_HIP_ABI_VERSION; }
 
+// hash of the sources and flags this library was built from (llmc_amd/build.py:source_digest), checked by the loader
+#ifndef LLMC_BUILD_ID
+#define LLMC_BUILD_ID "unknown"
+#endif
+extern "C" const char* llmc_hip_build_id(void) { return LLMC_BUILD_ID; }
+
 extern "C" int llmc_hip_last_error(char* buf_host, size_t n) {
     if (!buf_host || n == 0) return (int)strlen(llmc::g_last_error);
     strncpy(buf_host, llmc::g_last_error, n - 1);

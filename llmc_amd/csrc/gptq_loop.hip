@@ -491,6 +491,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     }
     hipEvent_t C1_prev = nullptr;                 // the previous group's far-far update has reached the next group's columns
     hipEvent_t C2_hist[3] = {nullptr, nullptr, nullptr};   // ... is complete (its err buffer may be rewritten)
+    hipEvent_t bulk_tail = nullptr;               // behind the most recent launch on the bulk stream
     const int force_generic = getenv("LLMC_GPTQ_GENERIC") ? 1 : 0;
     // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as
     // "W -= chain over the block's 128 k" (gptq.py:244). Columns inside the current outer group get them right
@@ -503,6 +504,13 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
         // never-visited columns beyond n_quant (their group-wide phased update could start on a ragged phase)
         const int64_t near_end = gend == NQ ? K : gend;
         float* Err = ErrBuf[gidx % 3];
+        if (ps && near_end > gend) {
+            // OWQ's last group: its per-block updates reach the never-visited columns [n_quant, K), which the earlier
+            // groups' far-far updates on the bulk stream also write (nothing else orders the two when
+            // last_group_start + 512 < K). Everything queued on the bulk stream so far has to land first.
+            int rc = pipe_wait(st, bulk_tail);
+            if (rc) return rc;
+        }
         if (ps && C2_hist[gidx % 3]) {            // the far-far update that read this err buffer three groups ago
             int rc = pipe_wait(st, C2_hist[gidx % 3]);
             if (rc) return rc;
@@ -586,6 +594,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
                     if ((rc = sgemm_launch(h2, false, false, bulk))) return rc;
                 }
                 if (ps && (rc = ps->record(bulk, &C2_hist[gidx % 3]))) return rc;
+                bulk_tail = C2_hist[gidx % 3];
             }
         }
     }

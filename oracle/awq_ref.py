@@ -329,3 +329,47 @@ def search_scale_wa(w, xs, dt, wcfg, acfg, version='v2', n_grid=20):
 
 def loss_mean_fn(y0, y, dt):
     return loss_mean(y0, y, dt)
+
+
+# ---- block-wise FP8 checkpoints (`weight` float8_e4m3fn + `weight_scale_inv` per b x b block; awq.py:53-58, 147-164,
+# base_blockwise_quantization.py:46-68, 655-700, 750-775). The reference de-blocks to bf16 (quant.py:18-30: fp32 product of
+# code value and block scale, rounded to bf16 once), works in bf16, and re-blocks (quant.py:33-43 = FloatQuantizer e4m3
+# per_block). `sem`: 'qtorch' = the reference's FloatQuantizer spelling, 'cast' = its Triton kernels' e4m3fn cast.
+def fp8ckpt_to_bf16(bits, scales, block):
+    M, N = bits.shape
+    s = np.repeat(np.repeat(np.asarray(scales, np.float32), block, 0), block, 1)[:M, :N]
+    return rnd((Q.e4m3fn_bits_to_f32(bits) * s).astype(np.float32), 'bf16')
+
+
+def fp8ckpt_from_bf16(w, block, sem='qtorch'):
+    bits, scales, _ = Q.fp8_per_block(w, 'bf16', block, sem)
+    return bits, scales
+
+
+def fp8ckpt_weight_scale(layers, block, group_size):
+    """get_weight_scale over FP8 layers [(bits, scales), ...]"""
+    return weight_scale([fp8ckpt_to_bf16(b, s, block) for b, s in layers], 'bf16', group_size)
+
+
+def fp8ckpt_fake_quantize_weight(bits, scales, cols, block, sym, qmin, qmax, group_size, sem='qtorch'):
+    w = fp8ckpt_to_bf16(bits, scales, block)
+    return fp8ckpt_from_bf16(fake_quantize_weight(w, cols, 'bf16', sym, qmin, qmax, group_size), block, sem)
+
+
+def fp8ckpt_w_qdq(bits, scales, block, sym, qmin, qmax, group_size, sem='qtorch'):
+    w = fp8ckpt_to_bf16(bits, scales, block)
+    g = group_size or w.shape[1]
+    fq, _, _ = Q.fake_quant_dynamic(w.reshape(-1, g), 'bf16', sym, qmin, qmax)
+    return fp8ckpt_from_bf16(fq.reshape(w.shape), block, sem)
+
+
+def fp8ckpt_mul_cols(bits, scales, cols, block, sem='qtorch'):
+    """fc.weight.mul_(scales.view(1, -1)) of scale_ln_fcs / scale_fc_fc on an FP8 layer"""
+    w = rnd(fp8ckpt_to_bf16(bits, scales, block) * np.asarray(cols, np.float32)[None, :], 'bf16')
+    return fp8ckpt_from_bf16(w, block, sem)
+
+
+def fp8ckpt_div_rows(bits, scales, rows, block, sem='qtorch'):
+    """fc1.weight.div_(scales.view(-1, 1)) of scale_fc_fc on an FP8 layer"""
+    w = rnd(fp8ckpt_to_bf16(bits, scales, block) / np.asarray(rows, np.float32)[:, None], 'bf16')
+    return fp8ckpt_from_bf16(w, block, sem)

@@ -1435,7 +1435,87 @@ def suite_mse():
     out['cases'] = np.array(['|'.join(map(str, c)) for c in cases])
     save('mse', **out)
 
-SUITES = {'fp8_group_qtorch': suite_fp8_group_qtorch, 'awq_wa': suite_awq_wa, 'clip_wide': suite_clip_wide, 'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
+def suite_awq_fp8ckpt():
+    """The FP8-checkpoint branches of the AWQ path (DeepSeek-V3 layout: `weight` float8_e4m3fn + `weight_scale_inv` per
+    128 x 128 block): Awq.get_weight_scale (awq.py:48-72), Awq.fake_quantize_weight (awq.py:147-164),
+    scale_ln_fcs / scale_fc_fc (base_blockwise_quantization.py:655-700, 750-775) and w_qdq (base_…:46-68), run from the
+    reference's own class code on CPU. There the reference binds its NON-Triton weight_cast_to_bf16 / weight_cast_to_fp8
+    (quant.py:18-43, FloatQuantizer e4m3 per_block with use_qtorch) — float_quantize = the restated qtorch, as in
+    suite_fp8_block_qtorch. (The search loop itself is not recorded: the reference's non-Triton LlmcFp8Linear.forward
+    replaces the layer's weight by a bf16 tensor, module_utils.py:160-164, so its first grid point turns the module
+    into a bf16 one.)"""
+    import llmc.compression.quantization.quant as qmod
+    qmod.float_quantize = _qtorch_stub
+    import llmc.compression.quantization.awq as awq_mod
+    import llmc.compression.quantization.base_blockwise_quantization as bb_mod
+    from llmc.compression.quantization.awq import Awq
+    from llmc.compression.quantization.module_utils import LlmcFp8Linear
+    for m in (awq_mod, bb_mod):            # the CPU binding (awq.py:17-20): the quantizer spelling of the two casts
+        m.weight_cast_to_bf16, m.weight_cast_to_fp8 = qmod.weight_cast_to_bf16, qmod.weight_cast_to_fp8
+    out = {}
+    gen = torch.Generator().manual_seed(20250926)
+    cfgs = [('w4g128_asym', 4, False, 128, 128), ('w4g64_sym', 4, True, 64, 128), ('w8ch_sym', 8, True, 0, 128),
+            ('w4g32_asym_b64', 4, False, 32, 64)]
+    for name, bit, sym, gs, bsz in cfgs:
+        K, Rs = 256, (192, 128)
+        wq = IntegerQuantizer(bit, sym, 'per_group', group_size=gs) if gs else IntegerQuantizer(bit, sym, 'per_channel')
+        a = Awq.__new__(Awq)
+        a.wquantizer = wq
+        a.fp8_block_size = bsz
+        a.has_gqa = False
+        a.do_gqa_trans = False
+        layers, p = [], name + '/'
+        for li, R in enumerate(Rs):
+            l = LlmcFp8Linear(K, R, None, bsz)
+            wt = torch.randn(R, K, generator=gen) * 0.02
+            wt[:, torch.randperm(K, generator=gen)[:4]] *= 20
+            w8, s8 = qmod.weight_cast_to_fp8(wt.to(torch.bfloat16), bsz)
+            l.weight.data, l.weight_scale_inv.data = w8, s8
+            layers.append(l)
+            out[p + f'w8_{li}'] = w8.view(torch.uint8).numpy().copy()
+            out[p + f's8_{li}'] = f32(s8)
+        layers_dict = {f'l{i}': l for i, l in enumerate(layers)}
+        w_max = a.get_weight_scale(layers_dict)
+        out[p + 'w_max'] = f32(w_max)
+        scales = (torch.exp(0.4 * torch.randn(K, generator=gen))).to(torch.bfloat16)
+        out[p + 'scales'] = f32(scales)
+        for li, l in enumerate(layers):
+            w_keep, s_keep = l.weight.data.clone(), l.weight_scale_inv.data.clone()
+            a.fake_quantize_weight(l, scales, False, f'l{li}')
+            out[p + f'fq_w8_{li}'] = l.weight.data.view(torch.uint8).numpy().copy()
+            out[p + f'fq_s8_{li}'] = f32(l.weight_scale_inv.data)
+            l.weight.data, l.weight_scale_inv.data = w_keep.clone(), s_keep.clone()
+            # w_qdq (deploy-time fake quant of an FP8 module): returns the fp8 tensor, replaces the block scales
+            r = a.w_qdq(l, wq)
+            out[p + f'qdq_w8_{li}'] = r.view(torch.uint8).numpy().copy()
+            out[p + f'qdq_s8_{li}'] = f32(l.weight_scale_inv.data)
+            l.weight.data, l.weight_scale_inv.data = w_keep, s_keep
+        # scale folding: LayerNorm -> the two FP8 layers, then fc -> fc (v_proj -> o_proj shape: out == in)
+        ln = torch.nn.LayerNorm(K).to(torch.bfloat16)
+        ln.weight.data = (1.0 + 0.1 * torch.randn(K, generator=gen)).to(torch.bfloat16)
+        ln.bias.data = (0.1 * torch.randn(K, generator=gen)).to(torch.bfloat16)
+        out[p + 'ln_w'], out[p + 'ln_b'] = f32(ln.weight.data), f32(ln.bias.data)
+        a.scale_ln_fcs(ln, layers, scales)
+        out[p + 'ln_w_after'], out[p + 'ln_b_after'] = f32(ln.weight.data), f32(ln.bias.data)
+        for li, l in enumerate(layers):
+            out[p + f'ln_w8_{li}'] = l.weight.data.view(torch.uint8).numpy().copy()
+            out[p + f'ln_s8_{li}'] = f32(l.weight_scale_inv.data)
+        fc1, fc2 = LlmcFp8Linear(K, K, None, bsz), LlmcFp8Linear(K, 128, None, bsz)
+        for li, l in enumerate((fc1, fc2)):
+            wt = torch.randn(l.out_features, K, generator=gen) * 0.03
+            l.weight.data, l.weight_scale_inv.data = qmod.weight_cast_to_fp8(wt.to(torch.bfloat16), bsz)
+            out[p + f'fc{li + 1}_w8'] = l.weight.data.view(torch.uint8).numpy().copy()
+            out[p + f'fc{li + 1}_s8'] = f32(l.weight_scale_inv.data)
+        a.scale_fc_fc(fc1, fc2, scales)
+        for li, l in enumerate((fc1, fc2)):
+            out[p + f'fc{li + 1}_w8_after'] = l.weight.data.view(torch.uint8).numpy().copy()
+            out[p + f'fc{li + 1}_s8_after'] = f32(l.weight_scale_inv.data)
+        out[p + 'meta'] = np.array([bit, int(sym), gs, bsz, K], dtype=np.int64)
+    out['names'] = np.array([c[0] for c in cfgs])
+    save('awq_fp8ckpt', **out)
+
+
+SUITES = {'awq_fp8ckpt': suite_awq_fp8ckpt, 'fp8_group_qtorch': suite_fp8_group_qtorch, 'awq_wa': suite_awq_wa, 'clip_wide': suite_clip_wide, 'clip_more': suite_clip_more, 'awq_more': suite_awq_more, 'gptq_more': suite_gptq_more, 'awq_gqa': suite_awq_gqa, 'clip_v2': suite_clip_v2, 'awq_flat': suite_awq_flat, 'clip_mb': suite_clip_mb, 'mse': suite_mse, 'quant': suite_quant, 'pack': suite_pack, 'gptq': suite_gptq, 'awq': suite_awq, 'clip': suite_clip,
           'fp8': suite_fp8, 'e2e': suite_e2e, 'awq_inspect': suite_awq_inspect, 'quant_pt': suite_quant_pt, 'gptq_owq': suite_gptq_owq, 'fp8_block': suite_fp8_block, 'fp8_qtorch': suite_fp8_qtorch, 'fp8_block_qtorch': suite_fp8_block_qtorch, 'spqr': suite_spqr, 'e2e_spqr': suite_e2e_spqr, 'hist': suite_hist}
 
 if __name__ == '__main__':

@@ -67,3 +67,18 @@ def test_product_refuses_cpu_tensors():
     q = IntegerQuantizer(4, True, 'per_group', group_size=128)
     with pytest.raises(_ffi.LlmcHipError):
         q.get_tensor_qparams(torch.zeros(4, 128))
+
+
+def test_a_stale_library_is_refused(monkeypatch):
+    """llmc_hip_build_id() is the hash of csrc/ + include/llmc_hip.h + flags at build time; the loader recomputes it from
+    the sources and fails loudly when they differ (a silently failed compile used to leave the old .so in place)."""
+    import pytest
+    from llmc_amd import _ffi, build
+    lib = _ffi.lib()
+    assert lib.llmc_hip_build_id().decode() == build.source_digest()
+    monkeypatch.setattr(_ffi, '_lib', None)
+    monkeypatch.setattr(build, 'source_digest', lambda: '0123456789abcdef')
+    with pytest.raises(_ffi.LlmcHipError, match='stale'):
+        _ffi.lib()
+    monkeypatch.setenv('LLMC_SKIP_BUILD_ID_CHECK', '1')
+    assert _ffi.lib() is not None

@@ -526,3 +526,33 @@ def test_pipelined_column_loop_is_bit_identical_to_the_single_stream_schedule(sh
     torch.cuda.current_stream().wait_stream(side)
     for a, b in zip(ref, out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(512, 4096, 3584), (256, 5248, 2944), (384, 4096, 1000)])
+def test_pipelined_owq_column_loop_is_bit_identical_to_the_single_stream_schedule(shape):
+    """OWQ (n_quant < K) with helper streams: the last group's per-block updates write the never-visited columns
+    [n_quant, K), which earlier groups' far-far updates on the bulk stream write too (a missing dependency
+    whenever last_group_start + 512 < K). Bit-identical to the single-stream schedule, repeatedly."""
+    from llmc_amd import _ffi
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper, gptq_quantize
+    R, K, nq = shape
+    gen = torch.Generator(device='cuda').manual_seed(R + K + nq)
+    X = torch.randn(2 * K, K, generator=gen, device='cuda')
+    H = (X.T @ X) / K
+    H.diagonal().add_(0.05)
+    U = chol_inv_upper(H, check=False)
+    W = torch.randn(R, K, generator=gen, device='cuda') * 0.02
+    ng = (K + 127) // 128
+    s0 = torch.ones(R, ng, device='cuda')
+    z0 = torch.zeros(R, ng, device='cuda')
+
+    def run():
+        Wc = W.clone()
+        out = gptq_quantize(Wc, U, False, 0.0, 15.0, 128, n_quant=nq, init_scales=s0, init_zeros=z0)
+        return (Wc,) + tuple(out)       # the running weights hold the outlier columns
+
+    with _ffi.helper_streams(False):
+        ref = run()
+    for _ in range(4):
+        for a, b in zip(ref, run()):
+            assert torch.equal(a, b)

@@ -657,3 +657,34 @@ def test_awq_search_with_two_near_equal_minima_picks_the_reference_grid_point():
     assert np.abs(losses - ref).max() / ref.min() < gap / 10
     assert n == int(np.argmin(ref))
     assert _ulp_close(best, g[p + 'best_scales'], dt, max_frac_diff=0.01, max_ulps=1)
+
+
+def test_awq_fp8_checkpoint_branches_bit_exact_vs_reference():
+    """oracle/awq_ref.py:fp8ckpt_* against the reference's own class code on block-wise FP8 modules (awq_fp8ckpt.npz:
+    get_weight_scale, fake_quantize_weight, w_qdq, scale_ln_fcs, scale_fc_fc with the non-Triton casts)."""
+    from oracle import awq_ref as A
+    g = load_golden('awq_fp8ckpt')
+    for name in [str(n) for n in g['names']]:
+        p = name + '/'
+        bit, sym, gs, bsz, K = [int(v) for v in g[p + 'meta']]
+        qmin, qmax = Q.int_range(bit, bool(sym))
+        layers = [(g[p + f'w8_{i}'], g[p + f's8_{i}']) for i in range(2)]
+        np.testing.assert_array_equal(A.fp8ckpt_weight_scale(layers, bsz, gs).view(np.uint32), g[p + 'w_max'].view(np.uint32), err_msg=name)
+        cols = g[p + 'scales']
+        for i, (b8, s8) in enumerate(layers):
+            fb, fs = A.fp8ckpt_fake_quantize_weight(b8, s8, cols, bsz, bool(sym), qmin, qmax, gs)
+            np.testing.assert_array_equal(fs.view(np.uint32), g[p + f'fq_s8_{i}'].view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(fb, g[p + f'fq_w8_{i}'], err_msg=name)
+            qb, qs = A.fp8ckpt_w_qdq(b8, s8, bsz, bool(sym), qmin, qmax, gs)
+            np.testing.assert_array_equal(qs.view(np.uint32), g[p + f'qdq_s8_{i}'].view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(qb, g[p + f'qdq_w8_{i}'], err_msg=name)
+            lb, ls = A.fp8ckpt_mul_cols(b8, s8, cols, bsz)
+            np.testing.assert_array_equal(ls.view(np.uint32), g[p + f'ln_s8_{i}'].view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(lb, g[p + f'ln_w8_{i}'], err_msg=name)
+        np.testing.assert_array_equal(Q.rnd(g[p + 'ln_w'] / cols, 'bf16').view(np.uint32), g[p + 'ln_w_after'].view(np.uint32))
+        b1, s1 = A.fp8ckpt_div_rows(g[p + 'fc1_w8'], g[p + 'fc1_s8'], cols, bsz)
+        np.testing.assert_array_equal(b1, g[p + 'fc1_w8_after'], err_msg=name)
+        np.testing.assert_array_equal(s1.view(np.uint32), g[p + 'fc1_s8_after'].view(np.uint32), err_msg=name)
+        b2, s2 = A.fp8ckpt_mul_cols(g[p + 'fc2_w8'], g[p + 'fc2_s8'], cols, bsz)
+        np.testing.assert_array_equal(b2, g[p + 'fc2_w8_after'], err_msg=name)
+        np.testing.assert_array_equal(s2.view(np.uint32), g[p + 'fc2_s8_after'].view(np.uint32), err_msg=name)
