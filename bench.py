@@ -66,6 +66,7 @@ def parity_envelope_summary(args):
         pick = lambda m: {k: m[k] for k in ('codes_equal', 'scales_within_1e-4', 'scales_within_1e-2', 'zeros_equal', 'perm_equal',
                                             'perm_diff_within_4x_noise') if k in m}
         return {'layer': j['shapes'][0]['title'], 'source': 'profiles/r04_parity_envelope_full_down.json',
+                'precomputed': 'NOT measured by this run: read from the committed file (tools/parity_envelope.py --full-down on an MI355X, round 4)',
                 'ours_vs_reference_cpu': pick(pr['ref_cpu_32t vs ours']),
                 'reference_cpu_vs_reference_rocm': pick(pr['ref_cpu_32t vs ref_rocm'])}
     except Exception:       # noqa: BLE001
@@ -190,8 +191,11 @@ def cpu_baseline_reference(model, n_seq, seq):
     return {
         'value': _block_model(model, n_seq, t['t_hessian_per_seq'], t['t_factor'], t['t_loop'], K),
         'unit': 'layers/s', 'cores': t['threads'], 'kind': 'reference',
+        'host_cores': t.get('host_cores', cores), 'hessian_thread_sweep_s': t.get('hessian_thread_sweep_s'),
+        'hessian_gflops': t.get('hessian_gflops'),
         'sample': (f"llmc's own GPTQ (oracle/_ref = /root/reference after its ci_check/change_files.py CPU rewrite), torch "
-                   f"CPU, {t['threads']} threads for the Hessian GEMM and {t.get('threads_small_ops', t['threads'])} for the "
+                   f"CPU, {t['threads']} threads for the Hessian GEMM (the best of a sweep over 8..{t.get('host_cores', cores)} threads: "
+                   f"{t.get('hessian_gflops', 0.0):.0f} GFLOP/s) and {t.get('threads_small_ops', t['threads'])} for the "
                    f"factorisations / column loop (more threads make those slower): add_batch on {nb} of {n_seq} sequences of one {K}-channel input "
                    f"({t['t_hessian_per_seq']:.3f} s/seq), process_hessian_and_weights ({t['t_factor']:.2f} s) and "
                    f"weight_transform ({t['t_loop']:.2f} s) of one {K}x{K} layer in full; other shapes scaled by flop "
@@ -483,7 +487,10 @@ def run_awq(args):
         print(json.dumps({
             'metric': 'layers/sec (AWQ W4A16 g128 scale search + fake-quant eval, %s Linear shapes, 128x512 calib)' % args.model,
             'value': n_layers * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step_median': med_ms, 'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
+            'value_at_median_step': (layers_step / (med_ms * 1e-3)) if med_ms else None,      # this rank's steps; `value` is the contract's mean
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'AWQ W4A16 g128 sym, trans v2, 20-point scale search with inspect = the Linear layers, '
                                    f'{args.model}-shaped random-init layers, 1 block (7 Linear, 4 subsets) per step per GPU',
@@ -579,7 +586,10 @@ def run_fp8(args):
         print(json.dumps({
             'metric': 'layers/sec (FP8 e4m3 per-tensor weight quantization + static activation ranges, Mixtral-8x7B block shapes)',
             'value': len(layers) * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step_median': med_ms, 'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
+            'value_at_median_step': (layers_step / (med_ms * 1e-3)) if med_ms else None,      # this rank's steps; `value` is the contract's mean
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f8e4m3 codes from ' + args.dtype, 'data': 'synthetic',
             'config': {'workload': 'FP8 e4m3 symmetric per-tensor RTN: 28 Linear weights of one Mixtral-8x7B block (4 attention + 8 experts '
                                    'x 3) -> absmax, scale, codes; static per-tensor ranges of their 18 inputs (128 x 512 calibration '
@@ -696,6 +706,14 @@ def main():
     ops = DryOps(cfg) if args.dry else HipOps(dev, cfg, args.variant)
     n_layers_block = sum(len(ls) for _, _, ls in groups)
     timing = []
+    # payload each mode moves between ranks per step (per rank; a ring all-reduce moves 2 (N - 1) / N of its payload):
+    # handoff = the block's first input; cooperative = per subset the broadcast Hessian (stacked subsets), the broadcast
+    # activations (single-layer subsets) or the all-reduced Hessian (sample-sharded wide subset)
+    esz = 4 if args.dry else 2
+    interrank_bytes = {
+        'handoff': args.n_seq * args.seq_len * groups[0][1] * esz,
+        'cooperative': sum((K * K * 4) if (K > 8192 or len(ls) > 1) else args.n_seq * args.seq_len * K * esz for _, K, ls in groups),
+    }
 
     def prepare(mode):
         """Resident synthetic data and the step function of one mode. independent / handoff: every rank owns different
@@ -893,11 +911,29 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
+    # per-step end marks on the launch stream (every chain stream is joined into it at the end of a step): the median step
+    # SURVEY 8d asks for, beside the contract's mean over exactly K steps
+    marks = []
+    if not args.dry:
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[0].record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step(True)
+        if not args.dry:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
+    med_ms = (step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])) if step_ms else None
+    # round barriers of the last step's SYRK launches that gave up (no longer silent)
+    barrier_timeouts = None
+    if not args.dry and hasattr(ops, 'accs') and ops.accs:
+        try:
+            barrier_timeouts = sum(a.barrier_timeouts() for a in ops.accs.values())
+        except Exception:        # noqa: BLE001
+            barrier_timeouts = None
     # deferred positive-definiteness check of the factorisations (the classes check once per subset; here after timing)
     def _infos(o):
         if isinstance(o, dict):
@@ -981,7 +1017,10 @@ def main():
                 {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B'}.get(args.model, args.model), args.n_seq,
                 args.seq_len),
             'value': total_layers / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step_median': med_ms, 'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
+            'value_at_median_step': (layers_step / (med_ms * 1e-3)) if med_ms else None,      # this rank's steps; `value` is the contract's mean
+            'higher_is_better': True,
             'scaling': 'strong' if coop else 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'dry-run (CPU stand-ins, no kernels): plumbing only' if args.dry else 'synthetic',
             'config': {
@@ -1007,12 +1046,22 @@ def main():
                 'algorithmic_flops_per_launch': fl / max(1, n_launch),
                 'avg_launch_ms': ms / max(1, n_launch),
                 'achieved_incl_fixup': achieved_fix, 'avg_fixup_ms': ms_fix / max(1, n_launch),
+                'round_barrier_timeouts_last_step': barrier_timeouts,
             },
         }
         if world > 1:
-            # No number of this script has been measured on more than one GPU yet (no multi-GPU box in rounds 1-4): the modes
+            # No number of this script has been measured on more than one GPU yet (no multi-GPU box in rounds 1-5): the modes
             # are covered by Gloo runs at world sizes 2, 4 and 8 (tests/test_bench_spawn.py) and a 2-GPU RCCL test.
             out['config']['multi_gpu_status'] = 'unmeasured on hardware before this run'
+            # what the timed value exercised: `independent` moves no byte between ranks
+            out['value_mode'] = ('cooperative' if coop else 'handoff' if handoff else 'independent_no_comm')
+            out['rccl_world'] = (torch.distributed.get_world_size() if not args.dry else None)        # ranks of the nccl (= RCCL) group
+            out['data_backend'] = 'gloo (dry run)' if args.dry else torch.distributed.get_backend()
+            out['interrank_bytes_per_step_per_rank'] = {
+                'independent': 0,
+                'handoff': interrank_bytes['handoff'],
+                'cooperative': interrank_bytes['cooperative'],
+            }
             out.update(secondary)    # handoff_value / cooperative_value (layers/s, a few steps each, outside the timed region) or *_error
         if handoff_error is not None:
             out['handoff_error'] = handoff_error              # the run fell back to the ownership without the hand-off

@@ -201,6 +201,11 @@ int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, const int64
                                      int64_t K, int64_t ldx, void* ws, llmc_stream_t stream);
 int llmc_hessian_accum_ptrs_reduce(float* H, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
                                    double n_before, double n_after, const void* ws, llmc_stream_t stream);
+/* Diagnostic: how many round barriers of the LAST llmc_hessian_accum*_partials launch on `ws` (same T list, K, ldx) gave
+ * up waiting because workgroups of its persistent grid were kept off their CUs by other streams. Synchronises `stream`
+ * and writes the count to *out_host. 0 in a healthy run; > 0 leaves the result correct but the launch slower. */
+int llmc_hessian_accum_barrier_timeouts(const void* ws, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
+                                        unsigned* out_host, llmc_stream_t stream);
 
 /* GPTQ.process_hessian_and_weights, first half (gptq.py:135-152, 169-171):
  *   dead = diag(H) == 0 -> H[dead,dead] = 1, W[:,dead] = 0; optional symmetric gather by perm

@@ -192,8 +192,21 @@ class HessianAccumulator:
             e2.record()
             self.timing.append((e0, e1, e2, T, K))
         self._flushed += b
+        self._last_launch = (Ts, n, K, ldx)
         # the tensors of xs may be released by the caller once this returns: the launches are stream-ordered and torch's
         # allocator keeps a freed block out of other streams' hands until this stream has passed
+
+    def barrier_timeouts(self):
+        """Diagnostic (synchronises the current stream): round barriers of the most recent SYRK launch that gave up waiting
+        for workgroups other streams kept off their CUs (llmc_hessian_accum_barrier_timeouts). 0 in a healthy run."""
+        last = getattr(self, '_last_launch', None)
+        if last is None or self._ws is None:
+            return 0
+        Ts, n, K, ldx = last
+        out = C.c_uint(0)
+        _ffi.check(_ffi.lib().llmc_hessian_accum_barrier_timeouts(_ffi.ptr(self._ws), Ts, n, K, ldx, C.byref(out), _ffi.stream()),
+                   'llmc_hessian_accum_barrier_timeouts')
+        return int(out.value)
 
     def reset(self):
         """Start a new Hessian in the same buffers (the first launch overwrites H: n_before = 0)."""

@@ -223,6 +223,10 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                     __builtin_amdgcn_s_sleep(8);
                     ++spins;
                 }
+                // a barrier that gave up (another stream holds CUs: some workgroups of this grid are not resident yet) is
+                // counted, not silent: sync[1] is read back by llmc_hessian_accum_barrier_timeouts (the result is still
+                // correct; the workgroups have lost their common token position and re-fetch their panels from the fabric)
+                if (spins >= (1 << 22)) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
         }
@@ -586,7 +590,7 @@ extern "C" int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, 
     if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
     if (const char* e = getenv("LLMC_SYRK_ABL")) abl = atoi(e);   // wrong results by design
 #endif
-    if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 4, st));
+    if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 8, st));     // round counter + time-out counter
     // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous), minus the CUs the caller keeps free for
     // kernels of other streams (llmc_hip_set_cu_reserve): a k_syrk4 workgroup owns its CU, nothing co-resides with it
     int grid = (device_cu_count() - cu_reserve()) & ~7;
@@ -611,6 +615,21 @@ extern "C" int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, 
     void* kargs[] = {(void*)&a};
     LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(S4_THREADS), kargs, (size_t)lds_bytes, st));
     LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+// Number of round barriers of the LAST launch on this workspace that gave up waiting (device word behind the partials):
+// copies it to *out_host after synchronising `stream`. 0 in a healthy run; > 0 means another stream kept workgroups of the
+// persistent grid off their CUs (results stay correct, the kernel re-fetches its panels: slower).
+extern "C" int llmc_hessian_accum_barrier_timeouts(const void* ws, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
+                                                   unsigned* out_host, llmc_stream_t stream) {
+    LLMC_REQUIRE(ws && out_host, "hessian_accum_barrier_timeouts: null argument");
+    SyrkArgs a;
+    int rc = syrk_plan(T_list_host, n, K, ldx, &a);
+    if (rc) return rc;
+    const char* p = (const char*)ws + (size_t)a.S * a.ntiles_p * TILE_FLOATS * sizeof(float) + 4;
+    LLMC_HIP_CHECK(hipMemcpyAsync(out_host, p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    LLMC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return LLMC_OK;
 }
 

@@ -62,6 +62,18 @@ def main():
     xs = [(torch.randn(1, a.seq, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(torch.bfloat16)
           for _ in range(a.batches)]
     g.add_batch(layer, 'fc', xs[0], None)                          # warm-up (thread pool, allocator)
+    # thread sweep for the Hessian GEMM (VERDICT r04 #9a: all 256 threads of the GPU box gave 69 GFLOP/s where 8 threads of
+    # the survey box gave 319): one sequence per count, the best count times the sample
+    sweep = {}
+    if not a.threads:
+        for n in sorted({c for c in (8, 16, 32, 64, 128, 256, cores) if c <= cores}):
+            torch.set_num_threads(n)
+            g.add_batch(layer, 'fc', xs[0], None)
+            t0 = time.perf_counter()
+            g.add_batch(layer, 'fc', xs[0], None)
+            sweep[n] = time.perf_counter() - t0
+        cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     for x in xs:
         g.add_batch(layer, 'fc', x, None)
@@ -77,6 +89,8 @@ def main():
     g.weight_transform(W, Hinv, Losses, tmp)
     t_l = time.perf_counter() - t0
     print(json.dumps({'K': K, 'seq': a.seq, 'batches': a.batches, 'threads': cores, 'threads_small_ops': small, 't_hessian_per_seq': t_h,
+                      'hessian_thread_sweep_s': {str(k): round(v, 4) for k, v in sweep.items()},
+                      'hessian_gflops': 2.0 * a.seq * K * K / t_h / 1e9, 'host_cores': os.cpu_count(),
                       't_factor': t_c, 't_loop': t_l, 'blas': torch.__config__.parallel_info().split('\n')[0:3],
                       'finite': bool(torch.isfinite(tmp).all())}), flush=True)
 
