@@ -773,17 +773,21 @@ def main():
                 evs.append(st)
 
             if args.order == 'shadow':
-                # the narrow subsets first: their Hessians (3 x 3.3 ms), then their chains on streams 1.., and BEHIND them the
-                # widest subset's Hessian (39 ms) with --reserve CUs left free: the narrow chains run in its shadow on those
-                # CUs, and the widest chain has the device to itself afterwards
-                for gi in order[1:]:
+                # the subsets with the short Hessians first: their Hessians (3 x 3.4 ms on every CU), their chains on streams 1..,
+                # and BEHIND them the WIDEST input's Hessian (down_proj: K = 14336, 39 ms) with --reserve CUs left free: K1 is
+                # power-limited, so it loses little on fewer CUs, and the other chains run in its shadow on the free ones; the
+                # widest chain has the device to itself afterwards (round 5: rounds 2-4 shadowed the subset with the largest
+                # K x rows = gate|up, a 3.4-ms Hessian, by mistake)
+                wide = max(range(len(groups)), key=lambda i: (groups[i][1], sum(r for _, r in groups[i][2])))
+                others = [gi for gi in order if gi != wide]
+                for gi in others:
                     Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs)
-                for si, gi in enumerate(order[1:]):
+                for si, gi in enumerate(others):
                     chain(si + 1, gi)
-                g0 = groups[order[0]]
+                g0 = groups[wide]
                 with ops.cu_reserve(args.reserve):
                     Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
-                chain(0, order[0], helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
+                chain(0, wide, helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
             else:
                 if args.order == 'k1first':
                     for name, K, layers in groups:

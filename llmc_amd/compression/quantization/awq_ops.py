@@ -122,8 +122,13 @@ def linear_out(x, wq, bias=None, tiled=False, blocked=False):
     if bias is not None:
         bias = bias.to(x.dtype).contiguous()
     fn, name = (L.llmc_linear_eval_kt, 'llmc_linear_eval_kt') if tiled else (L.llmc_linear_eval, 'llmc_linear_eval')
+    # the k-tiled kernel cuts a product that would leave CUs idle into k-slices when it is given the workspace for them
+    # (llmc_linear_eval_ws_bytes covers it; products that fill the chip need none)
+    ws = None
+    if tiled and not blocked and L.llmc_linear_eval_ws_bytes(N, K, R) > 4 * ((N + 255) // 256) * ((R + 255) // 256):
+        ws = _ffi.workspace(L.llmc_linear_eval_ws_bytes(N, K, R), x.device)
     _ffi.check(fn(_ffi.ptr(x2), _ffi.ptr(wq), _ffi.dt(x2), N, K, R, _ffi.LINEAR_YBLOCKED if blocked else 0, _ffi.ptr(y),
-                  _ffi.ptr(bias), 0, 0, _ffi.stream()), name)
+                  _ffi.ptr(bias), 0, _ffi.ptr(ws), _ffi.stream()), name)
     return y if blocked else y.reshape(*x.shape[:-1], R)
 
 
@@ -141,7 +146,7 @@ def linear_auto(x, w, bias=None, xcache=None):
         per shape on stderr, never silently, never the CPU."""
     R, K = w.shape
     N = x.numel() // max(1, x.shape[-1])
-    if ktile_supported(x, w) and N >= 512 and os.environ.get('LLMC_AWQ_KT', '1') != '0':
+    if ktile_supported(x, w) and os.environ.get('LLMC_AWQ_KT', '1') != '0':
         key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
         hit = xcache.get(key) if xcache is not None else None
         if hit is None:

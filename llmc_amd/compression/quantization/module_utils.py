@@ -10,37 +10,18 @@ import torch.nn as nn
 from .quant import pack_awq_gemm, pack_lsb
 
 
-_SMALL_SEEN = set()
-SMALL_TILES = 192      # fewer 256 x 256 output tiles than this leave CUs of the 256-CU chip idle in the HIP GEMMs
-
-
 def hip_linear(x, weight, bias):
     """y = x W^T + b for the fake-quant wrappers (module_utils.py:619-644, 706-741): the HIP MFMA GEMMs
-    (awq_ops.linear_auto: k-tiled one-wave-per-SIMD kernel for large inputs, row-major kernel otherwise; fp32
-    accumulation, one rounding); GPU shapes they do not take (K % 64 != 0, fp32 activations, operands >= 4 GiB) use the
-    framework's GPU linear, logged once per shape. Never the CPU.
-    Small outputs (fewer than SMALL_TILES tiles of 256 x 256: an evaluation forward of 1 x 2048 tokens through a 4096-wide
-    layer is 128) are a plain library GEMM that the 256-wide tiles of our kernels serve badly (2.3x slower than the
-    vendor GEMM at 2048 tokens, profiles/r02_linear_paths.txt): they go to torch.nn.functional.linear, said once per shape.
-    LLMC_LINEAR_SMALL=hip keeps them on the HIP kernels."""
-    import os
-    import sys
-
+    (awq_ops.linear_auto: the k-tiled one-wave-per-SIMD kernel whenever K % 128 == 0 — a product with fewer 256 x 256 output
+    tiles than CUs, e.g. an evaluation forward of 1 x 2048 tokens through a 4096-wide layer = 128 tiles, is cut into k-slices
+    so that tiles x slices fills the chip, fp32 partials summed and rounded once; the row-major kernel for K % 64 == 0; fp32
+    accumulation, one rounding). Round 5: no product of a supported shape goes to the vendor GEMM any more."""
     from llmc_amd import _ffi
 
     from . import awq_ops
     _ffi.require_gpu(x, weight)
     if weight.dtype != x.dtype:
         weight = weight.to(x.dtype)
-    n_tok = x.numel() // max(1, x.shape[-1])
-    tiles = -(-n_tok // 256) * -(-weight.shape[0] // 256)
-    if tiles < SMALL_TILES and os.environ.get('LLMC_LINEAR_SMALL', 'framework') != 'hip':
-        sig = (n_tok, tuple(weight.shape), str(x.dtype))
-        if sig not in _SMALL_SEEN:
-            _SMALL_SEEN.add(sig)
-            print(f'[llmc_amd] linear {sig}: {tiles} output tiles of 256 x 256 for 256 CUs -> torch.nn.functional.linear on the GPU '
-                  '(LLMC_LINEAR_SMALL=hip keeps the HIP GEMM)', file=sys.stderr)
-        return torch.nn.functional.linear(x, weight, bias)
     return awq_ops.linear_auto(x, weight, bias)
 
 
@@ -71,7 +52,7 @@ class OriginFloatLinear(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        return torch.nn.functional.linear(x, self.weight, self.bias)
+        return hip_linear(x, self.weight, self.bias)
 
     @classmethod
     @torch.no_grad()

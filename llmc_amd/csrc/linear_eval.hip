@@ -47,6 +47,9 @@ struct LinArgs {
     float csign;
     int krange, kunit;
     unsigned* queue;  // gemm6: tile counter (zeroed before the launch), or null = the static XCD block order
+    // split-K (k_linear_eval4, mode 3 into `C`): ntm = ntm_real * ksplit tile rows; tile row tm' is k-slice tm' / ntm_real of
+    // tile row tm' % ntm_real and writes its fp32 partial into C + slice * N * ldc (summed by k_splitk_reduce). ksplit <= 1: off
+    int ksplit, ntm_real;
 };
 
 // (round, block) -> tile; false = padding of a ragged block
@@ -326,11 +329,21 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
             else { tm = q / a.ntn; tn = q - tm * a.ntn; }
             round = -1;     // the loop ends by the break above
         } else if (!lin_tile(a, round, tm, tn)) continue;
+        int ks = 0;                               // split-K: which k-slice of the tile this unit is
+        if (a.ksplit > 1) {
+            ks = __builtin_amdgcn_readfirstlane(tm / a.ntm_real);    // (the division goes through the VALU; the value is uniform)
+            tm -= ks * a.ntm_real;
+        }
         const int t = tm * a.ntn + tn;
         // triangular operands (gemm6): stages [st0, st1) of 32 k; both ends are multiples of a ring turn
         int st0 = 0, st1 = (int)(a.K / L4_KS);
         if (a.krange == 1) st0 = tm * LT * a.kunit / L4_KS;
         if (a.krange == 2) st1 = min(st1, (tn + 1) * LT * a.kunit / L4_KS);
+        if (a.ksplit > 1) {                       // equal slices of whole ring turns, the last one takes the remainder
+            const int per = ((st1 / a.ksplit) >> 2) << 2;
+            st0 = ks * per;
+            if (ks + 1 < a.ksplit) st1 = st0 + per;
+        }
         const int ngroups = (st1 - st0) / L4_RING;
         if (ngroups <= 0 && a.mode != 3) continue;
         const uint32_t vA = (uint32_t)(tm * LT * 64) + vlane;
@@ -517,7 +530,8 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
 
         __builtin_amdgcn_s_barrier();    // every wave has read its last fragments before the next prologue refills the ring
         if (a.mode == 3) {
-            // gemm6: C = csign * acc in fp32; a lane's 32 consecutive columns per row segment are one 128-B line
+            // gemm6 / split-K: C = csign * acc in fp32; a lane's 32 consecutive columns per row segment are one 128-B line
+            float* const Cs = a.C + (int64_t)ks * a.N * a.ldc;
             l4_static_for<0, 16>([&](auto mnc) {
                 constexpr int m = decltype(mnc)::value >> 2, n = decltype(mnc)::value & 3;
                 const int64_t col = (int64_t)tn * LT + wn * 128 + n * 32 + (lane & 31);
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(L4_THREADS) void k_linear_eval4(LinArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t tok = tok0 + (r & 3) + 8 * (r >> 2);
-                        if (tok < a.N) a.C[tok * a.ldc + col] = a.csign * acc[m][n][r];
+                        if (tok < a.N) Cs[tok * a.ldc + col] = a.csign * acc[m][n][r];
                     }
                 }
             });
@@ -651,13 +665,56 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float* __restrict__ 
     if (threadIdx.x == 0) *out = *out + (float)red[0];
 }
 
+// split-K epilogue: Y[i] = round(sum_s part[s][i] (+ bias[i % R])), slices in ascending order; thread = 8 consecutive outputs
+template <int DT>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, int SK, int64_t NR, int64_t R,
+                                                       const char* __restrict__ bias, char* __restrict__ Y) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= NR) return;
+    float v[8];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(part + i0), a1 = *reinterpret_cast<const float4*>(part + i0 + 4);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    }
+    for (int s = 1; s < SK; ++s) {
+        const float* p = part + (int64_t)s * NR + i0;
+        const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    }
+    uint16_t o[8];
+    const int64_t c0 = i0 % R;      // R % 8 == 0: the 8 outputs lie in one row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float y = v[j] + (bias ? load_as_f32(bias, c0 + j, DT) : 0.0f);
+        o[j] = DT == LLMC_BF16 ? f32_to_bf16_bits(y) : f32_to_f16_bits(y);
+    }
+    uint4 ov;
+    __builtin_memcpy(&ov, o, 16);
+    *reinterpret_cast<uint4*>(Y + i0 * 2) = ov;
+}
+
+// How many k-slices a mode-0 product of this shape is cut into so that tiles x slices fills the persistent grid (an
+// evaluation forward of 2048 tokens through a 4096-wide layer is 128 tiles of 256 x 256 for 256 CUs): 1 = no split.
+static int lin_ksplit(int64_t N, int64_t K, int64_t R, int grid) {
+    const int64_t tiles = ceil_div64(N, LT) * ceil_div64(R, LT);
+    if (tiles * 4 >= (int64_t)grid * 3 || R % 8 != 0) return 1;       // >= 3/4 of the CUs busy already
+    int sk = (int)(grid / tiles);
+    const int by_k = (int)(K / 512);                                   // at least 4 ring turns per slice
+    if (sk > by_k) sk = by_k;
+    if (sk > 8) sk = 8;
+    return sk < 2 ? 1 : sk;
+}
+
 }  // namespace llmc
 
 using namespace llmc;
 
 extern "C" size_t llmc_linear_eval_ws_bytes(int64_t N, int64_t K, int64_t R) {
     if (N <= 0 || R <= 0) return 0;
-    return (size_t)(ceil_div64(N, LT) * ceil_div64(R, LT)) * sizeof(float);
+    const size_t loss = (size_t)(ceil_div64(N, LT) * ceil_div64(R, LT)) * sizeof(float);
+    const int sk = K > 0 && K % (L4_KS * L4_RING) == 0 ? lin_ksplit(N, K, R, 256) : 1;   // mode 0 of llmc_linear_eval_kt: fp32 slices
+    const size_t split = sk > 1 ? (size_t)sk * N * R * sizeof(float) : 0;
+    return loss > split ? loss : split;
 }
 
 extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N, int64_t K, int64_t R, int mode,
@@ -678,7 +735,7 @@ extern "C" int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N
     lin_tile_order(a, 256);
     a.y0_lds = 0;
     a.yblk = 0;
-    a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr;
+    a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr; a.ksplit = 1; a.ntm_real = a.ntm;
     if (dt == LLMC_BF16) {
         if (int rc = ensure_dynamic_lds((const void*)k_linear_eval<LLMC_BF16>, LLDS + 64)) return rc;
         hipLaunchKernelGGL((k_linear_eval<LLMC_BF16>), dim3(256), dim3(LTHREADS), LLDS + 64, st, a);
@@ -737,9 +794,16 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     a.ntm = (int)ceil_div64(N, LT); a.ntn = (int)ceil_div64(R, LT);
     const int grid = device_cu_count() & ~7;
     LLMC_REQUIRE(grid >= 8, "linear_eval_kt: device has fewer than 8 compute units");
-    lin_tile_order(a, grid);
     a.yblk = yblk;
-    a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr;
+    a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr; a.ksplit = 1; a.ntm_real = a.ntm;
+    // split-K for products that leave CUs idle (mode 0, row-major output, workspace given): fp32 slices into ws, then one
+    // reduction + rounding pass. LLMC_LINEAR_NOSPLIT=1 keeps the single-pass form (tests compare the two).
+    const int sk = (mode == 0 && !yblk && ws && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)Yout & 15) == 0 && !getenv("LLMC_LINEAR_NOSPLIT"))
+                       ? lin_ksplit(N, K, R, 256) : 1;
+    if (sk > 1) {
+        a.mode = 3; a.C = (float*)ws; a.ldc = R; a.ksplit = sk; a.ntm = a.ntm_real * sk;
+    }
+    lin_tile_order(a, grid);
     a.y0_lds = mode == 1 && !yblk && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
     int stage = mode == 1 ? (yblk ? 2 : a.y0_lds ? 1 : 0) : 0;
 #ifdef LLMC_LAB   // lab builds only (tools/probes): wrong losses by design, never compiled into the shipped library
@@ -757,6 +821,13 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     if (int rc = ensure_dynamic_lds(fn, L4_LDS + 64)) return rc;
     void* kargs[] = {(void*)&a};
     LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(L4_THREADS), kargs, (size_t)(L4_LDS + 64), st));
+    if (sk > 1) {
+        const int64_t NR = N * R;
+        const unsigned blocks = (unsigned)ceil_div64(NR, 256 * 8);
+        if (bf) hipLaunchKernelGGL((k_splitk_reduce<LLMC_BF16>), dim3(blocks), dim3(256), 0, st, (const float*)ws, sk, NR, R, (const char*)Y0, (char*)Yout);
+        else hipLaunchKernelGGL((k_splitk_reduce<LLMC_F16>), dim3(blocks), dim3(256), 0, st, (const float*)ws, sk, NR, R, (const char*)Y0, (char*)Yout);
+        LLMC_LAUNCH_CHECK();
+    }
     if (mode == 1) {
         hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, (const float*)ws, a.ntm * a.ntn, loss_sum);
         LLMC_LAUNCH_CHECK();
@@ -867,6 +938,7 @@ int gemm6_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float
     a.yblk = 0; a.y0_lds = 0;
     a.C = C; a.ldc = ldc; a.csign = sign; a.krange = a_upper ? 1 : b_upper ? 2 : 0; a.kunit = 6;
     a.queue = (unsigned*)((char*)Bp + g6_align((size_t)6 * Kd * N * 2));
+    a.ksplit = 1; a.ntm_real = a.ntm;
     LLMC_HIP_CHECK(hipMemsetAsync(a.queue, 0, 4, st));
     const void* fn = (const void*)k_linear_eval4<LLMC_BF16, 0>;
     if (int rc = ensure_dynamic_lds(fn, L4_LDS + 64)) return rc;

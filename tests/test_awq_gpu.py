@@ -393,7 +393,6 @@ def test_fake_quant_linear_forward_runs_on_the_hip_gemm(dt, bias, monkeypatch):
     q = make_q(True, 128)
     w_qdq = lambda m: q.fake_quant_weight_dynamic(m.weight.data)  # noqa: E731
     x = torch.randn(3, 100, K, generator=gen).to(TD[dt]).cuda()
-    monkeypatch.setenv('LLMC_LINEAR_SMALL', 'hip')          # this test is about the HIP kernels: keep small shapes on them
     calls = []
     orig = awq_ops.linear_out
     monkeypatch.setattr(awq_ops, 'linear_out', lambda *a, **k: calls.append(1) or orig(*a, **k))
@@ -457,31 +456,41 @@ def test_search_with_two_near_equal_minima_picks_the_reference_grid_point():
     assert n in (int(np.argsort(ref)[0]), int(np.argsort(ref)[1]))
 
 
-def test_small_fake_quant_forward_goes_to_the_framework_gemm_and_says_so(monkeypatch, capfd):
-    """VERDICT r03 hygiene: an output of fewer than 192 tiles (an evaluation forward) is routed to F.linear explicitly, with
-    one log line per shape; a large one stays on the HIP GEMM; both agree with fp32 to an ulp."""
-    from llmc_amd.compression.quantization import awq_ops, module_utils
-    from llmc_amd.compression.quantization.module_utils import EffcientFakeQuantLinear
-    monkeypatch.delenv('LLMC_LINEAR_SMALL', raising=False)
-    module_utils._SMALL_SEEN.clear()
+def test_small_fake_quant_forward_stays_on_the_hip_gemm_in_k_slices(monkeypatch, capfd):
+    """Round 5: an output of fewer 256 x 256 tiles than CUs (an evaluation forward) is no longer handed to the
+    vendor GEMM: the k-tiled kernel cuts it into k-slices (fp32 partials, one reduction + rounding pass). No fallback line on
+    stderr, the HIP entry point is what runs, the result equals the unsplit kernel's to an ulp and fp32 to an ulp."""
+    from llmc_amd.compression.quantization import awq_ops
+    from llmc_amd.compression.quantization.module_utils import EffcientFakeQuantLinear, OriginFloatLinear
     gen = torch.Generator().manual_seed(6)
-    lin = torch.nn.Linear(1024, 1024, bias=False).to(torch.bfloat16).cuda()
-    lin.weight.data = (torch.randn(1024, 1024, generator=gen) * 0.05).to(torch.bfloat16).cuda()
-    m = EffcientFakeQuantLinear.new(lin, lambda mod: mod.weight.data, None)
-    calls = []
-    orig = awq_ops.linear_out
-    monkeypatch.setattr(awq_ops, 'linear_out', lambda *a, **k: calls.append(1) or orig(*a, **k))
-    xs = torch.randn(2, 64, 1024, generator=gen).to(torch.bfloat16).cuda()          # 1 x 4 tiles
-    xl = torch.randn(64, 256, 1024, generator=gen).to(torch.bfloat16).cuda()        # 64 x 4 = 256 tiles
-    ys, _ = m(xs), m(xs)
-    assert calls == []
+    for (K, R, bias, shapes) in ((1024, 1024, False, [(2, 64), (1, 2048), (64, 256)]), (4096, 4096, True, [(1, 2048), (3, 100)]),
+                                 (2048, 520, True, [(1, 777)])):
+        lin = torch.nn.Linear(K, R, bias=bias).to(torch.bfloat16).cuda()
+        lin.weight.data = (torch.randn(R, K, generator=gen) * 0.05).to(torch.bfloat16).cuda()
+        if bias:
+            lin.bias.data = torch.randn(R, generator=gen).to(torch.bfloat16).cuda()
+        m = EffcientFakeQuantLinear.new(lin, lambda mod: mod.weight.data, None)
+        mo = OriginFloatLinear.new(lin)
+        calls = []
+        orig = awq_ops.linear_out
+        monkeypatch.setattr(awq_ops, 'linear_out', lambda *a, **k: calls.append(1) or orig(*a, **k))
+        for shp in shapes:
+            x = torch.randn(*shp, K, generator=gen).to(torch.bfloat16).cuda()
+            monkeypatch.delenv('LLMC_LINEAR_NOSPLIT', raising=False)
+            n0 = len(calls)
+            y = m(x)
+            yo = mo(x)
+            assert len(calls) == n0 + 2                      # both wrappers ran the HIP GEMM
+            monkeypatch.setenv('LLMC_LINEAR_NOSPLIT', '1')
+            y1 = m(x)
+            ref = x.float() @ lin.weight.data.float().T + (lin.bias.data.float() if bias else 0.0)
+            assert y.shape == (*shp, R) and y.dtype == torch.bfloat16 and torch.equal(y, yo)
+            for v in (y, y1):
+                assert ((v.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-5 * ref.abs().max()).all(), (K, R, shp)
+            assert (ulps(host(y), host(y1), 'bf16') > 1).mean() < 1e-3, (K, R, shp)      # k-slices only reorder the fp32 sum
+        monkeypatch.setattr(awq_ops, 'linear_out', orig)
     err = capfd.readouterr().err
-    assert err.count('torch.nn.functional.linear') == 1 and 'LLMC_LINEAR_SMALL' in err
-    yl = m(xl)
-    assert len(calls) == 1
-    for x, y in ((xs, ys), (xl, yl)):
-        ref = (x.float() @ lin.weight.data.float().T)
-        assert ((y.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-5 * ref.abs().max()).all()
+    assert 'functional.linear' not in err
 
 
 def _make_quantizer(cfg):

@@ -3,8 +3,10 @@ pass (profile the vendor kernel that sustains 0.61-0.64 of peak 
     python tools/probes/vendor_gemm_pmc.py            # timings only
     rocprofv3 --kernel-trace --pmc ... -- python tools/probes/vendor_gemm_pmc.py --pmc   # few launches, long enough to reach the sustained clock
 """
+import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from llmc_amd.compression.quantization import awq_ops

@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--step', type=int, default=-1)
     ap.add_argument('--full', action='store_true')
     ap.add_argument('--gap-us', type=float, default=20.0)
+    ap.add_argument('--syrk-per-step', type=int, default=0, help='a step = this many k_syrk4 launches (orders that interleave Hessians and chains)')
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.csv)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -65,6 +66,8 @@ def main():
     for p, q in zip(syrk, syrk[1:]):
         if q - p > 60:
             starts.append(q)
+    if a.syrk_per_step:
+        starts = syrk[0::a.syrk_per_step]
     if not starts:
         raise SystemExit('no k_syrk4 dispatch in the trace')
     si = a.step if a.step >= 0 else len(starts) + a.step
