@@ -228,6 +228,14 @@ int llmc_gather_cols(const float* in, int64_t R, int64_t K, const int64_t* idx, 
  * i+1 if the leading minor i is not positive definite. */
 size_t llmc_chol_inv_upper_ws_bytes(int64_t K);
 int llmc_chol_inv_upper(float* A, int64_t K, void* ws, int32_t* info_dev, llmc_stream_t stream);
+/* The two calls above without the transposing pass between them (K^2 floats read + written; 0.5 ms at K = 14336):
+ * llmc_hessian_prep_rev writes Hout index-reversed (Hout[i][j] = Hp[K-1-i][K-1-j]: the same gather with the permutation read
+ * backwards; workspace llmc_hessian_prep_ws_bytes), which for a symmetric H is Hp reflected across its anti-diagonal — the
+ * matrix llmc_chol_inv_upper builds first. llmc_chol_inv_upper_rev factors it in place (Arev is destroyed) and writes U to
+ * Uout (a separate buffer; workspace llmc_chol_inv_upper_ws_bytes). U is bit-identical to the two-call form. */
+int llmc_hessian_prep_rev(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
+                          float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream);
+int llmc_chol_inv_upper_rev(float* Arev, float* Uout, int64_t K, void* ws, int32_t* info_dev, llmc_stream_t stream);
 
 /* GPTQ.weight_transform (gptq.py:199-244), the blocked column loop, with the quantizer of
  * search_column_qparams (gptq.py:359-366) fused at group starts.

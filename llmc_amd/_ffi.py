@@ -53,6 +53,8 @@ SIGNATURES = {
     'llmc_hessian_prep': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
     'llmc_chol_inv_upper_ws_bytes': (_sz, [_i64]),
     'llmc_chol_inv_upper': (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    'llmc_hessian_prep_rev': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
+    'llmc_chol_inv_upper_rev': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     'llmc_gptq_quantize_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_gptq_quantize': (_i32, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                   _i32, _vp, _vp]),

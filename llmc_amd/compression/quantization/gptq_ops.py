@@ -4,9 +4,11 @@ import torch
 from llmc_amd import _ffi
 
 
-def hessian_prep(H, W, perm, percdamp, want_h=True, h_out=None):
+def hessian_prep(H, W, perm, percdamp, want_h=True, h_out=None, reverse_h=False):
     """gptq.py:135-152,169-171. H [K,K] fp32 (dead diagonal fixed in place), W [R,K] any float dtype or None.
-    Returns (Hout fp32 [K,K] permuted + damped | None, Wout fp32 [R,K] permuted, dead columns zeroed | None)."""
+    Returns (Hout fp32 [K,K] permuted + damped | None, Wout fp32 [R,K] permuted, dead columns zeroed | None).
+    reverse_h: Hout is written index-reversed (llmc_hessian_prep_rev) for chol_inv_upper_rev, which then needs no
+    transposing pass in front of the factorisation."""
     _ffi.require_gpu(H, W, perm)
     L = _ffi.lib()
     K = H.shape[0]
@@ -22,9 +24,10 @@ def hessian_prep(H, W, perm, percdamp, want_h=True, h_out=None):
     ws = _ffi.workspace(L.llmc_hessian_prep_ws_bytes(K), H.device)
     if perm is not None:
         perm = perm.to(torch.int64).contiguous()
-    _ffi.check(L.llmc_hessian_prep(_ffi.ptr(H), _ffi.ptr(W), _ffi.dt(W) if W is not None else 2, R, K,
-                                   _ffi.ptr(perm), float(percdamp), _ffi.ptr(Hout), _ffi.ptr(Wout), _ffi.ptr(ws),
-                                   _ffi.stream()), 'llmc_hessian_prep')
+    fn = L.llmc_hessian_prep_rev if reverse_h else L.llmc_hessian_prep
+    _ffi.check(fn(_ffi.ptr(H), _ffi.ptr(W), _ffi.dt(W) if W is not None else 2, R, K,
+                  _ffi.ptr(perm), float(percdamp), _ffi.ptr(Hout), _ffi.ptr(Wout), _ffi.ptr(ws),
+                  _ffi.stream()), 'llmc_hessian_prep')
     return Hout, Wout
 
 
@@ -70,6 +73,32 @@ def chol_inv_upper(H, check=True, return_info=False):
         if i != 0:
             raise RuntimeError(f'chol_inv_upper: matrix is not positive definite (leading minor {i})')
     return (H, info) if return_info else H
+
+
+def chol_inv_upper_rev(Hrev, check=True, return_info=False):
+    """chol_inv_upper for the index-reversed matrix of hessian_prep(..., reverse_h=True): Hrev is factored in place (destroyed),
+    U comes back in a new tensor — bit-identical to chol_inv_upper on the un-reversed matrix, one K^2 pass less."""
+    _ffi.require_gpu(Hrev)
+    L = _ffi.lib()
+    K = Hrev.shape[0]
+    need = L.llmc_chol_inv_upper_ws_bytes(K)
+    key = (Hrev.device, _ffi.stream())
+    ws = _chol_ws.get(key)
+    if ws is None or ws.numel() < need + 256:
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=Hrev.device)
+        _chol_ws[key] = ws
+    off = (-ws.data_ptr()) % 256
+    info = torch.zeros(1, dtype=torch.int32, device=Hrev.device)
+    # U lives in the (otherwise unused) work-matrix region of the per-stream workspace: valid until the next factorisation
+    # on this stream, which is stream-ordered behind every kernel that reads it
+    U = ws[off:off + K * K * 4].view(torch.float32).view(K, K)
+    _ffi.check(L.llmc_chol_inv_upper_rev(_ffi.ptr(Hrev), _ffi.ptr(U), K, ws.data_ptr() + off, _ffi.ptr(info), _ffi.stream()),
+               'llmc_chol_inv_upper_rev')
+    if check:
+        i = int(info.item())
+        if i != 0:
+            raise RuntimeError(f'chol_inv_upper: matrix is not positive definite (leading minor {i})')
+    return (U, info) if return_info else U
 
 
 def raise_if_not_pd(info, what='Hessian'):

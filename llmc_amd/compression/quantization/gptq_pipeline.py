@@ -53,6 +53,22 @@ def factor_from_hessian(H, cfg, h_work=None):
     return perm, U
 
 
+def _prep_and_factor(H, W, perm, percdamp, h_work):
+    """process_hessian_and_weights (gptq.py:128-176): dead fix, gather, damping, then U with H^-1 = U^T U. Round 5: the
+    permuted matrix is gathered index-reversed (the same gather, the permutation read backwards) so that the factorisation
+    starts from it directly — one pass over K^2 floats less on the chain of every subset (0.5 ms at K = 14336), same bits.
+    The factor then lives in the calling stream's factorisation workspace: valid until that stream's next factorisation.
+    LLMC_K3_FUSED_PREP=0 keeps the two separate entry points."""
+    import os
+    if os.environ.get('LLMC_K3_FUSED_PREP', '1') != '0':
+        Hrev, Wp = gptq_ops.hessian_prep(H, W, perm, percdamp, want_h=True, h_out=h_work, reverse_h=True)
+        U, info = gptq_ops.chol_inv_upper_rev(Hrev, check=False, return_info=True)
+        return U, Wp, info
+    Hp, Wp = gptq_ops.hessian_prep(H, W, perm, percdamp, want_h=True, h_out=h_work)
+    U, info = gptq_ops.chol_inv_upper(Hp, check=False, return_info=True)
+    return U, Wp, info
+
+
 def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_losses=True, rows=None):
     """W_list: weights [R_i, K] (model dtype or fp32) of layers sharing the input whose Hessian is H.
     static_qparams: list of (scales [R_i, ng], zeros [R_i, ng] | None) in ORIGINAL column order, required
@@ -76,8 +92,7 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
     perm = None
     if cfg.actorder:
         perm = torch.argsort(torch.diagonal(H), descending=True)
-    Hp, Wp = gptq_ops.hessian_prep(H, Wcat, perm, cfg.percdamp, want_h=True, h_out=h_work)
-    U, info = gptq_ops.chol_inv_upper(Hp, check=False, return_info=True)   # callers check `info` at their next sync
+    U, Wp, info = _prep_and_factor(H, Wcat, perm, cfg.percdamp, h_work)   # callers check `info` at their next sync
     qmin, qmax = cfg.qrange
     static_mode = cfg.static_groups or not cfg.group_size
     scales = zeros = col_group = None
@@ -124,8 +139,7 @@ def quantize_owq(W, H, cfg, n_out, wquantizer, rtn_scales=None, rtn_zeros=None, 
     K = H.shape[0]
     n_nonout = K - int(n_out)
     perm = owq_permutation(torch.diagonal(H), int(n_out))
-    Hp, Wp = gptq_ops.hessian_prep(H, W, perm, cfg.percdamp, want_h=True, h_out=h_work)
-    U, info = gptq_ops.chol_inv_upper(Hp, check=False, return_info=True)
+    U, Wp, info = _prep_and_factor(H, W, perm, cfg.percdamp, h_work)
     qmin, qmax = cfg.qrange
     R = Wp.shape[0]
     if cfg.group_size:

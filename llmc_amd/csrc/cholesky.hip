@@ -543,11 +543,36 @@ extern "C" int llmc_gather_cols(const float* in, int64_t R, int64_t K, const int
 
 extern "C" size_t llmc_hessian_prep_ws_bytes(int64_t K) {
     if (K <= 0) return 0;
-    return (size_t)(((K + 63) / 64) * 64 + 64);
+    // mean + dead flags, then (16-B aligned) the reversed permutation of llmc_hessian_prep_rev
+    return (size_t)(((K + 63) / 64) * 64 + 64) + (size_t)K * 8;
 }
+
+namespace llmc {
+__global__ __launch_bounds__(256) void k_reverse_perm(const int64_t* __restrict__ perm, int K, int64_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K) out[i] = perm ? perm[K - 1 - i] : (int64_t)(K - 1 - i);
+}
+}  // namespace llmc
+
+static int hessian_prep_impl(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm, float percdamp,
+                             float* Hout, float* Wout, void* ws, llmc_stream_t stream, bool rev);
 
 extern "C" int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
                                  float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream) {
+    return hessian_prep_impl(H, W, wdt, R, K, perm, percdamp, Hout, Wout, ws, stream, false);
+}
+
+// The same preparation with Hout written index-REVERSED: Hout[i][j] = Hp[K-1-i][K-1-j] (Hp = the permuted, damped matrix
+// llmc_hessian_prep writes). For a symmetric H that is Hp reflected across its anti-diagonal — exactly the matrix
+// llmc_chol_inv_upper builds first from Hp with a transposing pass over K^2 floats — at no cost: it is the same gather with
+// the permutation read backwards. llmc_chol_inv_upper_rev takes it. W is gathered with `perm` as always.
+extern "C" int llmc_hessian_prep_rev(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm,
+                                     float percdamp, float* Hout, float* Wout, void* ws, llmc_stream_t stream) {
+    return hessian_prep_impl(H, W, wdt, R, K, perm, percdamp, Hout, Wout, ws, stream, true);
+}
+
+static int hessian_prep_impl(float* H, const void* W, int wdt, int64_t R, int64_t K, const int64_t* perm, float percdamp,
+                             float* Hout, float* Wout, void* ws, llmc_stream_t stream, bool rev) {
     LLMC_REQUIRE(H && ws && K > 0, "hessian_prep: null/empty argument");
     LLMC_REQUIRE((W && Wout && R > 0) || (!W && !Wout), "hessian_prep: W and Wout go together");
     LLMC_REQUIRE(dtype_ok(wdt), "hessian_prep: bad dtype");
@@ -560,11 +585,18 @@ extern "C" int llmc_hessian_prep(float* H, const void* W, int wdt, int64_t R, in
     LLMC_LAUNCH_CHECK();
     int gx = (int)ceil_div64(K, 256 * 4);
     if (Hout) {
+        const int64_t* hperm = perm;
+        if (rev) {     // the permutation read backwards (identity: K-1 .. 0): Hout comes out reflected across the anti-diagonal
+            int64_t* pr = (int64_t*)((char*)ws + (((K + 63) / 64) * 64 + 64));
+            hipLaunchKernelGGL(k_reverse_perm, dim3((unsigned)ceil_div64(K, 256)), dim3(256), 0, st, perm, (int)K, pr);
+            LLMC_LAUNCH_CHECK();
+            hperm = pr;
+        }
         if (gather_lds_ok(K, H, Hout, 4)) {
-            int rc = gather_lds_launch<float, 2>(H, K, K, perm, nullptr, percdamp, diag_mean, Hout, st);
+            int rc = gather_lds_launch<float, 2>(H, K, K, hperm, nullptr, percdamp, diag_mean, Hout, st);
             if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(k_gather_h, dim3(gx, (unsigned)K), dim3(256), 0, st, (const float*)H, (int)K, perm,
+            hipLaunchKernelGGL(k_gather_h, dim3(gx, (unsigned)K), dim3(256), 0, st, (const float*)H, (int)K, hperm,
                                percdamp, (const float*)diag_mean, Hout);
             LLMC_LAUNCH_CHECK();
         }
@@ -617,13 +649,29 @@ extern "C" size_t llmc_chol_inv_upper_ws_bytes(int64_t K) {
     return work + vbuf + xbuf + gemm6_bytes(K);
 }
 
+static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream);
+
 extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
+    return chol_inv_upper_impl(A, nullptr, K64, ws, info_dev, stream);
+}
+
+// The same factor from the index-reversed matrix llmc_hessian_prep_rev writes: Arev is factored IN PLACE (destroyed) and U is
+// written to Uout (must not alias Arev): no transposing pass in front of the factorisation. Same workspace size as
+// llmc_chol_inv_upper; same kernels in the same order on the same values: U is bit-identical to llmc_chol_inv_upper's on the
+// un-reversed matrix whenever that matrix is exactly symmetric (every Hessian of this library is).
+extern "C" int llmc_chol_inv_upper_rev(float* Arev, float* Uout, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
+    LLMC_REQUIRE(Uout && Uout != Arev && ((uintptr_t)Uout & 15) == 0, "chol_inv_upper_rev: Uout must be a separate 16-B aligned buffer");
+    return chol_inv_upper_impl(Arev, Uout, K64, ws, info_dev, stream);
+}
+
+static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int32_t* info_dev, llmc_stream_t stream) {
     LLMC_REQUIRE(A && ws && info_dev && K64 > 0, "chol_inv_upper: null/empty argument");
     LLMC_REQUIRE(K64 % 4 == 0 && K64 < (1 << 30), "chol_inv_upper: K must be a multiple of 4");
     LLMC_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)ws & 255) == 0, "chol_inv_upper: alignment");
     hipStream_t st = (hipStream_t)stream;
     const int K = (int)K64;
-    float* Wk = (float*)ws;
+    const bool rev = Uout != nullptr;          // A already holds the reflected matrix: work in it
+    float* Wk = rev ? A : (float*)ws;
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
     void* G6buf = (char*)Xbuf + align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
@@ -632,8 +680,10 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
     if (int rc = ensure_dynamic_lds((const void*)k_potrf_inv, (NB * PLD + 32 * PLD + 64) * (int)sizeof(float))) return rc;
 
     dim3 tgrid((K + 31) / 32, (K + 31) / 32);
-    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
-    LLMC_LAUNCH_CHECK();
+    if (!rev) {
+        hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)A, Wk, K, 0);
+        LLMC_LAUNCH_CHECK();
+    }
 
     const int nblk = (K + NB - 1) / NB;
     // ---- blocked upper Cholesky Wk = U'^T U', two-level: 128-wide factor steps inside 512-wide outer blocks.
@@ -804,7 +854,7 @@ extern "C" int llmc_chol_inv_upper(float* A, int64_t K64, void* ws, int32_t* inf
         rc = lvl_x3 ? gemm3_launch(y, false, st) : sgemm_launch(y, false, false, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, A, K, 1);
+    hipLaunchKernelGGL(k_antitranspose, tgrid, dim3(256), 0, st, (const float*)Wk, rev ? Uout : A, K, 1);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }

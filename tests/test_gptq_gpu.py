@@ -556,3 +556,86 @@ def test_pipelined_owq_column_loop_is_bit_identical_to_the_single_stream_schedul
     for _ in range(4):
         for a, b in zip(ref, run()):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('K', [1536, 4096, 5248])
+@pytest.mark.parametrize('with_perm', [True, False])
+def test_reversed_prep_and_in_place_factor_give_the_same_bits(K, with_perm):
+    """llmc_hessian_prep_rev + llmc_chol_inv_upper_rev (round 5: the permuted Hessian is gathered index-reversed, the
+    factorisation starts from it in place, one K^2 pass less) against llmc_hessian_prep + llmc_chol_inv_upper: the same U bit
+    for bit, the same gathered weights, the same failure flag; and quantize_stacked gives the same layer either way."""
+    import os
+    from llmc_amd.compression.quantization import gptq_ops
+    from llmc_amd.compression.quantization.gptq_pipeline import GptqConfig, quantize_stacked
+    gen = torch.Generator(device='cuda').manual_seed(K + int(with_perm))
+    X = torch.randn(2 * K, K, generator=gen, device='cuda') * torch.exp(0.5 * torch.randn(K, generator=gen, device='cuda'))
+    H = (X.T @ X) / K
+    H = torch.triu(H) + torch.triu(H, 1).T          # exactly symmetric, like every accumulated Hessian
+    H[:, 7] = 0.0
+    H[7, :] = 0.0                                   # a dead channel
+    del X
+    W = (torch.randn(320, K, generator=gen, device='cuda') * 0.02).to(torch.bfloat16)
+    perm = torch.argsort(torch.diagonal(H), descending=True) if with_perm else None
+    Hp, Wp = gptq_ops.hessian_prep(H.clone(), W, perm, 0.01)
+    U0, i0 = gptq_ops.chol_inv_upper(Hp, check=False, return_info=True)
+    U0 = U0.clone()
+    Hr, Wr = gptq_ops.hessian_prep(H.clone(), W, perm, 0.01, reverse_h=True)
+    assert torch.equal(Wp, Wr)
+    assert torch.equal(Hr, torch.flip(gptq_ops.hessian_prep(H.clone(), None, perm, 0.01)[0], (0, 1)))
+    U1, i1 = gptq_ops.chol_inv_upper_rev(Hr, check=False, return_info=True)
+    assert int(i0.item()) == 0 and int(i1.item()) == 0
+    assert torch.equal(U0, U1)
+    cfg = GptqConfig(bit=4, symmetric=False, group_size=128, actorder=with_perm, static_groups=False)
+    outs = []
+    for flag in ('0', '1'):
+        os.environ['LLMC_K3_FUSED_PREP'] = flag
+        try:
+            r = quantize_stacked([W], H.clone(), cfg)[0]
+        finally:
+            os.environ.pop('LLMC_K3_FUSED_PREP', None)
+        outs.append((r.weight.clone(), r.scales.clone(), r.zeros.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    Hbad = H.clone()
+    Hbad[K // 2, K // 2] = -5.0
+    Hr, _ = gptq_ops.hessian_prep(Hbad, None, perm, 0.0, reverse_h=True)
+    _, info = gptq_ops.chol_inv_upper_rev(Hr, check=False, return_info=True)
+    assert int(info.item()) != 0
+
+
+@pytest.mark.parametrize('shape', [(256, 256, 64), (768, 1024, 512), (1000, 776, 512), (2048, 2048, 128), (3072, 3072, 512)])
+def test_gemm3w_one_wave_per_simd_kernel_is_bit_identical_to_k_gemm3(shape, monkeypatch):
+    """k_gemm3w (256 x 256 tiles, one wave per SIMD, K-step 16, planes double-buffered) takes the far trailing updates of K3
+    (TA, SG_SUB, Kd % 32 == 0): per accumulator the same six products in the same order per 16 k as k_gemm3 -> same bits,
+    ragged edges and the upper-tiles-only mode included."""
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M + N + Kd)
+    A = (torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    B = (torch.randn(Kd, N, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    C0 = torch.randn(M, N, generator=gen).cuda()
+    for hints in ((0, 0, 0), (0, 0, 1)):
+        if hints[2] and M != N:
+            continue
+        monkeypatch.setenv('LLMC_GEMM3_V1', '1')
+        ref = gemm3(A, B, C0.clone(), M, N, Kd, True, 0, hints)
+        monkeypatch.delenv('LLMC_GEMM3_V1')
+        out = gemm3(A, B, C0.clone(), M, N, Kd, True, 0, hints)
+        if hints[2]:        # tiles strictly below the diagonal are skipped at the kernels' own tile sizes: compare the upper part
+            assert torch.equal(torch.triu(ref), torch.triu(out)), shape
+        else:
+            assert torch.equal(ref, out), shape
+    # in place on one matrix, the way the factorisation calls it: C -= P^T P with P a row block above C
+    K = 1536
+    W = torch.randn(K, K, generator=gen).cuda()
+    outs = []
+    for v1 in (True, False):
+        if v1:
+            monkeypatch.setenv('LLMC_GEMM3_V1', '1')
+        else:
+            monkeypatch.delenv('LLMC_GEMM3_V1', raising=False)
+        Wc = W.clone()
+        P = Wc[:512, 512:]
+        Cw = Wc[512:, 512:]
+        gemm3(P, P, Cw, 1024, 1024, 512, True, 0, (0, 0, 1))
+        outs.append(torch.triu(Wc[512:, 512:]).clone())
+    assert torch.equal(outs[0], outs[1])
