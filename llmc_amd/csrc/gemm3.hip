@@ -13,8 +13,6 @@
 // P in `T -= P^T P`. A workgroup owns a 128x128 tile; per K-step of 32 it stages both 32x128 panels through
 // registers (split there) into three bf16 planes each, k-major in LDS exactly like hessian_syrk.hip's token-major
 // panels (64-B units XOR-swizzled by k & 3), and feeds the MFMAs with ds_read_b64_tr_b16 transposing reads.
-#include <stdlib.h>
-#include <type_traits>
 #include "sgemm.h"
 #include "mfma_common.h"
 
@@ -224,206 +222,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(SgemmArgs a) {
         }
 }
 
-
-// -----------------------------------------------------------------------------------------------------------------
-// k_gemm3w (round 5) — the same product for the shape that carries K3's flops, the far trailing update T -= P^T P
-// (TA, batch 1, SG_SUB, Kd % 16 == 0, no triangular k hints), with hessian_syrk.hip's one-wave-per-SIMD structure:
-//   * workgroup tile 256 x 256, 4 waves as 2 x 2, each wave 128 x 128 = 4 x 4 accumulators (256 accumulator registers):
-//     24 fragment reads feed 96 MFMAs per 16-k slice (0.25 per MFMA; k_gemm3's 64 x 64 wave tiles read 0.5 per MFMA, which at
-//     two workgroups per CU is the whole LDS bandwidth) and an operand element is fetched and split once per 256 output
-//     columns instead of once per 128;
-//   * K-step 16, the three bf16 planes of both operands double-buffered in LDS (2 x 48 KiB), ONE barrier per step: the fp32
-//     rows of step s + 1 are split and written to the other buffer, and the rows of step s + 3 requested (two register sets:
-//     a load has two whole steps to land), in slices placed between the MFMAs of step s — with one wave per SIMD nothing else
-//     hides them;
-//   * per accumulator the same six products in the same order per 16 k as k_gemm3: bit-identical results.
-// -----------------------------------------------------------------------------------------------------------------
-static constexpr int GW = 256;                 // tile edge
-static constexpr int GWK = 16;                 // K-step
-static constexpr int GWROW = GW * 2;           // bytes per k-row of one plane
-static constexpr int GWPLANE = GWK * GWROW;    // 8 KiB
-static constexpr int GWOPER = 3 * GWPLANE;     // hi | mid | lo of one operand: 24 KiB
-static constexpr int GWSTAGE = 2 * GWOPER;     // A | B: 48 KiB
-static constexpr int GWLDS = 2 * GWSTAGE;      // 96 KiB
-
-template <int I, int N, typename F> __device__ __forceinline__ void gw_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        gw_for<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ s16x8 tr_frag512(LDS_AS char* p, int imm0) {
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p + imm0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p + imm0 + 4 * GWROW));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// 4 fp32 -> three packed-bf16 quadruples into the three planes of one operand
-__device__ __forceinline__ void split_store_w(float4 v, LDS_AS char* plane0, int off) {
-    f32x2_t a0 = {v.x, v.y}, a1 = {v.z, v.w};
-    u32x2_t out[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const bf16x2_t h0 = __builtin_convertvector(a0, bf16x2_t);
-        const bf16x2_t h1 = __builtin_convertvector(a1, bf16x2_t);
-        out[t].x = __builtin_bit_cast(uint32_t, h0);
-        out[t].y = __builtin_bit_cast(uint32_t, h1);
-        if (t < 2) {
-            a0 = a0 - __builtin_convertvector(h0, f32x2_t);
-            a1 = a1 - __builtin_convertvector(h1, f32x2_t);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) *(LDS_AS u32x2_t*)(plane0 + t * GWPLANE + off) = out[t];
-}
-
-__global__ __launch_bounds__(256) void k_gemm3w(SgemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    LDS_AS char* lds = (LDS_AS char*)smem_w;
-    const float* A = a.A;
-    const float* B = a.B;
-    float* C = a.C;
-    const int M = a.M, N = a.N, Kd = a.Kd;
-    const int i0 = blockIdx.y * GW, j0 = blockIdx.x * GW;
-    if (i0 >= M || j0 >= N) return;
-    if (a.c_upper_only && j0 + GW <= i0) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
-
-    // staging: float4 q (0..3) of a thread = k-row (tid >> 6) + 4 q, columns 4 * (tid & 63) .. + 3 of the 256-column panel
-    const int sk = tid >> 6;
-    const int sc = 4 * (tid & 63);
-    const int swr_off = ((sc >> 5) << 6) + (sc & 31) * 2;
-    // M, N are multiples of 4: a float4 is inside or outside the operand. Columns past the edge re-read the tile's first
-    // columns instead: they only feed output rows / columns that are never stored, and the loop stays free of branches
-    // (with 256 live accumulators any control flow makes hipcc move them through scratch)
-    const float* pa = A + (int64_t)sk * a.lda + i0 + (i0 + sc < M ? sc : 0);
-    const float* pb = B + (int64_t)sk * a.ldb + j0 + (j0 + sc < N ? sc : 0);
-
-    // fragment addresses (hessian_syrk.hip's transposing reads): 64-B unit = 32 columns, XOR-ed with (k & 3)
-    const int p = lane & 15;
-    const int trow = 8 * (lane >> 5) + (p >> 2);
-    const int sub = 32 * ((lane >> 4) & 1) + 8 * (p & 3);
-    int offA[4], offB[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        offA[m] = trow * GWROW + (((4 * wm + m) ^ (p >> 2)) << 6) + sub;
-        offB[m] = GWOPER + trow * GWROW + (((4 * wn + m) ^ (p >> 2)) << 6) + sub;
-    }
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-    const int ns = Kd / GWK;
-    float4 ra[2][4], rb[2][4];         // two register sets: steps s + 1 and s + 2 in flight (indices are compile-time everywhere)
-    auto gload = [&](auto setc, int st, auto qc) {
-        constexpr int set = decltype(setc)::value;
-        constexpr int q = decltype(qc)::value;
-        const int64_t ko = (int64_t)(st < ns ? st : ns - 1) * GWK;       // requests past the end re-read the last step (unused)
-        ra[set][q] = *reinterpret_cast<const float4*>(pa + (ko + 4 * q) * a.lda);
-        rb[set][q] = *reinterpret_cast<const float4*>(pb + (ko + 4 * q) * a.ldb);
-    };
-    auto sstore = [&](auto setc, auto bufc, auto qc) {
-        constexpr int set = decltype(setc)::value;
-        constexpr int buf = decltype(bufc)::value;
-        constexpr int q = decltype(qc)::value;
-        const int k = sk + 4 * q;
-        const int off = k * GWROW + (swr_off ^ ((k & 3) << 6));
-        split_store_w(ra[set][q], lds + buf * GWSTAGE, off);
-        split_store_w(rb[set][q], lds + buf * GWSTAGE + GWOPER, off);
-    };
-    constexpr std::integral_constant<int, 0> I0{};
-    constexpr std::integral_constant<int, 1> I1{};
-
-    // prologue: step 0 into buffer 0, steps 1 and 2 into the register sets
-    gw_for<0, 4>([&](auto qc) { gload(I0, 0, qc); });
-    gw_for<0, 4>([&](auto qc) { sstore(I0, I0, qc); });
-    gw_for<0, 4>([&](auto qc) { gload(I1, 1, qc); });
-    gw_for<0, 4>([&](auto qc) { gload(I0, 2, qc); });
-    __syncthreads();
-
-    // one K-step: MFMAs on buffer CUR; register set CUR ^ 1 holds step s + 1
-    auto step = [&](auto curc, int s) {
-        constexpr int CUR = decltype(curc)::value;
-        constexpr std::integral_constant<int, CUR ^ 1> OTH{};
-        // plane indices of the six products, small terms first: (A plane, B plane) with 0 hi, 1 mid, 2 lo
-        constexpr int TA_[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int TB_[6] = {0, 2, 1, 0, 1, 0};
-        LDS_AS char* base = lds + CUR * GWSTAGE;
-        s16x8 fb[4][3];
-        s16x8 fa[2][3];
-        // first operands: row block 0 of A, all of B
-#pragma unroll
-        for (int t = 0; t < 3; ++t) fa[0][t] = tr_frag512(base + t * GWPLANE + offA[0], 0);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) fb[n][t] = tr_frag512(base + t * GWPLANE + offB[n], 0);
-        gw_for<0, 4>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            constexpr int fc = m & 1;
-            // the next row block's A fragments ride behind this block's MFMAs
-            if constexpr (m < 3) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) fa[fc ^ 1][t] = tr_frag512(base + t * GWPLANE + offA[m + 1], 0);
-            }
-            gw_for<0, 6>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = Mfma<LLMC_BF16>::run(fa[fc][TA_[j]], fb[n][TB_[j]], acc[m][n]);
-                // side work of this step, one slice per four MFMAs (24 slices): the split + store of step s + 1 (even slices of
-                // row blocks 0 and 1), then the requests for step s + 3 into the register set just freed (row block 2)
-                constexpr int slice = m * 6 + j;
-                if constexpr (slice < 8 && (slice & 1) == 0) {
-                    sstore(OTH, OTH, std::integral_constant<int, slice / 2>{});      // (past the end: a buffer nobody reads)
-                } else if constexpr (slice >= 12 && slice < 16) {
-                    gload(OTH, s + 3, std::integral_constant<int, slice - 12>{});
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        __syncthreads();
-    };
-    for (int s = 0; s < ns; s += 2) {      // Kd % 32 == 0 (gemm3w_takes): steps in pairs, no branch
-        step(I0, s);
-        step(I1, s + 1);
-    }
-
-    // epilogue: C -= acc, 16 loads in flight, then 16 stores (lane = one column, 32 consecutive columns per row segment)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int col = j0 + wn * 128 + n * 32 + (lane & 31);
-            const bool colok = col < N;
-            float old[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                old[r] = (colok && row < M) ? C[(int64_t)row * a.ldc + col] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (colok && row < M) C[(int64_t)row * a.ldc + col] = old[r] - acc[m][n][r];
-            }
-        }
-}
-
-static bool gemm3w_takes(const SgemmArgs& a, bool TA) {
-    const bool off = getenv("LLMC_GEMM3_V1") != nullptr;              // A/B switch: the round-1 kernel everywhere
-    return !off && TA && a.batch == 1 && a.epilogue == SG_SUB && a.Kd % (2 * GWK) == 0 && a.Kd >= 4 * GWK && !a.a_upper && !a.a_lower &&
-           !a.b_upper && a.M >= GW && a.N >= GW;
-}
-
 int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return LLMC_OK;
     LLMC_REQUIRE(a.phase_len == 0, "gemm3: no phased mode");
@@ -432,12 +230,6 @@ int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
                      (((uintptr_t)a.B & 15) == 0) && (a.sA % 4 == 0) && (a.sB % 4 == 0),
                  "gemm3: operands must be 16-B aligned with ld and sizes multiples of 4");
     LLMC_REQUIRE((const void*)a.C != (const void*)a.B && (const void*)a.C != (const void*)a.A, "gemm3: no in-place product");
-    if (gemm3w_takes(a, TA)) {
-        if (int rc = ensure_dynamic_lds((const void*)k_gemm3w, GWLDS)) return rc;
-        hipLaunchKernelGGL(k_gemm3w, dim3((a.N + GW - 1) / GW, (a.M + GW - 1) / GW), dim3(256), GWLDS, st, a);
-        LLMC_LAUNCH_CHECK();
-        return LLMC_OK;
-    }
     dim3 grid((a.N + G3B - 1) / G3B, (a.M + G3B - 1) / G3B, a.batch);
     if (TA) hipLaunchKernelGGL((k_gemm3<true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_gemm3<false>), grid, dim3(256), 0, st, a);

