@@ -105,6 +105,9 @@ def parse_args(argv=None):
     ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
     ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
                     help='subset schedule when --overlap > 1 (see step_independent)')
+    ap.add_argument('--small-streams', type=int, default=0,
+                    help='k1first order: 0 = one stream per chain (default); n > 0 = the widest chain (largest K) alone on stream 0 and the '
+                         'other chains dealt round-robin over n further streams (1 = serialised behind each other)')
     ap.add_argument('--overlap', type=int, default=4,
                     help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); '
                          '0 = one after the other on the current stream')
@@ -792,6 +795,20 @@ def main():
                 if args.order == 'k1first':
                     for name, K, layers in groups:
                         Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
+                if args.order == 'k1first' and args.small_streams > 0:
+                    wide = max(range(len(groups)), key=lambda i: (groups[i][1], sum(r for _, r in groups[i][2])))
+                    chain(0, wide, helper=(args.helpers in ('all', 'wide')) or bool(args.wide_helper))
+                    for j, gi in enumerate([g for g in order if g != wide]):
+                        st_i = 1 + j % args.small_streams
+                        name = groups[gi][0]
+                        st = ops.stream(st_i)
+                        st.wait_stream(cur)
+                        with torch.cuda.stream(st), ops.helper_streams(args.helpers == 'all'):
+                            slot[gi] = ops.quantize(name, weights[name], Hs[name])
+                        evs.append(st)
+                    for st in set(evs):
+                        cur.wait_stream(st)
+                    return [slot[gi] for gi in range(len(groups))]
                 for si, gi in enumerate(order):
                     name, K = groups[gi][0], groups[gi][1]
                     if args.order != 'k1first':
