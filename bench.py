@@ -105,6 +105,8 @@ def parse_args(argv=None):
     ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
     ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
                     help='subset schedule when --overlap > 1 (see step_independent)')
+    ap.add_argument('--exact-diag', type=int, default=0,
+                    help='1: diag(H) re-formed in fp64 by a second pass over the samples (GPTQ special.hessian_exact_diag); off by default')
     ap.add_argument('--small-streams', type=int, default=0,
                     help='k1first order: 0 = one stream per chain (default); n > 0 = the widest chain (largest K) alone on stream 0 and the '
                          'other chains dealt round-robin over n further streams (1 = serialised behind each other)')
@@ -287,8 +289,9 @@ def cpu_baseline(model, n_seq, seq, cfg):
 class HipOps:
     """The product path: llmc_amd classes over libllmc_hip.so. Raises without an MI355X."""
 
-    def __init__(self, dev, cfg, variant):
+    def __init__(self, dev, cfg, variant, exact_diag=False):
         import torch
+        self.exact_diag = bool(exact_diag)
 
         from llmc_amd.compression.quantization import IntegerQuantizer, pack_lsb
         from llmc_amd.compression.quantization import gptq_pipeline as P
@@ -301,7 +304,7 @@ class HipOps:
 
     def acc(self, name, K):
         if name not in self.accs:
-            self.accs[name] = self.Acc(K, self.dev)
+            self.accs[name] = self.Acc(K, self.dev, exact_diag=self.exact_diag)
             self.hwork[name] = self.torch.empty((K, K), dtype=self.torch.float32, device=self.dev)
         a = self.accs[name]
         a.timing = self.timing
@@ -491,8 +494,6 @@ def run_awq(args):
             'metric': 'layers/sec (AWQ W4A16 g128 scale search + fake-quant eval, %s Linear shapes, 128x512 calib)' % args.model,
             'value': n_layers * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'ms_per_step_median': med_ms, 'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
-            'value_at_median_step': (layers_step / (med_ms * 1e-3)) if med_ms else None,      # this rank's steps; `value` is the contract's mean
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'AWQ W4A16 g128 sym, trans v2, 20-point scale search with inspect = the Linear layers, '
@@ -590,8 +591,6 @@ def run_fp8(args):
             'metric': 'layers/sec (FP8 e4m3 per-tensor weight quantization + static activation ranges, Mixtral-8x7B block shapes)',
             'value': len(layers) * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'ms_per_step_median': med_ms, 'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
-            'value_at_median_step': (layers_step / (med_ms * 1e-3)) if med_ms else None,      # this rank's steps; `value` is the contract's mean
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f8e4m3 codes from ' + args.dtype, 'data': 'synthetic',
             'config': {'workload': 'FP8 e4m3 symmetric per-tensor RTN: 28 Linear weights of one Mixtral-8x7B block (4 attention + 8 experts '
@@ -706,7 +705,7 @@ def main():
     else:
         cfg = GptqConfig(bit=4, symmetric=True, group_size=128, actorder=True, static_groups=True)
     groups = block_groups(args.model)
-    ops = DryOps(cfg) if args.dry else HipOps(dev, cfg, args.variant)
+    ops = DryOps(cfg) if args.dry else HipOps(dev, cfg, args.variant, exact_diag=bool(args.exact_diag))
     n_layers_block = sum(len(ls) for _, _, ls in groups)
     timing = []
     # payload each mode moves between ranks per step (per rank; a ring all-reduce moves 2 (N - 1) / N of its payload):
@@ -1057,6 +1056,7 @@ def main():
                 'packs_codes': args.variant == 'vllm',
                 'symmetric': cfg.symmetric, 'actorder': cfg.actorder, 'static_groups': cfg.static_groups,
                 'subset_overlap_streams': 0 if (args.dry or coop) else args.overlap,
+                'hessian_exact_diag': bool(args.exact_diag),
                 'parallelism': 'single GPU' if world == 1 else primary_parallelism,
                 'parity_envelope': parity_envelope_summary(args),
             },

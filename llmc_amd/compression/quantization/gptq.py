@@ -46,6 +46,9 @@ class GPTQ(BaseBlockwiseQuantization):
         # not a reference key: False makes the Hessian accumulators copy every hooked sample instead of keeping a
         # reference to it until the subset's single launch (hessian.py)
         self.hessian_defer = bool(special.get('hessian_defer', True))
+        # diag(H) re-formed in fp64 by a second pass over the calibration samples (hessian.py: exact_diag): the sort key of
+        # actorder with the noise of the reference's own sgemm instead of twice that; costs one more HBM pass per Hessian
+        self.hessian_exact_diag = bool(special.get('hessian_exact_diag', False))
         self.owq = bool(special.get('owq', False))
         if self.owq:                                   # gptq.py:47-50: OWQ fixes dynamic groups and no actorder
             self.n_outs = special['n_outs']
@@ -90,7 +93,8 @@ class GPTQ(BaseBlockwiseQuantization):
 
     def _new_group(self, names, K, device):
         gid = self._next_gid = getattr(self, '_next_gid', 0) + 1
-        acc = HessianAccumulator(K, device, defer=getattr(self, 'hessian_defer', True))
+        acc = HessianAccumulator(K, device, defer=getattr(self, 'hessian_defer', True),
+                                 exact_diag=getattr(self, 'hessian_exact_diag', False))
         self._groups[gid] = {'acc': acc, 'pass': None, 'passes': 0, 'members': list(names)}
         for n in names:
             self._group_of[n] = gid

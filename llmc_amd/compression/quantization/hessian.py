@@ -33,8 +33,14 @@ class HessianAccumulator:
     _global_pending = 0            # bytes of deferred references held by all accumulators
     COPY_FLUSH_TOKENS = 65536      # defer=False: private copies are flushed at this many tokens
 
-    def __init__(self, columns, device, defer=True, max_pending_tokens=None):
+    def __init__(self, columns, device, defer=True, max_pending_tokens=None, exact_diag=False):
         self.K = int(columns)
+        # exact_diag (GPTQ: special.hessian_exact_diag): diag(H) re-formed in fp64 by a second pass over the samples
+        # (llmc_hessian_diag_accum_ptrs): the MFMA kernel's fp32 accumulation leaves 2-3e-6 of relative noise there, twice the
+        # reference's sgemm, and diag(H) is what actorder sorts. One more HBM pass (2 T K bytes): off by default.
+        self.exact_diag = bool(exact_diag) and self.K % 8 == 0
+        self._diag64 = None
+        self._diag_ws = None
         self._H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
         self.nsamples = 0         # sequences added (pending ones included)
         self._flushed = 0         # sequences already in H
@@ -137,6 +143,8 @@ class HessianAccumulator:
         if not groups:                                  # only empty calls: H <- H * n/(n+b)
             if self._flushed:
                 self._H.mul_(self._flushed / (self._flushed + b_total))
+                if self._diag64 is not None:
+                    self._diag64.mul_(self._flushed / (self._flushed + b_total))
             else:
                 self._H.zero_()                         # after reset() the buffer still holds the previous Hessian: 0 * n/(n+b)
             self._flushed += b_total
@@ -191,6 +199,12 @@ class HessianAccumulator:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
             self.timing.append((e0, e1, e2, T, K))
+        if self.exact_diag:
+            if self._diag64 is None:
+                self._diag64 = torch.zeros(K, dtype=torch.float64, device=xs[0].device)
+                self._diag_ws = _ffi.workspace(L.llmc_hessian_diag_ws_bytes(K), xs[0].device)
+            _ffi.check(L.llmc_hessian_diag_accum_ptrs(_ffi.ptr(self._H), _ffi.ptr(self._diag64), Xs, Ts, n, _ffi.dt(xs[0]), K, ldx,
+                                                      nb, na, _ffi.ptr(self._diag_ws), st), 'llmc_hessian_diag_accum_ptrs')
         self._flushed += b
         self._last_launch = (Ts, n, K, ldx)
         # the tensors of xs may be released by the caller once this returns: the launches are stream-ordered and torch's

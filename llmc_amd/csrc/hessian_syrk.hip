@@ -485,6 +485,80 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact diagonal (round 5, opt-in): d[j] = (n_before / n_after) d[j] + (2 / n_after) sum_t X[t][j]^2 with the sum formed in
+// fp64 (squares of 16-bit values are exact in fp32; eight of them are added in fp32 — 19 bits of a 24-bit significand unless
+// their exponents differ by more than 5 — then folded into an fp64 accumulator), and H[j][j] = (float) d[j].
+// k_syrk4 accumulates 16 products per MFMA into fp32 over 30 - 65 k tokens per unit: its diagonal carries 2 - 3e-6 of relative
+// noise, twice what the reference's sgemm leaves (profiles/r04_parity_envelope_full_down.txt); diag(H) is what GPTQ's actorder
+// sorts and what the damping averages. One more pass over X (HBM-bound: 2 T K bytes), which is why it is opt-in.
+// Grid: x = 512-column blocks, y = token slices; a wave reads whole 1-KiB row segments (16 B per lane).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void k_diag_sumsq(const SyrkArgs a, double* __restrict__ part /* [gridDim.y][K] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 512 + lane * 8;
+    double acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    if (c0 < a.K) {
+        const int nslice = gridDim.y;
+        for (int si = 0; si < a.n; ++si) {
+            const char* base = (const char*)(uintptr_t)a.smp[si].base;
+            const int64_t T = a.smp[si].T;
+            // rows of this sample dealt to (slice, wave) round-robin in runs of 8 (one fp32 partial per run)
+            for (int64_t r0 = ((int64_t)blockIdx.y * 4 + wv) * 8; r0 < T; r0 += (int64_t)nslice * 32) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r0 + r < T) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(base + ((r0 + r) * a.ldx + c0) * 2);
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float x0, x1;
+                            if constexpr (DT == LLMC_BF16) {
+                                x0 = __uint_as_float(w[q] << 16);
+                                x1 = __uint_as_float(w[q] & 0xffff0000u);
+                            } else {
+                                x0 = f16_bits_to_f32((uint16_t)(w[q] & 0xffffu));
+                                x1 = f16_bits_to_f32((uint16_t)(w[q] >> 16));
+                            }
+                            f[2 * q] = __builtin_fmaf(x0, x0, f[2 * q]);
+                            f[2 * q + 1] = __builtin_fmaf(x1, x1, f[2 * q + 1]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (double)f[e];
+            }
+        }
+    }
+    // the four waves of the workgroup hold disjoint rows of the same columns: sum them through LDS
+    __shared__ double red[4][512];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wv][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int64_t col = (int64_t)blockIdx.x * 512 + c;
+        if (col < a.K) part[(int64_t)blockIdx.y * a.K + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_diag_apply(const double* __restrict__ part, int nslice, int K, double alpha, double beta,
+                                                    double* __restrict__ dstate, float* __restrict__ H) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= K) return;
+    double s = 0.0;
+    for (int i = 0; i < nslice; ++i) s += part[(int64_t)i * K + j];
+    const double d = alpha * (alpha != 0.0 ? dstate[j] : 0.0) + beta * s;
+    dstate[j] = d;
+    H[(int64_t)j * K + j] = (float)d;
+}
+
 static inline int choose_chunks(int ntiles_real, int64_t ngroups, int64_t x_bytes, int ncu) {
     // pick S >= Smin minimising a simple time model (microseconds):
     //   rounds * (groups per unit * t_group + t_unit) + fixup traffic (S partial tiles written + read)
@@ -630,6 +704,41 @@ extern "C" int llmc_hessian_accum_barrier_timeouts(const void* ws, const int64_t
     const char* p = (const char*)ws + (size_t)a.S * a.ntiles_p * TILE_FLOATS * sizeof(float) + 4;
     LLMC_HIP_CHECK(hipMemcpyAsync(out_host, p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     LLMC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return LLMC_OK;
+}
+
+static constexpr int DIAG_SLICES = 96;       // token slices: 96 x ceil(K / 512) workgroups
+
+extern "C" size_t llmc_hessian_diag_ws_bytes(int64_t K) {
+    return K > 0 ? (size_t)DIAG_SLICES * K * sizeof(double) : 0;
+}
+
+// Optional second pass of an accumulation step (see k_diag_sumsq): dstate [K] fp64 carries the exact running diagonal across
+// calls (ignored and overwritten when n_before == 0); H's diagonal is overwritten with its fp32 rounding. Call it AFTER the
+// llmc_hessian_accum* call of the same samples, with the same n_before / n_after. ws: llmc_hessian_diag_ws_bytes(K).
+extern "C" int llmc_hessian_diag_accum_ptrs(float* H, double* dstate, const void* const* X_list_host, const int64_t* T_list_host,
+                                            int n, int dt, int64_t K, int64_t ldx, double n_before, double n_after, void* ws,
+                                            llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_diag: X must be f16 or bf16");
+    LLMC_REQUIRE(H && dstate && X_list_host && T_list_host && ws && n_after > 0, "hessian_diag: null argument");
+    LLMC_REQUIRE(n >= 1 && n <= SYRK_MAX_SAMPLES, "hessian_diag: 1 .. LLMC_HESSIAN_MAX_SAMPLES samples per call");
+    LLMC_REQUIRE(K > 0 && K % 8 == 0 && ldx >= K && ldx % 8 == 0, "hessian_diag: K and the row stride must be multiples of 8");
+    SyrkArgs a;
+    a.K = (int)K; a.ldx = ldx; a.n = n;
+    for (int i = 0; i < n; ++i) {
+        LLMC_REQUIRE(X_list_host[i] && ((uintptr_t)X_list_host[i] & 15) == 0 && T_list_host[i] > 0, "hessian_diag: bad sample");
+        a.smp[i].base = (uint64_t)(uintptr_t)X_list_host[i];
+        a.smp[i].T = (uint32_t)T_list_host[i];
+        a.smp[i].g0 = 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)ceil_div64(K, 512), DIAG_SLICES);
+    if (dt == LLMC_BF16) hipLaunchKernelGGL((k_diag_sumsq<LLMC_BF16>), grid, dim3(256), 0, st, a, (double*)ws);
+    else hipLaunchKernelGGL((k_diag_sumsq<LLMC_F16>), grid, dim3(256), 0, st, a, (double*)ws);
+    LLMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_diag_apply, dim3((unsigned)ceil_div64(K, 256)), dim3(256), 0, st, (const double*)ws, DIAG_SLICES, (int)K,
+                       n_before / n_after, 2.0 / n_after, dstate, H);
+    LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }
 

@@ -266,3 +266,36 @@ def test_pending_references_are_bounded_in_bytes(monkeypatch):
         ref.add(x)
     # an early flush splits the running mean into two updates: the same matrix up to fp32 rounding
     assert rel_err(a.H.cpu().numpy(), ref.H.cpu().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_exact_diag_option_gives_the_fp64_diagonal_and_leaves_the_rest_alone(dt):
+    """HessianAccumulator(exact_diag=True) (GPTQ special.hessian_exact_diag): diag(H) = (2 / n) sum x^2 formed in fp64 and rounded
+    once — at the fp32 rounding level of the exact value, where the MFMA kernel's fp32 accumulation over thousands of tokens is
+    10x further away; every off-diagonal bit is the default path's; per-sample feeds, several flushes (running mean) and ragged
+    sample lengths included."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    K = 1024
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    xs = [(torch.randn(1, t, K, generator=gen, device='cuda') * torch.exp(0.7 * torch.randn(K, generator=gen, device='cuda'))).to(dt)
+          for t in (2048, 2048, 777, 2048, 300, 2048, 4096, 2048)]
+    a0 = HessianAccumulator(K, 'cuda')
+    a1 = HessianAccumulator(K, 'cuda', exact_diag=True)
+    for i, x in enumerate(xs):
+        a0.add(x)
+        a1.add(x)
+        if i == 3:                      # a flush in the middle: the running mean continues (n_before > 0)
+            _ = a0.H, a1.H
+    H0, H1 = a0.H.clone(), a1.H.clone()
+    off = ~torch.eye(K, dtype=torch.bool, device='cuda')
+    assert torch.equal(H0[off], H1[off])
+    ref = sum((x.double() ** 2).sum(dim=(0, 1)) for x in xs) * (2.0 / len(xs))
+    e1 = ((torch.diagonal(H1).double() - ref).abs() / ref).max().item()
+    e0 = ((torch.diagonal(H0).double() - ref).abs() / ref).max().item()
+    assert e1 <= 1.2e-7, e1             # half an fp32 ulp (6e-8) + the fp32 partial sums of 8 squares
+    assert e0 > e1                      # (informative: the default diagonal is the noisier one)
+    # reset() starts over
+    a1.reset()
+    a1.add(xs[0])
+    r0 = (xs[0].double() ** 2).sum(dim=(0, 1)) * 2.0
+    assert ((torch.diagonal(a1.H).double() - r0).abs() / r0).max().item() <= 1.2e-7
