@@ -99,11 +99,14 @@ class AutoClipper:
         min_val = -max_val if self.clip_sym else (org_min.float() * f).to(org_min.dtype)
         return max_val, min_val
 
-    def _argmin_levels(self, errs, org_max, org_min, n_grid):
+    def _argmin_levels(self, errs, org_max, org_min, n_grid, levels=None):
+        """The reference keeps, per group, the (max, min) pair of the level whose error is smallest — the pair it EVALUATED
+        (auto_clip.py:153-176): `levels` are the shrink levels the candidates were built with (level 0 is 0 + eps for v2 with
+        quantized activations, auto_clip.py:128-130), default 0, 1, 2, ..."""
         best_max, best_min = org_max.clone(), org_min.clone()
         min_errs = torch.ones_like(org_max) * 1e9
         for i_s in range(errs.shape[0]):
-            max_val, min_val = self._levels(org_max, org_min, i_s, n_grid)
+            max_val, min_val = self._levels(org_max, org_min, i_s if levels is None else levels[i_s], n_grid)
             err = errs[i_s].unsqueeze(-1)
             better = err < min_errs
             min_errs = torch.where(better, err, min_errs)
@@ -155,9 +158,9 @@ class AutoClipper:
         org_min = wg.amin(dim=-1, keepdim=True)
         ns = int(max_shrink * n_grid)
         cands = torch.empty((ns, R, K), dtype=wd.dtype, device=wd.device)
+        levels = [i_s + eps if (i_s == 0 and self.clip_version == 'v2' and not self.w_only) else i_s for i_s in range(ns)]   # :128-130
         for i_s in range(ns):
-            lev = i_s + eps if (i_s == 0 and self.clip_version == 'v2' and not self.w_only) else i_s     # :128-130
-            max_val, min_val = self._levels(org_max, org_min, lev, n_grid)
+            max_val, min_val = self._levels(org_max, org_min, levels[i_s], n_grid)
             for b0 in range(0, R, oc):
                 sl = slice(b0, b0 + oc)
                 cands[i_s, sl] = self.fake_quantize_weight(wd[sl], min_val[sl], max_val[sl], org_min[sl], org_max[sl])
@@ -171,7 +174,7 @@ class AutoClipper:
             errs = e if errs is None else errs.add_(e)
         if len(inputs) > 1:
             errs /= len(inputs)
-        return self._argmin_levels(errs, org_max, org_min, n_grid)
+        return self._argmin_levels(errs, org_max, org_min, n_grid, levels)
 
     def get_clip_factor(self, block_idx, layer, min_val, max_val, layer_name):
         """auto_clip.py:233-256."""

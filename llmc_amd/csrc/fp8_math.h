@@ -97,14 +97,18 @@ template <int E, int M> __device__ __forceinline__ float qtorch_quantize(float x
 
 // qtorch_quantize<4, 3> without control flow for a finite, non-NaN x (both ranges evaluated, one selected): the normal range
 // as above with the saturation as a clamp to +-240 (256 is the next representable magnitude: nothing lies between); below 2^-6
-// the multiples of 2^-9 with ties away (x + sign * 2^-6 rounded and shifted back; a zero result is +0). A NaN takes the routine
+// the multiples of 2^-9 with ties away, formed exactly like the routine above (|x| + 2^-6 in fp32, rounded on its bits, shifted
+// back; a zero result is +0). A NaN takes the routine
 // above. tests/test_fp8_fast_gpu.py and the fp8 goldens run both forms on the same data.
 __device__ __forceinline__ float qtorch_e4m3_select(float x) {
     const uint32_t u = __float_as_uint(x), a = u & 0x7fffffffu;
     if (__builtin_expect(a > 0x7f800000u, 0)) return qtorch_quantize<4, 3>(x);
     const float n = __builtin_amdgcn_fmed3f(__uint_as_float((u + 0x80000u) & 0xfff00000u), -240.0f, 240.0f);
-    const float d = __uint_as_float(__float_as_uint(__builtin_floorf(__builtin_fmaf(__uint_as_float(a), 512.0f, 0.5f)) * 0.001953125f) |
-                                    (u & 0x80000000u)) + 0.0f;
+    // QPyTorch's own two roundings: fl32(|x| + 2^-6) first (spacing 2^-29 there), then ties-away at 2^-9's spacing on
+    // the sum's bits — an input within 2^-30 below a (k + 0.5) 2^-9 midpoint is carried over it by the first one
+    const float va = opaque_f32(__uint_as_float(a) + 0.015625f);
+    const float r = __uint_as_float((__float_as_uint(va) + 0x80000u) & 0xfff00000u) - 0.015625f;
+    const float d = __uint_as_float(__float_as_uint(r) | (u & 0x80000000u)) + 0.0f;
     return a < 0x3c800000u ? d : n;
 }
 

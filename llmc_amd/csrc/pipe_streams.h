@@ -16,7 +16,9 @@
 // Everything is fenced back into the caller's stream before the entry point returns: the C ABI contract (complete, in stream
 // order, on the stream passed in) is unchanged.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -29,15 +31,15 @@ struct PipeStreams {
     hipStream_t chain = nullptr;   // stands in for the caller's stream when that is the NULL stream (see pipe_chain_stream)
     static constexpr int NEV = 512;
     hipEvent_t ev[NEV] = {};
-    int next = 0;
+    std::atomic<unsigned> next{0};      // two host threads driving the same caller stream must not be handed the same event
     bool ok = false;
     bool masked = false;
 
     // a fresh event recorded on `s`. The pool is a ring: an event is re-recorded NEV records later; every wait on it is
-    // enqueued within a few outer blocks (< 64 records), and a wait captures the record that precedes it.
+    // enqueued within a few outer blocks (< 64 records per call: llmc_gptq_quantize records 3 per 512-column group and waits on
+    // each within three groups), and a wait captures the record that precedes it.
     int record(hipStream_t s, hipEvent_t* out) {
-        hipEvent_t e = ev[next];
-        next = (next + 1) % NEV;
+        hipEvent_t e = ev[next.fetch_add(1u, std::memory_order_relaxed) % NEV];
         LLMC_HIP_CHECK(hipEventRecord(e, s));
         *out = e;
         return LLMC_OK;
@@ -83,20 +85,37 @@ inline PipeStreams* pipe_streams_for(hipStream_t main_st) {
     auto key = std::make_pair(dev, main_st);
     auto it = pool.find(key);
     if (it != pool.end()) return it->second->ok ? it->second : nullptr;
-    if (pool.size() >= 32) return nullptr;
+    if (pool.size() >= 32) {
+        // bounded: callers cycle through few streams. Past the bound the entry points run their single-stream schedule (same
+        // results) — said once, not silently
+        static bool told = false;
+        if (!told) {
+            told = true;
+            fprintf(stderr, "[llmc_hip] helper-stream pool is full (32 caller streams): further streams run the single-stream schedule\n");
+        }
+        return nullptr;
+    }
     PipeStreams* p = new PipeStreams();
-    pool[key] = p;
+    pool[key] = p;             // a failed set stays registered with ok = false (no retry storm), its partial resources released below
     const char* e = getenv("LLMC_SIDE_CU_MASK");
     const bool masked = e && e[0] == '1';
     p->masked = masked;
-    if (!pipe_make_stream(&p->fast, masked) || !pipe_make_stream(&p->bulk, masked) || !pipe_make_stream(&p->inv, masked))
+    auto fail = [&]() -> PipeStreams* {
+        for (hipStream_t* s : {&p->fast, &p->bulk, &p->inv, &p->chain})
+            if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+        for (int i = 0; i < PipeStreams::NEV; ++i)
+            if (p->ev[i]) { (void)hipEventDestroy(p->ev[i]); p->ev[i] = nullptr; }
+        (void)hipGetLastError();
         return nullptr;
+    };
+    if (!pipe_make_stream(&p->fast, masked) || !pipe_make_stream(&p->bulk, masked) || !pipe_make_stream(&p->inv, masked))
+        return fail();
     // NORMAL priority: a high-priority chain stream made everything slower (K3 32.1 ms against 21.9 with the chain on the
     // caller's own normal-priority stream, gpurun_out/r04c/k3_time_q8.txt) — the far updates' waves are evicted for every
     // small chain kernel
-    if (hipStreamCreateWithFlags(&p->chain, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&p->chain, hipStreamNonBlocking) != hipSuccess) return fail();
     for (int i = 0; i < PipeStreams::NEV; ++i)
-        if (hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming) != hipSuccess) return fail();
     p->ok = true;
     return p;
 }

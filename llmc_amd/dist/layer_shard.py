@@ -211,9 +211,9 @@ def plan_memory(groups, n_seq, seq_len, world, mode, act_bytes=2):
         R = sum(r for _, r in layers)
         sample = coop and K > 8192
         n_mine = -(-n_seq // world) if sample else n_seq
-        holds = (not coop) or sample or True        # rank 0 holds the broadcast inputs; receivers allocate the same size
-        if holds:
-            items['activations'] += n_mine * seq_len * K * act_bytes
+        # every rank holds its inputs: its own sequences (sample-sharded), or the whole set (rank 0 holds the broadcast inputs and
+        # the receivers allocate the same size)
+        items['activations'] += n_mine * seq_len * K * act_bytes
         items['hessians'] += 2 * K * K * 4
         items['syrk_partials'] = max(items['syrk_partials'], int(L.llmc_hessian_accum_ws_bytes(n_mine * seq_len, K, K)))
         items['factor_ws'] += int(L.llmc_chol_inv_upper_ws_bytes(K)) + K * K * 4       # the four subsets' chains run side by side

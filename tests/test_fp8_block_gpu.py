@@ -225,3 +225,33 @@ def test_fp8_per_group_matches_reference_golden():
         fw = q.fake_quant_weight_dynamic(w).float().cpu().numpy()
         np.testing.assert_array_equal(fa.view(np.uint32), g[p + 'fake_x'].view(np.uint32), err_msg=f'{ci} act')
         np.testing.assert_array_equal(fw.view(np.uint32), g[p + 'fake_w'].view(np.uint32), err_msg=f'{ci} weight')
+
+
+def test_per_block_qtorch_subnormal_midpoints_follow_qpytorch_double_rounding():
+    """qtorch rounds fl32(|x| + 2^-6) first and the sum's bits second; a quotient 1..16 fp32 ulps below a
+    (k + 0.5) 2^-9 midpoint of e4m3's subnormal range is carried over the midpoint by the first rounding. FloatQuantizer per_block
+    feeds fp32 quotients w / s to that routine: an fp32 weight whose block absmax is 448 (s = 1) and whose other elements sit
+    around those midpoints must come out with the codes of the restated qtorch, element for element."""
+    from llmc_amd.compression.quantization import FloatQuantizer
+    ks = np.arange(0, 8, dtype=np.float32)
+    mids = (ks + 0.5) * np.float32(2.0 ** -9)
+    vals = []
+    for m in mids:
+        b = np.array([m], dtype=np.float32).view(np.uint32)[0]
+        for d in range(-20, 21):
+            vals.append(np.array([np.uint32(int(b) + d)], dtype=np.uint32).view(np.float32)[0])
+    vals = np.array(vals, dtype=np.float32)
+    w = np.zeros((128, 128), dtype=np.float32)
+    w.ravel()[:vals.size] = vals
+    w.ravel()[vals.size:2 * vals.size] = -vals
+    w[127, 127] = 448.0                                   # absmax 448: the block scale is exactly 1
+    q = FloatQuantizer('e4m3', True, 'per_block', block_size=128, use_qtorch=True)
+    rw, rs, _ = q.real_quant_weight_dynamic(torch.from_numpy(w).cuda())
+    assert float(rs.reshape(-1)[0]) == 1.0
+    ref = Q.qtorch_float_quantize(w, 4, 3)
+    got = rw.float().cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # and the restatement really does cross those midpoints (the case the single-rounding form got wrong)
+    x = np.array([np.float32(1.5 * 2.0 ** -9)], dtype=np.float32).view(np.uint32)
+    below = np.array([x[0] - 1], dtype=np.uint32).view(np.float32)
+    assert float(Q.qtorch_float_quantize(below, 4, 3)[0]) == 2.0 ** -8
