@@ -310,7 +310,7 @@ class HipOps:
         a.timing = self.timing
         return a
 
-    def hessian(self, name, K, x, calib_bs, lazy=False):
+    def hessian(self, name, K, x, calib_bs):
         a = self.acc(name, K)
         a.reset()
         if isinstance(x, (list, tuple)):          # per-call tensors, each its own allocation (hook calls)
@@ -319,11 +319,6 @@ class HipOps:
         else:
             for i in range(0, x.shape[0], calib_bs):
                 a.add(x[i:i + calib_bs])
-        if self.exact_diag and lazy:
-            # the launches are queued now; the diagonal is written on the accumulator's second stream, under the MFMA kernels of
-            # this and the following Hessians: whoever consumes H waits for it (quantize: `H.H` on the chain's stream)
-            a.flush()
-            return a
         return a.H
 
     def static_qparams(self, weights):
@@ -336,8 +331,6 @@ class HipOps:
         return out
 
     def quantize(self, name, weights, H, rows=None):
-        if isinstance(H, self.Acc):
-            H = H.H
         static = self.static_qparams(weights)
         res = self.P.quantize_stacked(weights, H, self.cfg, static_qparams=static, h_work=self.hwork.get(name), rows=rows)
         outs = [{'weight': r.weight, 'scales': r.scales, 'zeros': r.zeros, 'perm': r.perm, 'loss': r.loss, 'info': r.info} for r in res]
@@ -382,7 +375,7 @@ class DryOps:
         import torch
         self.torch, self.cfg, self.timing = torch, cfg, None
 
-    def hessian(self, name, K, x, calib_bs, lazy=False):
+    def hessian(self, name, K, x, calib_bs):
         if isinstance(x, (list, tuple)):
             x = self.torch.cat(list(x), 0)
         xf = x.reshape(-1, K).float()
@@ -755,7 +748,7 @@ def main():
             Hs = {}
             if args.overlap <= 1 or args.dry:
                 for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
-                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs, lazy=True)
+                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
                 for name, K, layers in groups:
                     outs.append(ops.quantize(name, weights[name], Hs[name]))
                 return outs
@@ -790,17 +783,17 @@ def main():
                 wide = max(range(len(groups)), key=lambda i: (groups[i][1], sum(r for _, r in groups[i][2])))
                 others = [gi for gi in order if gi != wide]
                 for gi in others:
-                    Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs, lazy=True)
+                    Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs)
                 for si, gi in enumerate(others):
                     chain(si + 1, gi)
                 g0 = groups[wide]
                 with ops.cu_reserve(args.reserve):
-                    Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs, lazy=True)
+                    Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
                 chain(0, wide, helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
             else:
                 if args.order == 'k1first':
                     for name, K, layers in groups:
-                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs, lazy=True)
+                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
                 if args.order == 'k1first' and args.small_streams > 0:
                     wide = max(range(len(groups)), key=lambda i: (groups[i][1], sum(r for _, r in groups[i][2])))
                     chain(0, wide, helper=(args.helpers in ('all', 'wide')) or bool(args.wide_helper))
@@ -818,7 +811,7 @@ def main():
                 for si, gi in enumerate(order):
                     name, K = groups[gi][0], groups[gi][1]
                     if args.order != 'k1first':
-                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs, lazy=True)
+                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
                     # one stream per chain, internal helper streams off (--helpers wide gives the widest chain its helper:
                     # measured 94.5 against 93.7 ms per step, gpurun_out/r03g: the other chains already fill its gaps)
                     chain(si, gi, helper=(args.helpers == 'all') or ((args.helpers == 'wide' or bool(args.wide_helper)) and si == 0))

@@ -201,18 +201,14 @@ int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, const int64
                                      int64_t K, int64_t ldx, void* ws, llmc_stream_t stream);
 int llmc_hessian_accum_ptrs_reduce(float* H, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
                                    double n_before, double n_after, const void* ws, llmc_stream_t stream);
-/* Optional exact diagonal: the MFMA kernel accumulates in fp32 over tens of thousands of tokens and leaves 2-3e-6 of relative noise on
- * diag(H), twice the reference's sgemm; diag(H) is what actorder sorts (gptq.py:58-83) and the damping averages (gptq.py:169). These two
- * calls re-form sum_t X[t][j]^2 in fp64 (one more read of the samples: 2 T K bytes), keep the running value in dstate [K] (fp64, carried
- * across calls; overwritten when n_before == 0) and write its fp32 rounding onto H's diagonal.
- *   llmc_hessian_diag_partials: per-slice sums into ws (llmc_hessian_diag_ws_bytes(K)). Built to fit in what a CU has left beside the
- *     MFMA kernel (32 VGPRs, 8 KiB of LDS): launched on a second stream right behind llmc_hessian_accum*_partials it runs under it.
- *   llmc_hessian_diag_apply: stream-ordered after the partials AND after the llmc_hessian_accum*_reduce of the same samples, with the
- *     same n_before / n_after. */
+/* Optional exact diagonal (opt-in: one more HBM pass over the samples, 2 T K bytes): the MFMA kernel accumulates in fp32 over tens of
+ * thousands of tokens and leaves 2-3e-6 of relative noise on diag(H), twice the reference's sgemm; diag(H) is what actorder sorts
+ * (gptq.py:58-83) and the damping averages (gptq.py:169). This call re-forms sum_t X[t][j]^2 in fp64, keeps the running value in
+ * dstate [K] (fp64, carried across calls; overwritten when n_before == 0) and writes its fp32 rounding onto H's diagonal. Call it
+ * after the llmc_hessian_accum* call of the same samples with the same n_before / n_after. ws: llmc_hessian_diag_ws_bytes(K). */
 size_t llmc_hessian_diag_ws_bytes(int64_t K);
-int llmc_hessian_diag_partials(const void* const* X_list_host, const int64_t* T_list_host, int n, int dt, int64_t K, int64_t ldx,
-                               void* ws, llmc_stream_t stream);
-int llmc_hessian_diag_apply(float* H, double* dstate, int64_t K, double n_before, double n_after, const void* ws, llmc_stream_t stream);
+int llmc_hessian_diag_accum_ptrs(float* H, double* dstate, const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,
+                                 int64_t K, int64_t ldx, double n_before, double n_after, void* ws, llmc_stream_t stream);
 /* Diagnostic: how many round barriers of the LAST llmc_hessian_accum*_partials launch on `ws` (same T list, K, ldx) gave
  * up waiting because workgroups of its persistent grid were kept off their CUs by other streams. Synchronises `stream`
  * and writes the count to *out_host. 0 in a healthy run; > 0 leaves the result correct but the launch slower. */

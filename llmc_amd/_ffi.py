@@ -49,8 +49,7 @@ SIGNATURES = {
     'llmc_hessian_accum_ptrs_reduce': (_i32, [_vp, _vp, _i32, _i64, _i64, _f64, _f64, _vp, _vp]),
     'llmc_hessian_accum_barrier_timeouts': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     'llmc_hessian_diag_ws_bytes': (_sz, [_i64]),
-    'llmc_hessian_diag_partials': (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
-    'llmc_hessian_diag_apply': (_i32, [_vp, _vp, _i64, _f64, _f64, _vp, _vp]),
+    'llmc_hessian_diag_accum_ptrs': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f64, _f64, _vp, _vp]),
     'llmc_gather_cols': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'llmc_hessian_prep_ws_bytes': (_sz, [_i64]),
     'llmc_hessian_prep': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),

@@ -38,11 +38,9 @@ class HessianAccumulator:
         # exact_diag (GPTQ: special.hessian_exact_diag): diag(H) re-formed in fp64 by a second pass over the samples
         # (llmc_hessian_diag_accum_ptrs): the MFMA kernel's fp32 accumulation leaves 2-3e-6 of relative noise there, twice the
         # reference's sgemm, and diag(H) is what actorder sorts. One more HBM pass (2 T K bytes): off by default.
-        self.exact_diag = bool(exact_diag) and self.K % 4 == 0
+        self.exact_diag = bool(exact_diag) and self.K % 8 == 0
         self._diag64 = None
         self._diag_ws = None
-        self._diag_stream = None      # the second stream the fp64 pass runs on, beside the MFMA kernel
-        self._diag_applied = None     # event: the diagonal of the most recent launch has been written
         self._H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
         self.nsamples = 0         # sequences added (pending ones included)
         self._flushed = 0         # sequences already in H
@@ -57,9 +55,6 @@ class HessianAccumulator:
     @property
     def H(self):
         self.flush()
-        ev = getattr(self, '_diag_applied', None)
-        if ev is not None:                       # exact_diag: the diagonal is written on the accumulator's second stream
-            torch.cuda.current_stream().wait_event(ev)
         return self._H
 
     @staticmethod
@@ -190,28 +185,10 @@ class HessianAccumulator:
         if self.timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.exact_diag:
-            ready = torch.cuda.Event()
-            ready.record()                       # the samples are complete on the calling stream (and the previous apply has been queued)
         _ffi.check(L.llmc_hessian_accum_ptrs_partials(Xs, Ts, n, _ffi.dt(xs[0]), K, ldx, _ffi.ptr(self._ws), st),
                    'llmc_hessian_accum_ptrs_partials')
         if self.timing is not None:
             e1.record()
-        side = None
-        if self.exact_diag:
-            # the fp64 sums of squares on a second stream, enqueued right BEHIND the MFMA kernel (so that kernel's workgroups are
-            # placed first) but ordered only after what came BEFORE it: the pass's workgroups fit into what a CU has left beside
-            # a k_syrk4 workgroup (32 VGPRs, 8 KiB of LDS) and read X under it
-            if self._diag64 is None:
-                self._diag64 = torch.zeros(K, dtype=torch.float64, device=xs[0].device)
-                self._diag_ws = _ffi.workspace(L.llmc_hessian_diag_ws_bytes(K), xs[0].device)
-                self._diag_stream = torch.cuda.Stream(device=xs[0].device)
-            side = self._diag_stream
-            side.wait_event(ready)
-            for x in xs:                         # the caller may free a sample once this returns: the allocator must keep it
-                x.record_stream(side)            # away from other streams until the second stream has read it too
-            _ffi.check(L.llmc_hessian_diag_partials(Xs, Ts, n, _ffi.dt(xs[0]), K, ldx, _ffi.ptr(self._diag_ws), side.cuda_stream),
-                       'llmc_hessian_diag_partials')
         # b = 0: a further launch of the same flush adds its products with the weights of the first (n stays)
         nb, na = float(self._flushed), float(self._flushed + b)
         if b == 0:
@@ -222,17 +199,12 @@ class HessianAccumulator:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
             self.timing.append((e0, e1, e2, T, K))
-        if side is not None:
-            # H[j][j] = (float) dstate[j] behind BOTH the slice sums (side stream) and this launch's reduction (calling stream);
-            # readers of H wait for `_diag_applied` (the H property does): the calling stream itself is not held up here, so the
-            # next Hessian's MFMA kernel can start while this pass is still reading
-            reduced = torch.cuda.Event()
-            reduced.record()
-            side.wait_event(reduced)
-            _ffi.check(L.llmc_hessian_diag_apply(_ffi.ptr(self._H), _ffi.ptr(self._diag64), K, nb, na, _ffi.ptr(self._diag_ws),
-                                                 side.cuda_stream), 'llmc_hessian_diag_apply')
-            self._diag_applied = torch.cuda.Event()
-            self._diag_applied.record(side)
+        if self.exact_diag:
+            if self._diag64 is None:
+                self._diag64 = torch.zeros(K, dtype=torch.float64, device=xs[0].device)
+                self._diag_ws = _ffi.workspace(L.llmc_hessian_diag_ws_bytes(K), xs[0].device)
+            _ffi.check(L.llmc_hessian_diag_accum_ptrs(_ffi.ptr(self._H), _ffi.ptr(self._diag64), Xs, Ts, n, _ffi.dt(xs[0]), K, ldx,
+                                                      nb, na, _ffi.ptr(self._diag_ws), st), 'llmc_hessian_diag_accum_ptrs')
         self._flushed += b
         self._last_launch = (Ts, n, K, ldx)
         # the tensors of xs may be released by the caller once this returns: the launches are stream-ordered and torch's

@@ -493,56 +493,59 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
 // k_syrk4 accumulates 16 products per MFMA into fp32 over 30 - 65 k tokens per unit: its diagonal carries 2 - 3e-6 of relative
 // noise, twice what the reference's sgemm leaves (profiles/r04_parity_envelope_full_down.txt); diag(H) is what GPTQ's actorder
 // sorts and what the damping averages. One more pass over X (HBM-bound: 2 T K bytes), which is why it is opt-in.
-// Grid: x = 256-column blocks, y = token slices; a wave reads whole 512-B row segments (8 B per lane), four rows in flight.
+// Grid: x = 512-column blocks, y = token slices; a wave reads whole 1-KiB row segments (16 B per lane).
 // ---------------------------------------------------------------------------------------------------------------------
-// Register budget: 32 VGPRs per lane, 8 KiB of LDS per workgroup — what a CU has LEFT beside a resident k_syrk4 workgroup (480 of 512
-// registers per SIMD, 128 of 160 KiB of LDS): launched on a second stream right behind k_syrk4, the workgroups of this kernel slot into
-// those leftovers and read X under the MFMA kernel (whose loop leaves the VALU and most of HBM idle) instead of after it.
 template <int DT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32)))
-void k_diag_sumsq(const SyrkArgs a, double* __restrict__ part /* [gridDim.y][K] */) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c0 = blockIdx.x * 256 + lane * 4;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    // columns past K (the last column block of a ragged K) re-read column block's first columns: their sums are never stored.
-    // Everything but the lane's byte offset is wave-uniform and stays in scalar registers.
-    const uint32_t voff = (uint32_t)((c0 < a.K ? c0 : blockIdx.x * 256) * 2);
-    const uint32_t rstep = gridDim.y * 8u;                        // rows between two runs of this (slice, wave)
-    const int64_t row_bytes = a.ldx * 2;
-    for (int si = 0; si < a.n; ++si) {
-        const char* sbase = (const char*)(uintptr_t)a.smp[si].base;
-        const uint32_t T = a.smp[si].T;
-        for (uint32_t r0 = (blockIdx.y * 4u + (uint32_t)wv) * 2u; r0 < T; r0 += rstep) {       // runs of 2 rows
-            const uint32_t r1 = r0 + 1 < T ? r0 + 1 : r0;        // a run's tail re-reads its first row with weight 0
-            const uint2 v0 = *reinterpret_cast<const uint2*>(sbase + (int64_t)r0 * row_bytes + voff);
-            const uint2 v1 = *reinterpret_cast<const uint2*>(sbase + (int64_t)r1 * row_bytes + voff);
-            const float keep = r0 + 1 < T ? 1.0f : 0.0f;
-            const uint32_t w0[2] = {v0.x, v0.y}, w1[2] = {v1.x, v1.y};
+__global__ __launch_bounds__(256) void k_diag_sumsq(const SyrkArgs a, double* __restrict__ part /* [gridDim.y][K] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 512 + lane * 8;
+    double acc[8];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float a0, a1, b0, b1;
-                if constexpr (DT == LLMC_BF16) {
-                    a0 = __uint_as_float(w0[q] << 16); a1 = __uint_as_float(w0[q] & 0xffff0000u);
-                    b0 = __uint_as_float(w1[q] << 16); b1 = __uint_as_float(w1[q] & 0xffff0000u);
-                } else {
-                    a0 = f16_bits_to_f32((uint16_t)(w0[q] & 0xffffu)); a1 = f16_bits_to_f32((uint16_t)(w0[q] >> 16));
-                    b0 = f16_bits_to_f32((uint16_t)(w1[q] & 0xffffu)); b1 = f16_bits_to_f32((uint16_t)(w1[q] >> 16));
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    if (c0 < a.K) {
+        const int nslice = gridDim.y;
+        for (int si = 0; si < a.n; ++si) {
+            const char* base = (const char*)(uintptr_t)a.smp[si].base;
+            const int64_t T = a.smp[si].T;
+            // rows of this sample dealt to (slice, wave) round-robin in runs of 8 (one fp32 partial per run)
+            for (int64_t r0 = ((int64_t)blockIdx.y * 4 + wv) * 8; r0 < T; r0 += (int64_t)nslice * 32) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r0 + r < T) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(base + ((r0 + r) * a.ldx + c0) * 2);
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float x0, x1;
+                            if constexpr (DT == LLMC_BF16) {
+                                x0 = __uint_as_float(w[q] << 16);
+                                x1 = __uint_as_float(w[q] & 0xffff0000u);
+                            } else {
+                                x0 = f16_bits_to_f32((uint16_t)(w[q] & 0xffffu));
+                                x1 = f16_bits_to_f32((uint16_t)(w[q] >> 16));
+                            }
+                            f[2 * q] = __builtin_fmaf(x0, x0, f[2 * q]);
+                            f[2 * q + 1] = __builtin_fmaf(x1, x1, f[2 * q + 1]);
+                        }
+                    }
                 }
-                // two squares of 16-bit values: exact in fp32 each, their sum within 2^-24; then fp64
-                acc[2 * q] += (double)__builtin_fmaf(b0 * keep, b0, a0 * a0);
-                acc[2 * q + 1] += (double)__builtin_fmaf(b1 * keep, b1, a1 * a1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (double)f[e];
             }
         }
     }
     // the four waves of the workgroup hold disjoint rows of the same columns: sum them through LDS
-    __shared__ double red[4][256];
+    __shared__ double red[4][512];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wv][lane * 4 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) red[wv][lane * 8 + e] = acc[e];
     __syncthreads();
-    const int c = threadIdx.x;
-    const int col = blockIdx.x * 256 + c;
-    if (col < a.K) part[(int64_t)blockIdx.y * a.K + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int64_t col = (int64_t)blockIdx.x * 512 + c;
+        if (col < a.K) part[(int64_t)blockIdx.y * a.K + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_diag_apply(const double* __restrict__ part, int nslice, int K, double alpha, double beta,
@@ -704,46 +707,37 @@ extern "C" int llmc_hessian_accum_barrier_timeouts(const void* ws, const int64_t
     return LLMC_OK;
 }
 
-static constexpr int DIAG_SLICES = 96;       // token slices: 96 x ceil(K / 256) workgroups
+static constexpr int DIAG_SLICES = 96;       // token slices: 96 x ceil(K / 512) workgroups
 
 extern "C" size_t llmc_hessian_diag_ws_bytes(int64_t K) {
     return K > 0 ? (size_t)DIAG_SLICES * K * sizeof(double) : 0;
 }
 
-// Optional second pass of an accumulation step (see k_diag_sumsq), in two halves so that the heavy one can run on ANOTHER stream
-// beside the MFMA kernel of the same samples:
-//   llmc_hessian_diag_partials  per-slice fp64 sums of squares of the listed samples into ws (llmc_hessian_diag_ws_bytes(K));
-//   llmc_hessian_diag_apply     dstate [K] fp64 = (n_before / n_after) dstate + (2 / n_after) sum of the slices (dstate is ignored and
-//                               overwritten when n_before == 0), H[j][j] = (float) dstate[j]. Stream-ordered AFTER the partials and after
-//                               the llmc_hessian_accum*_reduce of the same samples (same n_before / n_after).
-extern "C" int llmc_hessian_diag_partials(const void* const* X_list_host, const int64_t* T_list_host, int n, int dt, int64_t K,
-                                          int64_t ldx, void* ws, llmc_stream_t stream) {
+// Optional second pass of an accumulation step (see k_diag_sumsq): dstate [K] fp64 carries the exact running diagonal across
+// calls (ignored and overwritten when n_before == 0); H's diagonal is overwritten with its fp32 rounding. Call it AFTER the
+// llmc_hessian_accum* call of the same samples, with the same n_before / n_after. ws: llmc_hessian_diag_ws_bytes(K).
+extern "C" int llmc_hessian_diag_accum_ptrs(float* H, double* dstate, const void* const* X_list_host, const int64_t* T_list_host,
+                                            int n, int dt, int64_t K, int64_t ldx, double n_before, double n_after, void* ws,
+                                            llmc_stream_t stream) {
     LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_diag: X must be f16 or bf16");
-    LLMC_REQUIRE(X_list_host && T_list_host && ws, "hessian_diag: null argument");
+    LLMC_REQUIRE(H && dstate && X_list_host && T_list_host && ws && n_after > 0, "hessian_diag: null argument");
     LLMC_REQUIRE(n >= 1 && n <= SYRK_MAX_SAMPLES, "hessian_diag: 1 .. LLMC_HESSIAN_MAX_SAMPLES samples per call");
-    LLMC_REQUIRE(K > 0 && K < (1 << 30) && K % 4 == 0 && ldx >= K && ldx % 4 == 0, "hessian_diag: K and the row stride must be multiples of 4");
+    LLMC_REQUIRE(K > 0 && K % 8 == 0 && ldx >= K && ldx % 8 == 0, "hessian_diag: K and the row stride must be multiples of 8");
     SyrkArgs a;
     a.K = (int)K; a.ldx = ldx; a.n = n;
     for (int i = 0; i < n; ++i) {
-        LLMC_REQUIRE(X_list_host[i] && ((uintptr_t)X_list_host[i] & 7) == 0 && T_list_host[i] > 0 && T_list_host[i] < (1ll << 31),
-                     "hessian_diag: bad sample");
+        LLMC_REQUIRE(X_list_host[i] && ((uintptr_t)X_list_host[i] & 15) == 0 && T_list_host[i] > 0, "hessian_diag: bad sample");
         a.smp[i].base = (uint64_t)(uintptr_t)X_list_host[i];
         a.smp[i].T = (uint32_t)T_list_host[i];
         a.smp[i].g0 = 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)ceil_div64(K, 256), DIAG_SLICES);
+    dim3 grid((unsigned)ceil_div64(K, 512), DIAG_SLICES);
     if (dt == LLMC_BF16) hipLaunchKernelGGL((k_diag_sumsq<LLMC_BF16>), grid, dim3(256), 0, st, a, (double*)ws);
     else hipLaunchKernelGGL((k_diag_sumsq<LLMC_F16>), grid, dim3(256), 0, st, a, (double*)ws);
     LLMC_LAUNCH_CHECK();
-    return LLMC_OK;
-}
-
-extern "C" int llmc_hessian_diag_apply(float* H, double* dstate, int64_t K, double n_before, double n_after, const void* ws,
-                                       llmc_stream_t stream) {
-    LLMC_REQUIRE(H && dstate && ws && K > 0 && n_after > 0, "hessian_diag_apply: bad argument");
-    hipLaunchKernelGGL(k_diag_apply, dim3((unsigned)ceil_div64(K, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
-                       DIAG_SLICES, (int)K, n_before / n_after, 2.0 / n_after, dstate, H);
+    hipLaunchKernelGGL(k_diag_apply, dim3((unsigned)ceil_div64(K, 256)), dim3(256), 0, st, (const double*)ws, DIAG_SLICES, (int)K,
+                       n_before / n_after, 2.0 / n_after, dstate, H);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
 }
