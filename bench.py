@@ -61,13 +61,17 @@ def parity_envelope_summary(args):
     if args.model != 'llama3-8b':
         return None
     try:
-        j = json.load(open(os.path.join(ROOT, 'profiles', 'r04_parity_envelope_full_down.json')))
+        src = 'profiles/r05_parity_envelope_full_down.json'
+        j = json.load(open(os.path.join(ROOT, src)))
         pr = j['shapes'][0]['pairs']['w_only' if args.variant == 'w_only' else 'vllm']
         pick = lambda m: {k: m[k] for k in ('codes_equal', 'scales_within_1e-4', 'scales_within_1e-2', 'zeros_equal', 'perm_equal',
-                                            'perm_diff_within_4x_noise') if k in m}
-        return {'layer': j['shapes'][0]['title'], 'source': 'profiles/r04_parity_envelope_full_down.json',
-                'precomputed': 'NOT measured by this run: read from the committed file (tools/parity_envelope.py --full-down on an MI355X, round 4)',
-                'ours_vs_reference_cpu': pick(pr['ref_cpu_32t vs ours']),
+                                            'perm_diff_within_4x_noise', 'H_diag_rel_max') if k in m}
+        ours = 'ours_exactdiag' if getattr(args, 'exact_diag', 0) else 'ours'
+        return {'layer': j['shapes'][0]['title'], 'source': src,
+                'precomputed': 'NOT measured by this run: read from the committed file (tools/parity_envelope.py --full-down on an MI355X, round 5)',
+                'arm': ours + (' (diag(H) re-formed in fp64: --exact-diag 1 / special.hessian_exact_diag)' if ours != 'ours' else
+                               ' (default; the exact-diagonal arm of the same file reaches the reference-vs-itself values: extra.gptq_exact_hessian_diag)'),
+                'ours_vs_reference_cpu': pick(pr['ref_cpu_32t vs ' + ours]),
                 'reference_cpu_vs_reference_rocm': pick(pr['ref_cpu_32t vs ref_rocm'])}
     except Exception:       # noqa: BLE001
         return None
@@ -615,6 +619,9 @@ def run_extras(args):
     runs = {
         'awq_llama3_8b': ['--workload', 'awq', '--steps', '2', '--warmup', '1'],
         'gptq_vllm_variant_packed': ['--variant', 'vllm', '--steps', '3', '--warmup', '1'],
+        # the same workload with diag(H) re-formed in fp64 (GPTQ special.hessian_exact_diag): what the reference-level parity
+        # envelope costs (config.parity_envelope of this entry carries the measured agreement of that arm)
+        'gptq_exact_hessian_diag': ['--exact-diag', '1', '--steps', '3', '--warmup', '1'],
         'gptq_llama3_70b_shapes': ['--model', 'llama3-70b', '--steps', '2', '--warmup', '1'],
         'fp8_mixtral_8x7b_shapes': ['--workload', 'fp8', '--steps', '3', '--warmup', '1'],
     }
