@@ -344,7 +344,11 @@ int llmc_linear_eval(const void* X, const void* Wq, int dt, int64_t N, int64_t K
  * mode | LLMC_LINEAR_YBLOCKED: Yout (mode 0) / Y0 (mode 1) is an opaque TILE-BLOCKED image of the [N, R] matrix,
  * llmc_linear_eval_yblocked_bytes(N, R) bytes: per 256 x 256 tile one contiguous 128 KiB in the kernel's own
  * accumulator order (tile, wave, 32 KiB-pieces, lane x 16 B), so that the reference output of the search
- * (get_original_out) is written with 16-B stores and re-read 20 times as one contiguous run per tile. */
+ * (get_original_out) is written with 16-B stores and re-read 20 times as one contiguous run per tile.
+ * Small products (mode 0, row-major Yout, R % 8 == 0): when the output has fewer 256 x 256 tiles than 3/4 of the CUs and the
+ * caller passes a workspace of llmc_linear_eval_ws_bytes(N, K, R) bytes, the k range is cut into 2..8 slices so that
+ * tiles x slices fills the chip; the slices' fp32 partial tiles are summed in slice order and rounded once by a second
+ * kernel. A reordering of the fp32 sum: within one rounding of the single-pass result. ws == NULL keeps the single pass. */
 #define LLMC_LINEAR_YBLOCKED 4
 size_t llmc_linear_eval_yblocked_bytes(int64_t N, int64_t R);
 int llmc_ktile_pack(const void* src, int dt, int64_t rows, int64_t K, void* dst, llmc_stream_t stream);
