@@ -493,137 +493,6 @@ __global__ __launch_bounds__(256) void k_sgemm_shortk_phased(SgemmArgs a) {
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------
-// k_sgemm_far (round 5): the phased far update of the GPTQ column loop, C -= A[:, p] B[p, :] phase by phase with A = the
-// block errors [M x Kd] row-major and B = rows of Hinv [Kd x N] k-major (k_sgemm<false, false, true, *>'s job), on a
-// 128 (M) x 64 (N) workgroup tile: 4 waves as 2 x 2 of 64 x 32, 32 accumulator + 32 C-tile registers per lane instead of
-// 64 + 64, 25 KiB of LDS — FOUR workgroups per CU (16 waves, four per SIMD) where k_sgemm fits two: its MFMA pipe was idle
-// 37 % of the time waiting (profiles/r04_chain_pmc.txt: 0.64 busy, SQ_WAIT_INST_ANY 68 %) with two waves per SIMD to cover
-// for each other. Same arithmetic per element (one accumulator, ascending k from +0, one rounding C - acc per phase):
-// bit-identical to k_sgemm, which tests compare (LLMC_SGEMM_FAR=0 keeps k_sgemm).
-// ---------------------------------------------------------------------------------------------------------
-static constexpr int FN = 64;            // tile width
-static constexpr int FLB = 68;           // LDS row stride of the B panel (floats)
-template <bool EDGE>
-__global__ __launch_bounds__(256, 4) void k_sgemm_far(SgemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * GK * (GLD + FLB)];   // [buf][A: 16 x 132 | B: 16 x 68]
-    constexpr int BUF = GK * (GLD + FLB);
-    const float* A = a.A;
-    const float* B = a.B;
-    float* C = a.C;
-    const int M = a.M, N = a.N, Kd = a.Kd;
-    const int i0 = blockIdx.y * GB, j0 = blockIdx.x * FN;
-    if (i0 >= M || j0 >= N) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    f32x16 acc[2], cv[2];
-    const int col = j0 + wn * 32 + (lane & 31);
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            acc[m][r] = 0.0f;
-            cv[m][r] = (!EDGE || (row < M && col < N)) ? C[(int64_t)row * a.ldc + col] : 0.0f;
-        }
-    // staging: A [128 rows x 16 k] c-major: 2 float4 per thread (row = idx >> 2, k = 4 (idx & 3)); B [16 k x 64 cols] k-major: 1 float4
-    auto loadA = [&](int k0, float4 (&v)[2]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int idx = tid + 256 * h;
-            const int r = i0 + (idx >> 2), k = k0 + 4 * (idx & 3);
-            v[h] = (!EDGE || r < M) ? *reinterpret_cast<const float4*>(A + (int64_t)r * a.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto loadB = [&](int k0) {
-        const int k = k0 + (tid >> 4), c = j0 + 4 * (tid & 15);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!EDGE || c + 3 < N) v = *reinterpret_cast<const float4*>(B + (int64_t)k * a.ldb + c);
-        else {
-            const float* p = B + (int64_t)k * a.ldb + c;
-            if (c < N) v.x = p[0];
-            if (c + 1 < N) v.y = p[1];
-            if (c + 2 < N) v.z = p[2];
-        }
-        return v;
-    };
-    auto storeA = [&](int buf, const float4 (&v)[2]) {
-        float* p = lds + buf * BUF;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int idx = tid + 256 * h;
-            const int c = idx >> 2, k = 4 * (idx & 3);
-            p[(k + 0) * GLD + c] = v[h].x;
-            p[(k + 1) * GLD + c] = v[h].y;
-            p[(k + 2) * GLD + c] = v[h].z;
-            p[(k + 3) * GLD + c] = v[h].w;
-        }
-    };
-    auto storeB = [&](int buf, float4 v) {
-        *reinterpret_cast<float4*>(lds + buf * BUF + GK * GLD + (tid >> 4) * FLB + 4 * (tid & 15)) = v;
-    };
-    float4 ra[2][2], rb[2];
-    loadA(0, ra[0]);
-    rb[0] = loadB(0);
-    storeA(0, ra[0]);
-    storeB(0, rb[0]);
-    if (GK < Kd) {
-        loadA(GK, ra[1]);
-        rb[1] = loadB(GK);
-    }
-    __syncthreads();
-    auto step = [&](int k0, int cur, float4 (&a2)[2], float4& b2, const float4 (&a1)[2], const float4& b1) {
-        const bool more = k0 + GK < Kd;
-        if (k0 + 2 * GK < Kd) {
-            loadA(k0 + 2 * GK, a2);
-            b2 = loadB(k0 + 2 * GK);
-        }
-        const float* pa = lds + cur * BUF + (lane >> 5) * GLD + wm * 64 + (lane & 31);
-        const float* pb = lds + cur * BUF + GK * GLD + (lane >> 5) * FLB + wn * 32 + (lane & 31);
-        float fa[2][2], fb[2];
-        fa[0][0] = pa[0];
-        fa[0][1] = pa[32];
-        fb[0] = pb[0];
-#pragma unroll
-        for (int kk = 0; kk < GK / 2; ++kk) {
-            const int c = kk & 1;
-            if (kk + 1 < GK / 2) {
-                fa[c ^ 1][0] = pa[2 * (kk + 1) * GLD];
-                fa[c ^ 1][1] = pa[2 * (kk + 1) * GLD + 32];
-                fb[c ^ 1] = pb[2 * (kk + 1) * FLB];
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][m], fb[c], acc[m], 0, 0, 0);
-        }
-        if ((k0 + GK) % a.phase_len == 0 || !more) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    cv[m][r] = cv[m][r] - acc[m][r];
-                    acc[m][r] = 0.0f;
-                }
-        }
-        if (more) {
-            storeA(cur ^ 1, a1);
-            storeB(cur ^ 1, b1);
-        }
-        __syncthreads();
-    };
-    for (int k0 = 0; k0 < Kd; k0 += 2 * GK) {
-        step(k0, 0, ra[0], rb[0], ra[1], rb[1]);
-        if (k0 + GK < Kd) step(k0 + GK, 1, ra[1], rb[1], ra[0], rb[0]);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (!EDGE || (row < M && col < N)) C[(int64_t)row * a.ldc + col] = cv[m][r];
-        }
-}
-
 int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return LLMC_OK;
     LLMC_REQUIRE((a.lda % 4 == 0) && (a.ldb % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
@@ -666,19 +535,6 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
         if (edge) hipLaunchKernelGGL((k_sgemm<TA_, TB_, PH_, true>), grid, dim3(256), 0, st, a);      \
         else hipLaunchKernelGGL((k_sgemm<TA_, TB_, PH_, false>), grid, dim3(256), 0, st, a);          \
     } while (0)
-    // the column loop's far update on the narrow tile with four workgroups per CU (k_sgemm_far)
-    if (a.phase_len > 0 && !TA && !TB && a.batch == 1 && a.epilogue == SG_SUB && !a.a_upper && !a.a_lower && !a.b_upper &&
-        !a.c_upper_only && a.phase_len % GK == 0 && a.Kd % GK == 0 && a.Kd >= 2 * GK && a.lda % 4 == 0 && a.N >= 4 * FN) {
-        const char* e = getenv("LLMC_SGEMM_FAR");
-        if (!(e && e[0] == '0')) {
-            dim3 fgrid((a.N + FN - 1) / FN, (a.M + GB - 1) / GB, 1);
-            // (the bounds-checked instantiation for every shape: the unchecked one needs 46 registers more than the 128 four
-            // workgroups per CU leave it)
-            hipLaunchKernelGGL((k_sgemm_far<true>), fgrid, dim3(256), 0, st, a);
-            LLMC_LAUNCH_CHECK();
-            return LLMC_OK;
-        }
-    }
     if (a.phase_len > 0) {
         LLMC_REQUIRE(a.phase_len % GK == 0 && a.epilogue == SG_SUB && !a.a_upper, "sgemm: bad phased configuration");
         if (TA && !TB) LLMC_SG(true, false, true);
