@@ -13,6 +13,6 @@ try:
 except Exception as e: print('bench failed', e); print(open('$O/bench.err').read()[-1500:])
 PY
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/ks.log 2>&1
-F=$(ls $O/ks/*/*kernel_stats.csv $O/ks/*kernel_stats.csv 2>/dev/null | head -1)
+F=$(ls $O/ks/*/*kernel_trace.csv $O/ks/*kernel_trace.csv 2>/dev/null | head -1)
 python tools/kernel_stats_csv.py $F > $O/kernel_stats.txt 2>&1; head -30 $O/kernel_stats.txt
 rm -rf $O/ks
