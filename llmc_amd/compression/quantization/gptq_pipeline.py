@@ -53,6 +53,13 @@ def factor_from_hessian(H, cfg, h_work=None):
     return perm, U
 
 
+def _inverse_permutation(perm):
+    """torch.argsort(perm) of gptq.py:186 for a permutation: one scatter instead of a radix sort (same indices)."""
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=perm.device, dtype=perm.dtype)
+    return inv
+
+
 def _prep_and_factor(H, W, perm, percdamp, h_work):
     """process_hessian_and_weights (gptq.py:128-176): dead fix, gather, damping, then U with H^-1 = U^T U. Round 5: the
     permuted matrix is gathered index-reversed (the same gather, the permutation read backwards) so that the factorisation
@@ -107,7 +114,7 @@ def quantize_stacked(W_list, H, cfg, static_qparams=None, h_work=None, want_loss
                                                cfg.static_groups, col_group, scales, zeros,
                                                want_losses=want_losses, blocksize=cfg.blocksize)
     if perm is not None:
-        invperm = torch.argsort(perm)
+        invperm = _inverse_permutation(perm)
         K4 = tmp.shape[1]
         # gptq.py:188. LDS-staged gather where the shape allows it (K % 4 == 0, K <= 40960: a row of up to 160 KB staged in LDS)
         tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= gptq_ops.GATHER_MAX_K) else tmp.index_select(1, invperm)
@@ -155,7 +162,7 @@ def quantize_owq(W, H, cfg, n_out, wquantizer, rtn_scales=None, rtn_zeros=None, 
                                                    zeros=None if cfg.symmetric else z, n_quant=n_nonout,
                                                    blocksize=cfg.blocksize)
     tmp[:, n_nonout:] = Wp[:, n_nonout:]                     # gptq.py:187: the compensated fp outlier columns
-    invperm = torch.argsort(perm)
+    invperm = _inverse_permutation(perm)
     K4 = tmp.shape[1]
     tmp = gptq_ops.gather_cols(tmp, invperm) if (K4 % 4 == 0 and K4 <= gptq_ops.GATHER_MAX_K) else tmp.index_select(1, invperm)
     return GptqResult(weight=tmp, scales=s, zeros=None if cfg.symmetric else z, perm=perm,
