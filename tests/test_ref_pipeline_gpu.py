@@ -31,6 +31,10 @@ def run_arms(tmp_path, arch, methods):
                        capture_output=True, text=True, timeout=1500)
     tb = [l for l in r.stderr.splitlines() if l.startswith('[rank0]') or 'Error' in l]
     assert r.returncode == 0, ('\n'.join(tb[-40:]), r.stdout[-800:])
+    # round 5: no product of the pipeline — calibration forwards, the evaluator's 1 x seq_len forwards through the
+    # fake-quant Linear wrappers — is handed to the vendor GEMM any more: no fallback line of llmc_amd's linear on stderr
+    fb = [l for l in r.stderr.splitlines() if l.startswith('[llmc_amd] linear')]
+    assert not fb, fb[:3]
     res = {}
     for m in methods:
         res[m] = (dict(np.load(os.path.join(out, f'ref_{m}_{arch}.npz'))), dict(np.load(os.path.join(out, f'ours_{m}_{arch}.npz'))))
