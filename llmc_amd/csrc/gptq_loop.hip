@@ -32,8 +32,9 @@ struct GptqBlockArgs {
     const float* U;       // [K, K] upper factor
     float* Wout;          // [R, K] tmp
     float* losses;        // [R, K] or null
-    float* Err;           // err of this block: Err[row * err_ld + c], c < 128
+    float* Err;           // err of this block, c < 128: Err[row * err_ld + c], or k-major (err_kmajor) Err[c * err_ld + row]
     int err_ld;
+    int err_kmajor;
     float* scales;        // [R, ng]
     float* zeros;         // [R, ng] or null (sym static)
     const int32_t* col_group;  // [K] group of processed column (static mode)
@@ -294,7 +295,7 @@ __device__ __forceinline__ bool block_fast(const GptqBlockArgs& a, const float* 
             const float d = dtab[c].x;
             a.losses[row * a.K + a.i1 + c] = (df[e] * df[e]) / (2.0f * (d * d));
         }
-        a.Err[row * a.err_ld + c] = er[e];
+        a.Err[a.err_kmajor ? (int64_t)c * a.err_ld + row : (int64_t)row * a.err_ld + c] = er[e];
     }
     if (!STATIC && p == 0) {
 #pragma unroll
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_gptq_block(GptqBlockArgs a) {
             a.Wout[row * a.K + a.i1 + c] = w[e];
             if (a.losses) a.losses[row * a.K + a.i1 + c] = ls[e];
         }
-        a.Err[row * a.err_ld + c] = (c < a.count) ? er[e] : 0.0f;
+        a.Err[a.err_kmajor ? (int64_t)c * a.err_ld + row : (int64_t)row * a.err_ld + c] = (c < a.count) ? er[e] : 0.0f;
     }
     if (!a.static_mode && p == 0) {
         // qparams of the groups that start in this block (gsz divides 128, multiple of 16)
@@ -432,7 +433,7 @@ static constexpr int GRP = 4;  // 128-column blocks per outer group (far updates
 
 extern "C" size_t llmc_gptq_quantize_ws_bytes(int64_t R, int64_t K) {
     if (R <= 0 || K <= 0) return 0;
-    return 3 * (size_t)R * BS * GRP * sizeof(float);   // err columns of three groups in flight (pipelined far updates)
+    return 3 * (size_t)((R + 3) & ~(int64_t)3) * BS * GRP * sizeof(float);   // err columns of three groups in flight (pipelined far updates)
 }
 
 extern "C" int llmc_gptq_quantize(float* W, const float* Hinv, int64_t R, int64_t K, int sym, float qmin,
@@ -471,7 +472,14 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     }
     hipStream_t caller = (hipStream_t)stream;
     const int ELD = BS * GRP;
-    float* ErrBuf[3] = {(float*)ws, (float*)ws + (size_t)R * ELD, (float*)ws + 2 * (size_t)R * ELD};   // [R, GRP*128] x 3
+    // Round 5: the error columns are kept K-MAJOR, [GRP * 128][Rp] — the fp32 GEMMs stage a k-major A panel with 16-B LDS writes,
+    // a row-major one ([R][512]) through four scalar transposing writes per float4 (square 4096: 130 vs 122 TFLOP/s). The in-block
+    // kernel's stores become 16-B segments (four rows of one column); the volume is 2 MB per block. LLMC_K4_ERR_ROWMAJOR=1: the old
+    // layout (same bits).
+    const bool ekm = getenv("LLMC_K4_ERR_ROWMAJOR") == nullptr;
+    const int64_t Rp = (R + 3) & ~(int64_t)3;
+    const int64_t err_ld = ekm ? Rp : ELD;
+    float* ErrBuf[3] = {(float*)ws, (float*)ws + (size_t)Rp * ELD, (float*)ws + 2 * (size_t)Rp * ELD};   // [R, GRP*128] or [GRP*128, Rp], x 3
     // Round 4 schedule. The caller's stream carries the CHAIN: per 128-column block the in-block kernel and the update of the
     // rest of its group's columns, per group the update of the NEXT group's columns. The `bulk` helper stream (CU-masked:
     // pipe_streams.h) carries the update of everything beyond the next group, the columns of the group after next FIRST
@@ -519,7 +527,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
             const int count = (int)(NQ - i1 < BS ? NQ - i1 : BS);
             GptqBlockArgs a;
             a.W = W; a.U = Hinv; a.Wout = Wout; a.losses = losses;
-            a.Err = Err + (i1 - g0); a.err_ld = ELD;
+            a.Err = Err + (ekm ? (i1 - g0) * Rp : (i1 - g0)); a.err_ld = (int)err_ld; a.err_kmajor = ekm ? 1 : 0;
             a.scales = scales; a.zeros = zeros; a.col_group = per_channel ? nullptr : col_group;
             a.R = R; a.K = (int)K; a.i1 = (int)i1; a.count = count; a.ng = ng; a.gsz = static_mode ? BS : gsz;
             a.static_mode = static_mode; a.sym = sym; a.qmin = qmin; a.qmax = qmax;
@@ -546,12 +554,12 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
                 // columns the loop has already visited — W is dead there (their values live in Wout)
                 const int64_t c0 = i2 & ~(int64_t)3;
                 SgemmArgs g{};
-                g.A = Err + (i1 - g0); g.lda = ELD;
+                g.A = Err + (ekm ? (i1 - g0) * Rp : (i1 - g0)); g.lda = err_ld;
                 g.B = Hinv + i1 * K + c0; g.ldb = K;
                 g.C = W + c0; g.ldc = K;
                 g.M = g.M_last = (int)R; g.N = g.N_last = (int)(near_end - c0); g.Kd = g.Kd_last = count;
                 g.epilogue = SG_SUB; g.batch = 1;
-                int rc = sgemm_launch(g, false, false, st);
+                int rc = sgemm_launch(g, ekm, false, st);
                 if (rc) return rc;
             }
         }
@@ -563,12 +571,12 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
                 if (rc) return rc;
             }
             SgemmArgs g{};
-            g.A = Err; g.lda = ELD;
+            g.A = Err; g.lda = err_ld;
             g.B = Hinv + g0 * K + gend; g.ldb = K;
             g.C = W + gend; g.ldc = K;
             g.M = g.M_last = (int)R; g.N = g.N_last = (int)(gend2 - gend); g.Kd = g.Kd_last = (int)(gend - g0);
             g.epilogue = SG_SUB; g.batch = 1; g.phase_len = BS;
-            int rc = sgemm_launch(g, false, false, st);
+            int rc = sgemm_launch(g, ekm, false, st);
             if (rc) return rc;
             C1_prev = nullptr;
             if (gend2 < K) {
@@ -584,14 +592,14 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
                 h.B = Hinv + g0 * K + gend2;
                 h.C = W + gend2;
                 h.N = h.N_last = (int)(gend3 - gend2);
-                if ((rc = sgemm_launch(h, false, false, bulk))) return rc;
+                if ((rc = sgemm_launch(h, ekm, false, bulk))) return rc;
                 if (ps && (rc = ps->record(bulk, &C1_prev))) return rc;
                 if (gend3 < K) {
                     SgemmArgs h2 = g;
                     h2.B = Hinv + g0 * K + gend3;
                     h2.C = W + gend3;
                     h2.N = h2.N_last = (int)(K - gend3);
-                    if ((rc = sgemm_launch(h2, false, false, bulk))) return rc;
+                    if ((rc = sgemm_launch(h2, ekm, false, bulk))) return rc;
                 }
                 if (ps && (rc = ps->record(bulk, &C2_hist[gidx % 3]))) return rc;
                 bulk_tail = C2_hist[gidx % 3];
