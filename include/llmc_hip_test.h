@@ -18,6 +18,15 @@ int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64
                     int c_upper_only, llmc_stream_t stream);
 int llmc_test_gemm3(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
                     int Kd, int TA, int epilogue, int a_upper, int b_upper, int c_upper_only, llmc_stream_t stream);
+/* The k-major product (TA) of llmc_test_gemm3 in the form K3's large far updates use: both operands are first split into
+ * their three bf16 planes in `ws` (6 * Kd * roundup8(max(M, N)) * 2 bytes, 16-B aligned), then multiplied by the
+ * producer / MFMA-wave kernel (gemm3.hip, k_gemm3s). M % 8 == 0, N % 8 == 0, Kd a multiple of 64 and >= 128. Returns
+ * LLMC_ENOTSUP when the shape is not eligible (too few tiles unless LLMC_GEMM3S_MIN_TILES lowers the bar). */
+int llmc_test_gemm3_planes(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
+                           int Kd, int epilogue, int c_upper_only, void* ws, llmc_stream_t stream);
+/* tools/probes/gemm3s_probe.py: the s_memtime stamps (8 waves x 128 slots, int64) one workgroup of the last k_gemm3s
+ * launch wrote under LLMC_GEMM3S_DBG=4, copied to host memory. */
+int llmc_test_gemm3s_stamps(long long* host_out);
 
 #ifdef __cplusplus
 }

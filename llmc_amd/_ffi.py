@@ -95,6 +95,8 @@ SIGNATURES = {
     'llmc_test_sgemm': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i32, _vp]),
     'llmc_test_gemm3': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'llmc_test_gemm3_planes': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'llmc_test_gemm3s_stamps': (_i32, [_vp]),
 }
 
 _lib = None

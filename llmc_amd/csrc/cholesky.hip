@@ -698,6 +698,8 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
     // the fp32 MFMA path.
     const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
     const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
+    const bool use_planes = getenv("LLMC_K3_NO_PLANES") == nullptr;
+    const size_t xbuf_bytes = (size_t)(K / 2 + NB) * (K / 2 + NB) * 4;
     // Inside an outer block the columns split into NEAR (the block's own, which the next factor step needs) and FAR (all
     // the columns to its right, needed by the later far panel solves and by the block's far update). The near panel solve
     // and near update stay on the caller's stream between the diagonal factorisations — three small latency-bound
@@ -777,15 +779,31 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
             u.C = Wk + (size_t)oend * K + oend; u.ldc = K;
             u.M = u.M_last = m1; u.N = u.N_last = nfar; u.Kd = u.Kd_last = nbo;
             u.epilogue = SG_SUB; u.c_upper_only = 1; u.batch = 1;
+            const int m2 = nfar - m1;
+            SgemmArgs v{};
+            v.A = P + m1; v.lda = K; v.B = P + m1; v.ldb = K;
+            v.C = Wk + (size_t)(oend + m1) * K + oend + m1; v.ldc = K;
+            v.M = v.M_last = m2; v.N = v.N_last = m2; v.Kd = v.Kd_last = nbo;
+            v.epilogue = SG_SUB; v.c_upper_only = 1; v.batch = 1;
+            // Large far updates: the panel P is split ONCE into its three bf16 planes (in Xbuf, which only the inverse
+            // levels use) and the products copy planes instead of splitting P again in every tile (gemm3.hip, k_gemm3s).
+            // Same planes, same MFMA order: the factor is bit-identical either way. The previous block's side update
+            // (which reads the previous planes) was joined above.
+            if (use_x3 && use_planes && nfar % 8 == 0 && (size_t)3 * nbo * nfar * 2 <= xbuf_bytes) {
+                SgemmArgs w = m2 > 0 ? v : u;
+                w.planesA = w.planesB = Xbuf; w.ldp = nfar; w.plane_stride = (int64_t)nbo * nfar;
+                if (gemm3_uses_planes(w)) {
+                    int rc = gemm3_split_planes(P, K, nbo, nfar, Xbuf, nfar, (int64_t)nbo * nfar, st);
+                    if (rc) return rc;
+                    u.planesA = u.planesB = Xbuf;
+                    v.planesA = v.planesB = (const uint16_t*)Xbuf + m1;
+                    u.ldp = v.ldp = nfar;
+                    u.plane_stride = v.plane_stride = (int64_t)nbo * nfar;
+                }
+            }
             int rc = use_x3u ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
             if (rc) return rc;
-            const int m2 = nfar - m1;
             if (m2 > 0) {
-                SgemmArgs v{};
-                v.A = P + m1; v.lda = K; v.B = P + m1; v.ldb = K;
-                v.C = Wk + (size_t)(oend + m1) * K + oend + m1; v.ldc = K;
-                v.M = v.M_last = m2; v.N = v.N_last = m2; v.Kd = v.Kd_last = nbo;
-                v.epilogue = SG_SUB; v.c_upper_only = 1; v.batch = 1;
                 if (side) {
                     rc = fork_to_side(side, st);   // P is final on main at this point
                     if (rc) return rc;

@@ -32,6 +32,11 @@ struct SgemmArgs {
     int64_t sA, sB, sC;
     int batch;
     int M_last, N_last, Kd_last;
+    // gemm3 only (k-major A and B): the operands already split into bf16 planes (gemm3_split_planes) — hi | mid | lo planes of
+    // `plane_stride` elements each, row stride ldp, pointing at the operand's first column. nullptr = split in the kernel.
+    const void* planesA;
+    const void* planesB;
+    int64_t ldp, plane_stride;
 };
 
 // launches on `st`; returns LLMC_* status
@@ -42,6 +47,10 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st);
 int gemm3_tn_launch(const SgemmArgs& a, hipStream_t st);
 // general form: TA as in sgemm_launch, op(B) = N; hints a_upper / a_lower / b_upper / c_upper_only, all epilogues, batch
 int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st);
+// true when gemm3_launch(a, true, ..) would run the planes form for these arguments (a.planesA set): split only then
+bool gemm3_uses_planes(const SgemmArgs& a);
+// hi | mid | lo bf16 planes of a k-major fp32 panel [rows x n] (n % 8 == 0): planes + t * plane_stride + r * ldp + c
+int gemm3_split_planes(const float* P, int64_t ld, int rows, int n, void* planes, int64_t ldp, int64_t plane_stride, hipStream_t st);
 
 // C [M, N] = sign * A B (A [M, Kd] row-major, B [Kd, N] k-major, fp32) with the same three-bf16-term arithmetic on the
 // one-wave-per-SIMD GEMM of linear_eval.hip: operands split ONCE into k-tiled stacked planes. For the large, deep levels of

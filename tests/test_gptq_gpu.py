@@ -100,6 +100,78 @@ def test_gemm3_split_bf16_matches_fp32_accuracy(shape, TA):
         assert torch.equal(Cu[iu], C3[iu])
 
 
+@pytest.mark.parametrize('shape', [(256, 128, 128), (512, 640, 512), (1000, 776, 192), (260, 132, 256), (1024, 1024, 512),
+                                   (768, 768, 128)])
+def test_gemm3_specialised_kernel_is_bit_identical(shape, monkeypatch):
+    """k_gemm3s (producer waves split the panels, MFMA waves multiply; range-checked buffer loads two K-steps ahead) against
+    k_gemm3 (LLMC_GEMM3_NOSPEC=1): same bits for every epilogue and for the upper-only form, on panels that sit inside a
+    larger poisoned matrix (anything read beyond a panel's rows or columns would show), and nothing written outside C's
+    upper part when only that is asked for."""
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M * 7 + Kd)
+    ld = 2304
+    big = torch.full((Kd + 64, ld), float('nan'))
+    big[:Kd, 8:8 + M] = torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))
+    big[:Kd, 1200:1200 + N] = torch.randn(Kd, N, generator=gen)
+    big = big.cuda()
+    A = big[:, 8:]
+    B = big[:, 1200:]
+    C0 = torch.randn(M, N, generator=gen).cuda()
+    monkeypatch.setenv('LLMC_GEMM3S_MIN_TILES', '1')
+    for epi in (0, 1, 2):
+        for hints in ((0, 0, 0), (0, 0, 1)) if M == N else ((0, 0, 0),):
+            monkeypatch.delenv('LLMC_GEMM3_NOSPEC', raising=False)
+            c_new = gemm3(A, B, C0.clone(), M, N, Kd, True, epi, hints)
+            monkeypatch.setenv('LLMC_GEMM3_NOSPEC', '1')
+            c_old = gemm3(A, B, C0.clone(), M, N, Kd, True, epi, hints)
+            if hints[2]:
+                iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
+                assert torch.equal(c_new[iu], c_old[iu]), (epi, hints)
+                # 128 x 128 blocks strictly below the diagonal blocks are untouched by both
+                blk = (torch.arange(M)[:, None] // 128 > torch.arange(N)[None, :] // 128).cuda()
+                assert torch.equal(c_new[blk], C0[blk])
+            else:
+                assert not torch.isnan(c_new).any()
+                assert torch.equal(c_new, c_old), (epi, hints)
+
+
+@pytest.mark.parametrize('shape', [(256, 128, 128), (512, 640, 512), (1000, 776, 192), (264, 136, 256), (1024, 1024, 512)])
+def test_gemm3_planes_form_is_bit_identical(shape, monkeypatch):
+    """The far updates' form with the panels split once into bf16 planes in memory (k_split3_planes + k_gemm3s copying
+    planes) against k_gemm3 splitting inside every tile: same bits, every epilogue, upper-only included."""
+    from llmc_amd import _ffi
+    L = _ffi.lib()
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M * 5 + Kd)
+    ld = 2304
+    big = torch.full((Kd + 64, ld), float('nan'))
+    big[:Kd, 8:8 + M] = torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))
+    big[:Kd, 1200:1200 + N] = torch.randn(Kd, N, generator=gen)
+    big = big.cuda()
+    A = big[:, 8:]
+    B = big[:, 1200:]
+    C0 = torch.randn(M, N, generator=gen).cuda()
+    ldp = (max(M, N) + 7) // 8 * 8
+    ws = torch.full((6 * Kd * ldp,), -1, dtype=torch.int16).cuda()
+    monkeypatch.setenv('LLMC_GEMM3S_MIN_TILES', '1')
+    for epi in (0, 1, 2):
+        for upper in (0, 1) if M == N else (0,):
+            monkeypatch.delenv('LLMC_GEMM3_NOSPEC', raising=False)
+            c_new = C0.clone()
+            _ffi.check(L.llmc_test_gemm3_planes(A.data_ptr(), B.data_ptr(), c_new.data_ptr(), A.stride(0), B.stride(0), c_new.stride(0),
+                                                M, N, Kd, epi, upper, ws.data_ptr(), _ffi.stream()), 'gemm3 planes')
+            monkeypatch.setenv('LLMC_GEMM3_NOSPEC', '1')
+            c_old = gemm3(A, B, C0.clone(), M, N, Kd, True, epi, (0, 0, upper))
+            if upper:
+                iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
+                assert torch.equal(c_new[iu], c_old[iu]), (epi, upper)
+                blk = (torch.arange(M)[:, None] // 128 > torch.arange(N)[None, :] // 128).cuda()
+                assert torch.equal(c_new[blk], C0[blk])
+            else:
+                assert not torch.isnan(c_new).any()
+                assert torch.equal(c_new, c_old), (epi, upper)
+
+
 def test_gemm3_triangular_hints_do_not_change_results():
     n = 384
     gen = torch.Generator().manual_seed(3)
