@@ -435,6 +435,24 @@ def test_chol_inv_upper_vs_fp64(K):
     assert E.abs().max() < 5e-3
 
 
+@pytest.mark.parametrize('K', [4096, 5000])
+def test_chol_inv_upper_far_updates_on_planes_keep_every_bit(K, monkeypatch):
+    """K3 with the large far updates on pre-split planes (the default) against the same factorisation with k_gemm3 splitting
+    inside every tile (LLMC_K3_NO_PLANES=1): the factor is the same to the last bit. K = 5000: far widths that are multiples
+    of 8 but not of 128 (ragged last tiles)."""
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
+    gen = torch.Generator().manual_seed(K + 1)
+    X = torch.randn(2 * K, K, generator=gen)
+    X[:, ::5] *= 4
+    H = ((X.T @ X) / K).cuda()
+    H += 0.01 * H.diag().mean() * torch.eye(K, device='cuda')
+    monkeypatch.delenv('LLMC_K3_NO_PLANES', raising=False)
+    u_planes = chol_inv_upper(H.clone())
+    monkeypatch.setenv('LLMC_K3_NO_PLANES', '1')
+    u_plain = chol_inv_upper(H.clone())
+    assert torch.equal(u_planes, u_plain)
+
+
 def test_hessian_prep_vs_oracle():
     from llmc_amd.compression.quantization.gptq_ops import hessian_prep
     g = load_golden('gptq')
