@@ -699,6 +699,7 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
     const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
     const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
     const bool use_planes = getenv("LLMC_K3_NO_PLANES") == nullptr;
+    const bool merge_far = getenv("LLMC_K3_SPLIT_FAR") == nullptr;
     const size_t xbuf_bytes = (size_t)(K / 2 + NB) * (K / 2 + NB) * 4;
     // Inside an outer block the columns split into NEAR (the block's own, which the next factor step needs) and FAR (all
     // the columns to its right, needed by the later far panel solves and by the block's far update). The near panel solve
@@ -789,8 +790,13 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
             // levels use) and the products copy planes instead of splitting P again in every tile (gemm3.hip, k_gemm3s).
             // Same planes, same MFMA order: the factor is bit-identical either way. The previous block's side update
             // (which reads the previous planes) was joined above.
+            // Without a helper stream the two parts are ONE product: the upper triangle of the whole trailing matrix (u's tiles
+            // are the first two tile rows of it, v's start at row and column 512 = whole tiles): one launch less per outer block
+            // and u's 216 tiles no longer run as a round of their own. Same tiles, same arithmetic.
+            const bool merged = !side && use_x3 && use_x3u && m2 > 0 && merge_far;
+            if (merged) u.M = u.M_last = nfar;
             if (use_x3 && use_planes && nfar % 8 == 0 && (size_t)3 * nbo * nfar * 2 <= xbuf_bytes) {
-                SgemmArgs w = m2 > 0 ? v : u;
+                SgemmArgs w = merged ? u : (m2 > 0 ? v : u);
                 w.planesA = w.planesB = Xbuf; w.ldp = nfar; w.plane_stride = (int64_t)nbo * nfar;
                 if (gemm3_uses_planes(w)) {
                     int rc = gemm3_split_planes(P, K, nbo, nfar, Xbuf, nfar, (int64_t)nbo * nfar, st);
@@ -803,7 +809,7 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
             }
             int rc = use_x3u ? gemm3_tn_launch(u, st) : sgemm_launch(u, true, false, st);
             if (rc) return rc;
-            if (m2 > 0) {
+            if (m2 > 0 && !merged) {
                 if (side) {
                     rc = fork_to_side(side, st);   // P is final on main at this point
                     if (rc) return rc;

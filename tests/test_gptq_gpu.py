@@ -451,6 +451,21 @@ def test_chol_inv_upper_far_updates_on_planes_keep_every_bit(K, monkeypatch):
     monkeypatch.setenv('LLMC_K3_NO_PLANES', '1')
     u_plain = chol_inv_upper(H.clone())
     assert torch.equal(u_planes, u_plain)
+    # the far update of an outer block as two launches (next block's rows, the rest) instead of one, and with the library's
+    # helper streams (always two launches, the second beside the next block's chain)
+    monkeypatch.delenv('LLMC_K3_NO_PLANES', raising=False)
+    monkeypatch.setenv('LLMC_K3_SPLIT_FAR', '1')
+    assert torch.equal(chol_inv_upper(H.clone()), u_planes)
+    monkeypatch.delenv('LLMC_K3_SPLIT_FAR', raising=False)
+    from llmc_amd import _ffi
+    prev = _ffi.lib().llmc_hip_set_helper_streams(0)
+    try:
+        u_single = chol_inv_upper(H.clone())
+        _ffi.lib().llmc_hip_set_helper_streams(1)
+        u_helper = chol_inv_upper(H.clone())
+    finally:
+        _ffi.lib().llmc_hip_set_helper_streams(prev)
+    assert torch.equal(u_single, u_planes) and torch.equal(u_helper, u_planes)
 
 
 def test_hessian_prep_vs_oracle():
