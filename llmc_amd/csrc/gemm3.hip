@@ -9,6 +9,10 @@
 // fp32 rounding. Six v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each)
 // per 32x32x16 block: 2.7x fewer matrix-pipe cycles for fp32-level accuracy.
 //
+// Two kernels: k_gemm3 (128 x 128 tiles, every wave splits and multiplies: the small and the hinted products) and, for the
+// factorisation's large far updates, k_gemm3s (256 x 128 tiles, producer waves / MFMA waves, operands split once into bf16
+// planes by k_split3_planes) — same terms, same MFMA order, same bits; see the comment above k_gemm3s for the measurements.
+//
 // Layout: both operands are k-major in memory ([Kd x M], [Kd x N], row stride ld) — the shape of the Cholesky panel
 // P in `T -= P^T P`. A workgroup owns a 128x128 tile; per K-step of 32 it stages both 32x128 panels through
 // registers (split there) into three bf16 planes each, k-major in LDS exactly like hessian_syrk.hip's token-major
@@ -569,10 +573,12 @@ static bool gemm3s_eligible(const SgemmArgs& a) {
     if (getenv("LLMC_GEMM3_NOSPEC")) return false;
     if (a.a_upper || a.a_lower || a.b_upper) return false;
     if ((((uintptr_t)a.C) & 15) || a.ldc % 4 || a.sC % 4) return false;            // 16-B accesses to C
+    if ((int64_t)S_BM * a.ldc * 4 >= (int64_t)0x7fffff00) return false;             // 32-bit offsets inside a C tile
     const int64_t kd = a.Kd > a.Kd_last ? a.Kd : a.Kd_last;
     const bool pre = a.planesA != nullptr;
     if (a.Kd % (2 * G3K) || a.Kd_last % (2 * G3K) || a.Kd < 4 * G3K || a.Kd_last < 4 * G3K) return false;   // an even number of K-steps, >= 4
     if (pre) {
+        if (a.batch != 1) return false;                                             // the planes of ONE panel
         if (a.ldp % 8 || a.plane_stride % 8 || (((uintptr_t)a.planesA | (uintptr_t)a.planesB) & 15)) return false;
         if ((2 * a.plane_stride + (kd + G3K) * a.ldp) * 2 >= (int64_t)0x7fffff00) return false;
     } else {
