@@ -488,6 +488,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     // still arrive in the reference's order (block 0, 1, 2, ...: bulk stream order, then the chain behind C1), from the
     // same kernels on the same tile grid: bit-identical to one stream (LLMC_NO_SIDE_STREAM=1), which tests compare.
     PipeStreams* ps = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : pipe_streams_for(caller);
+    const bool merge_far = getenv("LLMC_K4_SPLIT_FAR") == nullptr;
     hipStream_t st = ps ? pipe_chain_stream(ps, caller) : caller;
     hipStream_t bulk = ps ? ps->bulk : st;
     if (ps) {
@@ -576,10 +577,16 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
             g.C = W + gend; g.ldc = K;
             g.M = g.M_last = (int)R; g.N = g.N_last = (int)(gend2 - gend); g.Kd = g.Kd_last = (int)(gend - g0);
             g.epilogue = SG_SUB; g.batch = 1; g.phase_len = BS;
+            // Without helper streams the three column ranges of the group's far update (the next group's columns, the group
+            // after next, the rest) are one product on one stream: ONE launch over [gend, K). Column tiles are independent and
+            // every kernel the GEMM may pick computes an element the same way (one accumulator per phase from +0 in ascending k,
+            // then one rounding C - acc): same bits, two launches less per group and no half-empty 128-workgroup grids.
+            const bool one_far = !ps && merge_far;
+            if (one_far) g.N = g.N_last = (int)(K - gend);
             int rc = sgemm_launch(g, ekm, false, st);
             if (rc) return rc;
             C1_prev = nullptr;
-            if (gend2 < K) {
+            if (gend2 < K && !one_far) {
                 if (ps) {
                     hipEvent_t e = nullptr;       // this group's err columns are complete on the chain
                     if ((rc = ps->record(st, &e))) return rc;
