@@ -86,6 +86,24 @@ class Awq(BaseBlockwiseQuantization):
             return awq_ops.scale_fakequant(w0, cols, self.wquantizer)
         return self.wquantizer.fake_quant_weight_dynamic(awq_ops.mul_cols_(w0.clone(), cols))
 
+    @torch.no_grad()
+    def scaling_weight(self, w, scales, is_gqa):
+        """awq.py:40-46: w *= scales[None, :] in place (per key/value channel repeated per query-head group under GQA)."""
+        cols = self.repeat_gqa_scales(scales) if is_gqa else scales
+        return awq_ops.mul_cols_(w, cols.reshape(-1).to(w.dtype).contiguous())
+
+    @torch.no_grad()
+    def fake_quantize_weight(self, fc, scales, is_gqa, layer_name):
+        """awq.py:147-164: fc.weight.data <- fakequant(fc.weight.data * scales) (a block-wise FP8 checkpoint weight is
+        de-blocked, scaled, fake-quantized and re-blocked together with weight_scale_inv); returns fc.weight. The tensor
+        fc.weight.data pointed at before the call is left untouched (the reference scales it in place and then drops it)."""
+        cols = (self.repeat_gqa_scales(scales) if is_gqa else scales).reshape(-1).contiguous()
+        if self._is_fp8(fc):
+            fc.weight.data, fc.weight_scale_inv.data = self._fake_quantize_weight(fc.weight.data, cols, fc.weight_scale_inv.data)
+        else:
+            fc.weight.data = self._fake_quantize_weight(fc.weight.data, cols)
+        return fc.weight
+
     def fake_quantize_input(self, x_tmp, layers_dict=None):
         """awq.py:166-177: dynamic activation fake-quant of the scaled input — the whole batch when it is one awq_bs
         batch, else sample by sample (a per_tensor range is then per sample)."""
@@ -216,11 +234,8 @@ class Awq(BaseBlockwiseQuantization):
                     else:
                         scales = awq_ops.awq_scales(self._act_scale_batched(x), w_max, ratio, self.trans_version)
                         cols = scales
-                    for fc, w0, s0 in zip(layers, org_w, org_s):      # fake_quantize_weight (awq.py:147-164)
-                        if s0 is not None:
-                            fc.weight.data, fc.weight_scale_inv.data = self._fake_quantize_weight(w0, cols, s0)
-                        else:
-                            fc.weight.data = self._fake_quantize_weight(w0, cols)
+                    for lname, fc in layers_dict.items():             # awq.py:218-219; fc.weight.data is the original here
+                        self.fake_quantize_weight(fc, scales, is_gqa, lname)
                     x_tmp = awq_ops.div_cols(x, cols)     # scaling_input (base_blockwise_quantization.py:877-889)
                     if not self.w_only:
                         x_tmp = self.fake_quantize_input(x_tmp, layers_dict)      # awq.py:223-224

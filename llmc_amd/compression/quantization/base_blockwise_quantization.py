@@ -288,60 +288,21 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
             h.remove()
         return feat
 
-    # ---- static activation qparams (base_…:567-588; quant.py:253-263 static_minmax) ------------------
+    # ---- static activation qparams (base_…:567-588): ranges from the quantizer (quant.py:561-586), one entry per input ----
     @torch.no_grad()
     def register_act_qparams(self, layers_dict, act_tensors):
-        if len(act_tensors) == 1:
-            samples = [act_tensors[0][i] for i in range(act_tensors[0].shape[0])]
-        else:
-            samples = list(act_tensors)
-        aq = self.aquantizer
-        algo = getattr(aq, 'calib_algo', 'static_minmax')
-        if algo == 'static_moving_minmax':
-            # quant.py:524-543: exponential moving average of the per-sample ranges (alpha = 0.01, the default of
-            # get_batch_tensors_qparams), in the sample dtype like the reference. The per-sample min / max come from one
-            # kernel pass (hist_range.sample_minmax); the recurrence runs on the host on 0-dim tensors of the sample dtype —
-            # the arithmetic the reference performs on its (CPU) scalars
-            from .hist_range import sample_minmax
-            alpha = 0.01
-            smn, smx = sample_minmax(samples)
-            smn, smx = smn.cpu().to(samples[0].dtype), smx.cpu().to(samples[0].dtype)
-            mn = mx = None
-            for a, b in zip(smn, smx):
-                mn, mx = (a, b) if mn is None else (mn + alpha * (a - mn), mx + alpha * (b - mx))
-            mn, mx = mn.to(samples[0].device), mx.to(samples[0].device)
-        elif algo == 'static_minmax':
-            # quant.py:253-263: mean over samples of per-sample min / max (fp32), then get_qparams on the means
-            from .hist_range import sample_minmax
-            smn, smx = sample_minmax(samples)
-            mx, mn = smx.mean(), smn.mean()
-        elif algo == 'static_hist':
-            # quant.py:462-512 (+ get_batch_tensors_qparams' assert, :564-568): histogram-observer range, data pass in HIP
-            assert aq.sym is True and aq.granularity == 'per_tensor', \
-                'Only support per tensor static symmetric int quantize.'
-            from .hist_range import static_hist_range
-            lo, hi = static_hist_range(samples, aq.bins, aq.upsample_rate, aq.bit)
-            mn = torch.tensor(lo, dtype=torch.float32, device=samples[0].device)
-            mx = torch.tensor(hi, dtype=torch.float32, device=samples[0].device)
-        else:
-            raise ValueError(f'Unsupported calibration algorithm: {algo}')      # quant.py:573-574, 'minmax' (the default) included
-        qmax, qmin = aq.qmax.to(mx.device), aq.qmin.to(mx.device)
-        abs_max = torch.max(mx.abs(), mn.abs()).clamp(min=1e-5)
-        if aq.sym:
-            scales = abs_max / qmax
-            zeros = torch.tensor(0.0, device=mx.device)
-        else:
-            scales = (mx - mn).clamp(min=1e-5) / (qmax - qmin)
-            zeros = (qmin - torch.round(mn / scales)).clamp(qmin, qmax)
-        if _world() > 1:
-            dist.all_reduce(scales, op=dist.ReduceOp.SUM)
-            scales = scales / _world()
-        for layer in layers_dict.values():
-            if isinstance(layer, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)):
-                layer.register_buffer('buf_act_scales_0', scales)
-                layer.register_buffer('buf_act_zeros_0', zeros)
-                layer.register_buffer('buf_act_qmin_0', qmin)
-                layer.register_buffer('buf_act_qmax_0', qmax)
+        scales_list, zeros_list, qmin_list, qmax_list = self.aquantizer.get_batch_tensors_qparams(act_tensors)
+        for i, (scales, zeros, qmin, qmax) in enumerate(zip(scales_list, zeros_list, qmin_list, qmax_list)):
+            dev = scales.device
+            if _world() > 1:
+                dist.all_reduce(scales, op=dist.ReduceOp.SUM)
+                scales = scales / _world()
+            for layer in layers_dict.values():
+                if isinstance(layer, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_)):
+                    layer.register_buffer(f'buf_act_scales_{i}', scales)
+                    layer.register_buffer(f'buf_act_zeros_{i}', zeros.to(dev))
+                    layer.register_buffer(f'buf_act_qmin_{i}', qmin.to(dev))
+                    layer.register_buffer(f'buf_act_qmax_{i}', qmax.to(dev))
 
     # ---- scale folding (base_…:597-611, 632-700, 750-778) ---------------------------------------------
     @torch.no_grad()

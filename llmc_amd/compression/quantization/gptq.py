@@ -12,6 +12,9 @@ per-batch all_reduce of H — with several ranks (data-parallel calibration) H i
 sequences; no `.item()` sync per layer. OWQ (gptq.py:44-50, 66-83): the floating-point columns ride through the same
 column loop (`quantize_owq`, llmc_gptq_quantize_cols).
 """
+import copy
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -223,6 +226,11 @@ class GPTQ(BaseBlockwiseQuantization):
     def subset_transform(self, subset, input_feat, subset_kwargs):
         layers_dict = {n: l for n, l in subset['layers'].items()
                        if isinstance(l, tuple(_LLMC_LINEAR_TYPES_ + _TRANSFORMERS_LINEAR_TYPES_))}
+        if self._overrides_reference_hooks():        # a subclass written against the reference's per-layer methods
+            for n, l in layers_dict.items():
+                self.layer_transform_reference(l, n)
+                self.free(n)
+            return
         for gid in {self._group_of[n] for n in layers_dict}:
             self._settle_group(gid)
         by_group = {}
@@ -236,6 +244,8 @@ class GPTQ(BaseBlockwiseQuantization):
 
     @torch.no_grad()
     def layer_transform(self, layer, name):
+        if self._overrides_reference_hooks():
+            return self.layer_transform_reference(layer, name)
         self._settle_group(self._group_of[name])
         gid = self._group_of[name]
         self._sync_hessian(gid)
@@ -299,6 +309,217 @@ class GPTQ(BaseBlockwiseQuantization):
                 l.buf_scales = r.scales.reshape(-1, 1).clone()        # merge_qparams: [R * K/g, 1] fp32
                 if not self.wquantizer.sym:
                     l.buf_zeros = r.zeros.reshape(-1, 1).clone()
+
+    # ================================================================================================================
+    # The reference's per-layer method surface (gptq.py:58-83, 119-244, 333-409) — same names, arguments, return values
+    # and in-place effects, arithmetic on the same HIP entry points the stacked path uses. `main()` never needs them
+    # (subset_transform above runs a whole subset through ONE Hessian / factor / column loop); they exist for callers
+    # and subclasses written against llmc's class: a subclass that overrides any of them is routed through the
+    # reference's per-layer flow (`layer_transform_reference`) so that its override is honoured.
+    # ================================================================================================================
+    _REFERENCE_HOOKS = ('hessian_sorting', 'initialize_qparams_and_prepare_weights', 'process_hessian_and_weights',
+                        'update_layer_with_transformed_weights', 'weight_transform', 'search_column_qparams',
+                        'search_layer_qparams', 'search_group_qparams', 'split_qparams', 'merge_qparams',
+                        'update_model_qparams', 'ready')
+
+    def _overrides_reference_hooks(self):
+        """True when a class outside this package (a maintainer's subclass) defines one of the reference-named hooks."""
+        for h in self._REFERENCE_HOOKS:
+            f = getattr(type(self), h, None)
+            if f is not None and not (getattr(f, '__module__', '') or '').startswith('llmc_amd.'):
+                return True
+        return False
+
+    def _hessian_of(self, name):
+        """The layer's Hessian with every pending sample folded in (and reduced over the ranks)."""
+        gid = self._group_of[name]
+        self._settle_group(gid)
+        self._sync_hessian(gid)
+        return self._groups[self._group_of[name]]['acc'].H
+
+    def hessian_sorting(self, name):
+        """gptq.py:58-83: `self.perm` — actorder: columns by descending diag(H); OWQ: the non-outlier columns in their
+        original order, then the n_out columns with the largest diagonal."""
+        H = self._hessian_of(name)
+        if not self.owq:
+            if self.actorder:
+                self.perm = torch.argsort(torch.diag(H), descending=True)
+            return
+        self.perm = owq_permutation(torch.diagonal(H), int(self.n_out))
+
+    def initialize_qparams_and_prepare_weights(self, layer, name):
+        """gptq.py:119-126."""
+        self.qparams = {}
+        self.columns = self.layers_cache[name]['columns']
+        self.n_out = int(self.n_out_dict[name]) if self.owq else 0
+        self.n_nonout = self.columns - self.n_out
+        self.dev = layer.weight.device
+        if self.actorder or self.owq:
+            self.hessian_sorting(name)
+
+    def process_hessian_and_weights(self, layer, name):
+        """gptq.py:128-176 -> (W, H): W fp32 [R, K] with the dead columns zeroed and the columns permuted, H the upper
+        factor U with (H_perm + damp I)^-1 = U^T U (llmc_hessian_prep + llmc_chol_inv_upper: one reverse Cholesky and one
+        triangular inverse instead of cholesky -> cholesky_inverse -> cholesky(upper)). Raises like torch.linalg.cholesky
+        when the damped Hessian is not positive definite. The shared accumulator keeps its Hessian (the reference deletes
+        the per-layer copy): other layers of the subset read the same matrix."""
+        W = layer.weight.data
+        if W.dim() > 2:
+            W = W.flatten(1)
+        elif type(layer).__name__ == 'Conv1D':
+            W = W.t()
+        H = self._hessian_of(name)
+        if not self.ready():
+            if self.wquantizer.granularity == 'per_group':
+                self.groups = []
+                self.search_group_qparams(layer)
+            else:
+                self.search_layer_qparams(layer)
+        perm = self.perm if (self.actorder or self.owq) else None
+        Hp, Wp = gptq_ops.hessian_prep(H, W.contiguous(), perm, self.percdamp, want_h=True)
+        if perm is not None:
+            self.invperm = torch.argsort(self.perm)
+            layer.register_buffer('buf_perm', self.perm)
+            layer.register_buffer('buf_invperm', self.invperm)
+            if self.owq:
+                layer.register_buffer('buf_n_nonout', torch.tensor(self.n_nonout))
+                if self.wquantizer.granularity == 'per_channel':
+                    _, layer.buf_scales, layer.buf_zeros, _, _ = self.wquantizer.get_tensor_qparams(
+                        Wp[:, :self.n_nonout].contiguous())
+                    self.qparams['scale'], self.qparams['zero'] = layer.buf_scales, layer.buf_zeros
+        U = gptq_ops.chol_inv_upper(Hp, check=True)
+        return Wp, U
+
+    def update_layer_with_transformed_weights(self, layer, W, H, name):
+        """gptq.py:178-197."""
+        Losses = torch.zeros_like(W)
+        tmp = torch.zeros_like(W)
+        self.weight_transform(W, H, Losses, tmp)
+        self.last_losses = getattr(self, 'last_losses', {})
+        self.last_losses[name] = Losses.sum()
+        if self.actorder or self.owq:
+            tmp[:, self.n_nonout:] = W[:, self.n_nonout:]
+            tmp = gptq_ops.gather_cols(tmp, self.invperm) if (tmp.shape[1] % 4 == 0 and tmp.shape[1] <= gptq_ops.GATHER_MAX_K) \
+                else tmp[:, self.invperm]
+        if type(layer).__name__ == 'Conv1D':
+            tmp = tmp.t()
+        layer.weight.data = tmp.reshape(layer.weight.shape)
+        if self.wquantizer.granularity == 'per_group' and not self.static_groups:
+            self.update_model_qparams(layer)
+
+    @torch.no_grad()
+    def weight_transform(self, W, Hinv, Losses, tmp):
+        """gptq.py:199-244, the blocked column loop (llmc_gptq_quantize_cols). In place like the reference: `tmp` receives
+        the error-compensated weight of every visited column, `Losses` its loss, `W` the running weights — its columns
+        from n_nonout on (OWQ's floating-point columns) end with every block's feedback applied, which is what the caller
+        reads (gptq.py:187); the visited columns of W are scratch afterwards (the reference leaves each block's columns at
+        their value before the block was entered). Uses self.n_nonout / columns / perm / qparams / groups as the reference
+        does: dynamic groups (per_group without static_groups) write `self.groups[g]` and `self.qparams` at every group
+        start (search_column_qparams, gptq.py:359-366), static groups read `self.groups`, per_channel reads `self.qparams`."""
+        wq = self.wquantizer
+        per_group = wq.granularity == 'per_group'
+        gs = int(wq.group_size) if per_group else 0
+        R, K = W.shape
+        n_nonout = int(getattr(self, 'n_nonout', K))
+        qmin, qmax = float(wq.qmin), float(wq.qmax)
+        dynamic = per_group and not self.static_groups
+        col_group = scales = zeros = init_s = init_z = None
+        if dynamic:
+            groups = getattr(self, 'groups', None)
+            if groups and n_nonout < K:      # OWQ: groups the loop never visits keep their RTN qparams (gptq.py:380-395)
+                init_s = torch.cat([g['scale'].reshape(R, 1).float() for g in groups], 1)
+                if not wq.sym:
+                    init_z = torch.cat([g['zero'].reshape(R, 1).float() for g in groups], 1)
+        elif per_group:
+            scales = torch.cat([g['scale'].reshape(R, 1).float() for g in self.groups], 1)
+            if not wq.sym:
+                zeros = torch.cat([g['zero'].reshape(R, 1).float() for g in self.groups], 1)
+            idx = self.perm if self.actorder else torch.arange(K, device=W.device)
+            col_group = (idx // gs).to(torch.int32)
+        else:
+            scales = self.qparams['scale'].reshape(R, 1).float()
+            if not wq.sym:
+                zeros = self.qparams['zero'].reshape(R, 1).float()
+        if not W.is_contiguous():
+            raise ValueError('GPTQ.weight_transform: W must be contiguous (it is updated in place)')
+        t, l, s, z = gptq_ops.gptq_quantize(W, Hinv.contiguous(), wq.sym, qmin, qmax, gs, self.static_groups, col_group, scales,
+                                            zeros, want_losses=True, blocksize=self.blocksize,
+                                            n_quant=n_nonout if n_nonout < K else None, init_scales=init_s, init_zeros=init_z)
+        tmp.copy_(t)
+        Losses.copy_(l)
+        if dynamic:
+            ng = s.shape[1]
+            if not isinstance(getattr(self, 'groups', None), list) or len(self.groups) < ng:
+                self.groups = list(getattr(self, 'groups', None) or []) + [None] * (ng - len(getattr(self, 'groups', None) or []))
+            qmax_t, qmin_t = wq.qmax.to(W.device), wq.qmin.to(W.device)
+            for g in range(-(-n_nonout // gs)):          # the groups the loop visited
+                self.groups[g] = {'scale': s[:, g:g + 1].clone(), 'zero': torch.tensor(0.0) if wq.sym else z[:, g:g + 1].clone(),
+                                  'qmax': qmax_t, 'qmin': qmin_t}
+            if n_nonout > 0:
+                self.qparams = dict(self.groups[-(-n_nonout // gs) - 1])
+
+    @torch.no_grad()
+    def layer_transform_reference(self, layer, name):
+        """gptq.py:113-117: the reference's per-layer flow through the methods above."""
+        self.initialize_qparams_and_prepare_weights(layer, name)
+        W, H = self.process_hessian_and_weights(layer, name)
+        self.update_layer_with_transformed_weights(layer, W, H, name)
+
+    # ---- qparam bookkeeping (gptq.py:333-409) ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def split_qparams(self, qparams):
+        group_num = math.ceil(self.columns / self.wquantizer.group_size)
+        qparams = qparams.reshape(math.ceil(qparams.shape[0] / group_num), -1).t()
+        return [q.reshape(-1, 1) for q in torch.split(qparams, 1, dim=0)]
+
+    @torch.no_grad()
+    def merge_qparams(self, qparams):
+        if isinstance(qparams, int):
+            return qparams
+        if self.wquantizer.granularity == 'per_head':
+            head_size = self.rows // self.head_num
+            qparams = qparams.t().repeat(head_size, 1).t().reshape(-1, 1)
+        elif self.wquantizer.granularity == 'per_group':
+            qparams = torch.stack(qparams, dim=1).reshape(-1, 1)
+        return qparams
+
+    @torch.no_grad()
+    def search_column_qparams(self, c_tensor, idx):
+        """gptq.py:359-366: min/max qparams of one column group (llmc_minmax_qparams), kept as `self.qparams` and in
+        `self.groups[idx // group_size]`."""
+        _, scale, zero, qmax, qmin = self.wquantizer.get_tensor_qparams(c_tensor.contiguous())
+        self.qparams = {'scale': scale, 'zero': zero, 'qmax': qmax, 'qmin': qmin}
+        self.groups[idx // self.wquantizer.group_size] = copy.deepcopy(self.qparams)
+
+    @torch.no_grad()
+    def search_layer_qparams(self, layer):
+        scales, zeros = self.merge_qparams(layer.buf_scales), layer.buf_zeros
+        if not self.wquantizer.sym:
+            zeros = self.merge_qparams(zeros)
+        self.qparams['scale'], self.qparams['zero'] = scales, zeros
+        self.qparams['qmax'], self.qparams['qmin'] = layer.buf_qmax, layer.buf_qmin
+
+    @torch.no_grad()
+    def search_group_qparams(self, layer):
+        self.group_scales = self.split_qparams(layer.buf_scales)
+        if not self.wquantizer.sym:
+            self.group_zeros = self.split_qparams(layer.buf_zeros)
+        for i in range(len(self.group_scales)):
+            self.groups.append({'scale': self.group_scales[i],
+                                'zero': self.group_zeros[i] if not self.wquantizer.sym else torch.tensor(0.0),
+                                'qmax': layer.buf_qmax, 'qmin': layer.buf_qmin})
+
+    @torch.no_grad()
+    def update_model_qparams(self, layer):
+        layer.buf_scales = copy.deepcopy(self.merge_qparams([g['scale'] for g in self.groups]))
+        if not self.wquantizer.sym:
+            layer.buf_zeros = copy.deepcopy(self.merge_qparams([g['zero'] for g in self.groups]))
+
+    @torch.no_grad()
+    def ready(self):
+        if 'scale' not in self.qparams:
+            return False
+        return torch.all(self.qparams['scale'] != 0)
 
     @torch.no_grad()
     def collect_model_qparams(self):

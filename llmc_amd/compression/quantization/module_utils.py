@@ -101,6 +101,10 @@ class FakeQuantLinear(nn.Module):
         m.a_qdq_name = _func_name(a_qdq) if a_qdq is not None else 'None'
         return m
 
+    @classmethod
+    def get_func_name(cls, any_callable):
+        return _func_name(any_callable)
+
     def __repr__(self):
         return (f'FakeQuantLinear(in_features={self.in_features},out_features={self.out_features}, '
                 f'bias={self.bias is not None},weight_quant={self.w_qdq_name},act_quant={self.a_qdq_name})')
@@ -137,6 +141,10 @@ class EffcientFakeQuantLinear(nn.Module):
         m.a_qdq_name = _func_name(a_qdq) if a_qdq is not None else 'None'
         m.debug_print = debug_print
         return m
+
+    @classmethod
+    def get_func_name(cls, any_callable):
+        return _func_name(any_callable)
 
     def __repr__(self):
         return (f'EffcientFakeQuantLinear(in_features={self.in_features},out_features={self.out_features},'

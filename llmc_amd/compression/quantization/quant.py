@@ -94,7 +94,7 @@ class BaseQuantizer(object):
             return ()
         return (*tensor.shape[:-1], 1)
 
-    def _mse_qparams(self, tensor, want_range=False):
+    def _mse_qparams(self, tensor, want_range=False, norm=2.4):
         """get_mse_range + get_qparams (quant.py:145-203, 545-559): fp32 scales / zeros whatever the tensor dtype
         (the reference searches on tensor.float()). mse_b_num only batches the reference's memory use."""
         _ffi.require_gpu(tensor)
@@ -110,7 +110,7 @@ class BaseQuantizer(object):
         mx = torch.empty(G, dtype=torch.float32, device=dev) if want_range else None
         _ffi.check(L.llmc_mse_qparams(
             _ffi.ptr(tensor), _ffi.dt(tensor), G, g, int(self.sym), int(self.round_zp), float(self.qmin),
-            float(self.qmax), int(self.maxshrink * self.mse_grid), int(self.mse_grid), 2.4, _ffi.ptr(scales),
+            float(self.qmax), int(self.maxshrink * self.mse_grid), int(self.mse_grid), float(norm), _ffi.ptr(scales),
             _ffi.ptr(zeros), _ffi.ptr(mn), _ffi.ptr(mx), _ffi.stream()), 'llmc_mse_qparams')
         shp = self._qparam_shape(tensor)
         scales = scales.reshape(shp)
@@ -156,16 +156,101 @@ class BaseQuantizer(object):
                 zeros = qmin - (min_val / scales)
         return scales, zeros, qmax, qmin
 
+    def get_minmax_range(self, tensor):
+        """quant.py:132-143: (min_val, max_val) of the reshaped tensor, one pair per row (0-dim for per_tensor)."""
+        if self.granularity == 'per_tensor':
+            return torch.min(tensor), torch.max(tensor)
+        return tensor.amin(dim=-1, keepdim=True), tensor.amax(dim=-1, keepdim=True)
+
+    def get_mse_range(self, tensor, norm=2.4, bs=256):
+        """quant.py:145-203: the shrunk (min, max) with the smallest |fakequant(x) - x|^norm per row (k_mse_qparams; fp32, the
+        reference searches on tensor.float()). `bs` only batches the reference's memory use."""
+        _, _, mn, mx = self._mse_qparams(tensor, want_range=True, norm=norm)
+        return mn, mx
+
     def get_tensor_range(self, tensor, args={}):
         """quant.py:122-130 for the algorithms on the accelerated path: (min_val, max_val)."""
         if self.calib_algo == 'learnable':
             return self.get_learnable_range(tensor, **{k: v for k, v in args.items() if k in ('lowbound_factor', 'upbound_factor')})
         if self.calib_algo == 'mse':
-            _, _, mn, mx = self._mse_qparams(tensor, want_range=True)
-            return mn, mx
-        if self.granularity == 'per_tensor':
-            return torch.min(tensor), torch.max(tensor)
-        return tensor.amin(dim=-1, keepdim=True), tensor.amax(dim=-1, keepdim=True)
+            return self.get_mse_range(tensor)
+        return self.get_minmax_range(tensor)
+
+    # ---- static activation ranges over a list of calibration samples (quant.py:103-120, 221-263, 462-543, 561-586) ----------
+    def reshape_batch_tensors(self, act_tensors):
+        """quant.py:103-120 -> a list (one entry per module input) of lists of per-sample tensors."""
+        assert len(act_tensors) > 0, (
+            'Calibration data is insufficient. Please provide more data to ensure '
+            'all experts in the MOE receive an adequate number of tokens.')
+        if isinstance(act_tensors[0], tuple):
+            return [torch.stack(tl) for tl in zip(*act_tensors)]
+        if len(act_tensors) == 1:
+            return [[act_tensors[0][i] for i in range(act_tensors[0].size(0))]]
+        return [list(act_tensors)]
+
+    def get_minmax_stats(self, act_tensors):
+        """quant.py:221-251: per module input the fp32 vectors of per-sample min / max — one launch pair over all the
+        separately allocated samples (llmc_minmax_samples) instead of one reduction pair per sample."""
+        from .hist_range import sample_minmax
+        stats = {}
+        for idx, tensors in enumerate(act_tensors):
+            mn, mx = sample_minmax(list(tensors))
+            stats[idx] = {'min': mn, 'max': mx}
+        return stats
+
+    def get_static_minmax_range(self, act_tensors):
+        """quant.py:253-263: mean over the samples of the per-sample min / max (fp32)."""
+        stats = self.get_minmax_stats(self.reshape_batch_tensors(act_tensors))
+        return [r['min'].mean() for r in stats.values()], [r['max'].mean() for r in stats.values()]
+
+    def get_static_moving_minmax_range(self, act_tensors, alpha):
+        """quant.py:524-543: exponential moving average of the per-sample ranges in the sample dtype. The per-sample min / max
+        come from one kernel pass; the recurrence runs on the host on 0-dim tensors of the sample dtype — the arithmetic the
+        reference performs on its scalars."""
+        from .hist_range import sample_minmax
+        mins, maxs = [], []
+        for tensors in self.reshape_batch_tensors(act_tensors):
+            tensors = list(tensors)
+            smn, smx = sample_minmax(tensors)
+            smn, smx = smn.cpu().to(tensors[0].dtype), smx.cpu().to(tensors[0].dtype)
+            mn = mx = None
+            for a, b in zip(smn, smx):
+                mn, mx = (a, b) if mn is None else (mn + alpha * (a - mn), mx + alpha * (b - mx))
+            mins.append(mn.to(tensors[0].device))
+            maxs.append(mx.to(tensors[0].device))
+        return mins, maxs
+
+    def get_static_hist_range(self, act_tensors):
+        """quant.py:462-522: histogram-observer range (data passes in HIP: hist_range.static_hist_range)."""
+        from .hist_range import static_hist_range
+        mins, maxs = [], []
+        for tensors in self.reshape_batch_tensors(act_tensors):
+            tensors = list(tensors)
+            lo, hi = static_hist_range(tensors, self.bins, self.upsample_rate, self.bit)
+            mins.append(torch.tensor(lo, dtype=torch.float32, device=tensors[0].device))
+            maxs.append(torch.tensor(hi, dtype=torch.float32, device=tensors[0].device))
+        return mins, maxs
+
+    def get_batch_tensors_qparams(self, act_tensors, alpha=0.01, args={}):
+        """quant.py:561-586 -> (scales_list, zeros_list, qmin_list, qmax_list), one entry per module input."""
+        if self.calib_algo == 'static_hist':
+            assert self.sym is True and self.granularity == 'per_tensor', \
+                'Only support per tensor static symmetric int quantize.'
+            min_vals, max_vals = self.get_static_hist_range(act_tensors)
+        elif self.calib_algo == 'static_minmax':
+            min_vals, max_vals = self.get_static_minmax_range(act_tensors)
+        elif self.calib_algo == 'static_moving_minmax':
+            min_vals, max_vals = self.get_static_moving_minmax_range(act_tensors, alpha)
+        else:
+            raise ValueError(f'Unsupported calibration algorithm: {self.calib_algo}')
+        scales_list, zeros_list, qmin_list, qmax_list = [], [], [], []
+        for mn, mx in zip(min_vals, max_vals):
+            scales, zeros, qmax, qmin = self.get_qparams((mn, mx), mn.device)
+            scales_list.append(scales)
+            zeros_list.append(zeros)
+            qmin_list.append(qmin)
+            qmax_list.append(qmax)
+        return scales_list, zeros_list, qmin_list, qmax_list
 
     def _per_tensor_asym_qparams(self, tensor):
         """per_tensor + asymmetric (quant.py:132-136,555-556): min / max are 0-dim tensors of the tensor dtype and
@@ -528,6 +613,25 @@ class FloatQuantizer(BaseQuantizer):
         tensor = self.reshape_tensor(tensor)
         _, scales = self._run(tensor, True)
         return tensor, scales, torch.tensor(0.0), self.qmax, self.qmin
+
+    # ---- static arithmetic with given scales (quant.py:1061-1081) ----------------------------------------------------
+    def quant(self, tensor, scales, zeros, qmax, qmin):
+        """quant.py:1061-1072: float_quantize(tensor / scales + zeros) — values ON the 8-bit grid, in fp32 (the reference
+        discards its cast back to the input dtype). `zeros` is 0 for every FloatQuantizer configuration (sym only)."""
+        if torch.is_tensor(zeros) and zeros.numel() and bool((zeros != 0).any()) or (not torch.is_tensor(zeros) and zeros):
+            raise NotImplementedError('FloatQuantizer.quant: non-zero zero points do not occur (the quantizer is symmetric)')
+        if self.granularity == 'per_block' and tensor.dim() == 4:
+            mb, b, nb, _ = tensor.shape
+            bits, _ = self._run_block(tensor.reshape(mb * b, nb * b), False, scales=scales)
+            return bits.view(self._tdtype).float().view(mb, b, nb, b)
+        bits, _ = self._run(tensor, False, scales=scales)
+        return bits.view(self._tdtype).float().reshape(tensor.shape)
+
+    def dequant(self, tensor, scales, zeros):
+        return (tensor - zeros.to(tensor.device) if torch.is_tensor(zeros) else tensor - zeros) * scales
+
+    def quant_dequant(self, tensor, scales, zeros, qmax, qmin):
+        return self.dequant(self.quant(tensor, scales, zeros, qmax, qmin), scales, zeros)
 
     def fake_quant_weight_dynamic(self, weight, args={}):
         if self.granularity == 'per_block':

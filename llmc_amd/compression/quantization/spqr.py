@@ -11,6 +11,7 @@ As in the reference, only asymmetric per-group weights work (its get_group_qpara
 0-dim zero point to `reshape_tensor`, which raises), and the second-level scale / zero quantizers act on [R, 1]
 tensors, i.e. never group anything (spqr.py:323-345): `llmc_spqr_quantize` reproduces what they do return.
 """
+import copy
 import math
 from dataclasses import dataclass
 
@@ -181,6 +182,96 @@ class SpQR(GPTQ):
             l.register_buffer('buf_qmax', torch.tensor(float(self.wquantizer.qmax)))
             l.register_buffer('buf_qmin', torch.tensor(float(self.wquantizer.qmin)))
             l.register_buffer('buf_mask', r.mask.float().to_sparse())
+
+    # ---- the reference's per-layer method surface (spqr.py:116-254, 315-355): same names, arguments and in-place effects ----
+    _REFERENCE_HOOKS = ('weight_transform', 'get_group_qparams', 'set_model_qparams', 'merge_qparams')
+
+    @torch.no_grad()
+    def weight_transform(self, W, Hinv, Losses, tmp, mask):
+        """spqr.py:185-254 (llmc_spqr_quantize): in place like the reference — `tmp` the compensated weights, `Losses` the
+        squared errors, `mask` the outliers, `W` the running weights; `self.groups[g]` / `self.qparams` hold every group's
+        second-level-quantized scales / zeros (get_group_qparams)."""
+        thr = math.inf
+        if self.relative_threshold != math.inf:
+            thr = self.relative_threshold * (W.var(dim=0) / torch.diag(Hinv).square()).mean().item()     # spqr.py:205-206
+        if not W.is_contiguous():
+            raise ValueError('SpQR.weight_transform: W must be contiguous (it is updated in place)')
+        t, l, m, s, z = spqr_quantize(W, Hinv.contiguous(), self.scfg, thr)
+        tmp.copy_(t)
+        Losses.copy_(l)
+        mask.copy_(m.to(mask.dtype))
+        qmax, qmin = self.wquantizer.qmax.to(W.device), self.wquantizer.qmin.to(W.device)
+        self.groups = [{'scales': s[:, g:g + 1].clone(), 'zeros': z[:, g:g + 1].clone(), 'qmax': qmax, 'qmin': qmin}
+                       for g in range(s.shape[1])]
+        self.qparams = dict(self.groups[-1])
+        self.last_threshold = thr
+
+    @torch.no_grad()
+    def merge_qparams(self, qparams):
+        if isinstance(qparams, int):
+            return qparams
+        if self.wquantizer.granularity == 'per_group':
+            qparams = torch.stack(qparams, dim=1).reshape(-1, 1)
+        return qparams
+
+    @torch.no_grad()
+    def get_group_qparams(self, c_tensor, idx):
+        """spqr.py:323-345: min/max qparams of one column group, then the second-level scale / zero quantizers (which see
+        [R, 1] tensors, i.e. one value per row: their fake-quant returns what the reference's returns). HIP quantizer
+        kernels; kept in `self.qparams` and `self.groups[idx // group_size]`."""
+        _, s, z, qmax, qmin = self.wquantizer.get_tensor_qparams(c_tensor.contiguous())
+        _, ss, zs, Ps, Ns = self.scale_quantizer.get_tensor_qparams(s)
+        scales = self.scale_quantizer.fake_quant_weight_static(s.data, {'scales': ss, 'zeros': zs, 'qmin': Ns, 'qmax': Ps})
+        _, sz, zz, Pz, Nz = self.zero_quantizer.get_tensor_qparams(z)
+        zeros = self.zero_quantizer.fake_quant_weight_static(z.data, {'scales': sz, 'zeros': zz, 'qmin': Nz, 'qmax': Pz})
+        self.qparams = {'scales': scales, 'zeros': zeros, 'qmax': qmax, 'qmin': qmin}
+        if not isinstance(getattr(self, 'groups', None), list):
+            self.groups = [None] * (self.columns // self.wquantizer.group_size)
+        self.groups[idx // self.wquantizer.group_size] = copy.deepcopy(self.qparams)
+
+    @torch.no_grad()
+    def set_model_qparams(self, layer):
+        """spqr.py:347-355."""
+        layer.register_buffer('buf_scales', copy.deepcopy(self.merge_qparams([g['scales'] for g in self.groups])))
+        layer.register_buffer('buf_zeros', copy.deepcopy(self.merge_qparams([g['zeros'] for g in self.groups])))
+        layer.register_buffer('buf_qmax', torch.tensor(float(self.groups[0]['qmax'])))
+        layer.register_buffer('buf_qmin', torch.tensor(float(self.groups[0]['qmin'])))
+
+    @torch.no_grad()
+    def layer_transform_reference(self, layer, name):
+        """spqr.py:116-183: the reference's per-layer flow through weight_transform / set_model_qparams."""
+        self.qparams = {}
+        self.columns = self.layers_cache[name]['columns']
+        W = layer.weight.data
+        if W.dim() > 2:
+            W = W.flatten(1)
+        self.groups = [None] * (self.columns // self.wquantizer.group_size)
+        perm, Wp, U, info = spqr_factor(self._hessian_of(name), W.contiguous(), self.scfg)
+        gptq_ops.raise_if_not_pd(info, f'SpQR: Hessian of {name}')
+        if perm is not None:
+            self.perm, self.invperm = perm, torch.argsort(perm)
+            layer.register_buffer('buf_perm', self.perm)
+            layer.register_buffer('buf_invperm', self.invperm)
+        Losses, tmp = torch.zeros_like(Wp), torch.zeros_like(Wp)
+        mask = torch.zeros_like(Wp, dtype=torch.bool)
+        self.weight_transform(Wp, U, Losses, tmp, mask)
+        self.last_losses = getattr(self, 'last_losses', {})
+        self.last_losses[name] = Losses.sum()
+        if perm is not None:
+            tmp, mask = tmp[:, self.invperm], mask[:, self.invperm]
+        layer.weight.data = tmp.reshape(layer.weight.shape)
+        self.set_model_qparams(layer)
+        layer.register_buffer('buf_mask', mask.float().to_sparse())
+
+    @torch.no_grad()
+    def block_transform_true_sequential(self, block, input_feat):
+        """spqr.py:61-91: subset by subset, re-hooking the block after each (the base class's block loop with
+        true_sequential on: rehook_next_subset)."""
+        saved, self.true_sequential = self.true_sequential, True
+        try:
+            BaseBlockwiseQuantization.block_transform(self, block, input_feat, {})
+        finally:
+            self.true_sequential = saved
 
     @torch.no_grad()
     def collect_model_qparams(self):
