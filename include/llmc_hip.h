@@ -71,6 +71,27 @@ int llmc_hip_set_helper_streams(int enable);
  * previous value. No reference counterpart. */
 int llmc_hip_set_cu_reserve(int n_cus);
 
+/* Explicit A/B switches, per calling thread, all 0 by default. The library reads NO environment variable: what used to be
+ * LLMC_* variables (rounds 2-5) are these keys. Every value produces valid results; "same bits" = bit-identical to the default.
+ *   k3_fp32           K3's large products on the fp32 MFMA pipe instead of split-bf16 (other rounding, same accuracy class)
+ *   k3_no_gemm6       deep levels of the triangular inverse on k_gemm3 instead of gemm6 (other rounding)
+ *   k3_no_planes      K3's far updates split inside every tile (k_gemm3) instead of pre-split planes + k_gemm3s; same bits
+ *   k3_split_far      without a helper stream, an outer block's far update as two launches instead of one; same bits
+ *   k4_split_far      without helper streams, a column group's far update as three launches instead of one; same bits
+ *   k4_err_rowmajor   the column loop's error columns row-major instead of k-major; same bits
+ *   gptq_generic      k_gptq_block: every wave on the generic IEEE-division path; same bits
+ *   gemm3_nospec      never k_gemm3s; same bits.   gemm3s_min_tiles = n > 0: its tile-count threshold (tests)
+ *   no_shortk         short products through the general fp32 GEMM; same bits
+ *   linear_nosplit    the k-tiled GEMM never cuts a small product into k-slices (single pass: the row-major kernel's bits)
+ *   fp8_exact_div     FP8 casts through the IEEE division + general encoder; same bits
+ *   side_cu_mask      helper streams created with a CU mask (read when a caller stream's helper set is first created)
+ *   k1_batch_off      llmc_hessian_accum_multi as one launch per problem instead of one tile queue; same bits
+ * set: returns the previous value, or LLMC_EINVAL for an unknown key / negative value. get: the value, or LLMC_EINVAL.
+ * option_name: the key of index 0, 1, ... (copied into buf), LLMC_EINVAL past the last one. No reference counterpart. */
+int llmc_hip_set_option(const char* key, int value);
+int llmc_hip_get_option(const char* key);
+int llmc_hip_option_name(int index, char* buf_host, size_t n);
+
 /* ------------------------------------------------------------------------------------------------
  * Quantizer arithmetic (llmc/compression/quantization/quant.py)
  * ---------------------------------------------------------------------------------------------- */

@@ -26,6 +26,9 @@ SIGNATURES = {
     'llmc_hip_last_error': (_i32, [C.c_char_p, _sz]),
     'llmc_hip_set_helper_streams': (_i32, [_i32]),
     'llmc_hip_set_cu_reserve': (_i32, [_i32]),
+    'llmc_hip_set_option': (_i32, [C.c_char_p, _i32]),
+    'llmc_hip_get_option': (_i32, [C.c_char_p]),
+    'llmc_hip_option_name': (_i32, [_i32, C.c_char_p, _sz]),
     'llmc_minmax_qparams_ws_bytes': (_sz, [_i64, _i64]),
     'llmc_minmax_qparams': (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     'llmc_minmax_samples_max': (_i32, []),
@@ -130,7 +133,81 @@ def lib():
                 raise LlmcHipError(f'{LIB_PATH} is stale: built from sources {have}, csrc/ is {want} '
                                    '(run `python -m llmc_amd.build`; LLMC_SKIP_BUILD_ID_CHECK=1 skips this check)')
         _lib = handle
+        _apply_startup_options()
     return _lib
+
+
+# ---- explicit A/B switches --------------------------------------------------------------------------------------------------
+# The library reads no environment variable; its switches are llmc_hip_set_option(key, value) (per calling thread, table in
+# include/llmc_hip.h). Host-side switches of the Python layer live in HOST_OPTIONS. `option(k3_no_planes=1)` sets either kind
+# for the duration of a `with` block. For command-line A/B runs (tools/) ONE variable is read, once, when the library is
+# loaded: LLMC_OPTIONS="key=value,key=value".
+HOST_OPTIONS = {
+    'awq_kt': 1,                              # 0: AWQ products on row-major operands and the 8-wave kernel (round-1 path)
+    'awq_y_bytes': (1 << 32) - (1 << 20),     # chunk bound of the tile-blocked reference output (tests lower it)
+    'k3_fused_prep': 1,                       # 0: llmc_hessian_prep + llmc_chol_inv_upper instead of the reversed gather + in-place factor
+}
+
+_HOST_DEFAULTS = dict(HOST_OPTIONS)
+
+
+def reset_options():
+    """Every switch back to its default (tests)."""
+    HOST_OPTIONS.update(_HOST_DEFAULTS)
+    if _lib is not None:
+        for k in library_options():
+            _lib.llmc_hip_set_option(k.encode(), 0)
+
+
+def set_option(key, value):
+    """Set a switch; returns the previous value. Library keys: llmc_hip_set_option; host keys: HOST_OPTIONS."""
+    if key in HOST_OPTIONS:
+        prev, HOST_OPTIONS[key] = HOST_OPTIONS[key], int(value)
+        return prev
+    prev = lib().llmc_hip_set_option(key.encode(), int(value))
+    if prev < 0:
+        raise ValueError(f'unknown option {key!r} (library keys: {library_options()}; host keys: {sorted(HOST_OPTIONS)})')
+    return prev
+
+
+def get_option(key):
+    if key in HOST_OPTIONS:
+        return HOST_OPTIONS[key]
+    v = lib().llmc_hip_get_option(key.encode())
+    if v < 0:
+        raise ValueError(f'unknown option {key!r}')
+    return v
+
+
+def library_options():
+    out, buf, i = [], C.create_string_buffer(64), 0
+    while lib().llmc_hip_option_name(i, buf, 64) > 0:
+        out.append(buf.value.decode())
+        i += 1
+    return out
+
+
+class option:
+    """with _ffi.option(k3_no_planes=1, gemm3s_min_tiles=1): ..."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.prev = {k: set_option(k, v) for k, v in self.kv.items()}
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
+
+
+def _apply_startup_options():
+    spec = os.environ.get('LLMC_OPTIONS', '')
+    for item in filter(None, (x.strip() for x in spec.split(','))):
+        k, _, v = item.partition('=')
+        set_option(k.strip(), int(v or 1))
 
 
 def last_error():

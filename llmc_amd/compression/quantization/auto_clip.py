@@ -38,6 +38,11 @@ class AutoClipper:
         self.weight_clips = {}
         self.w_only = w_only
         self.logit = lambda x: torch.log(x / (1 - x))
+        # block-wise FP8 checkpoints: (weight, weight_scale_inv) -> bf16 and bf16 -> (fp8 weight, block scales); bound by the
+        # owning algorithm to its own casts (base_blockwise_quantization.py: _fp8_to_bf16 / _bf16_to_fp8)
+        self.fp8_block_size = 128
+        self.fp8_to_bf16 = None
+        self.bf16_to_fp8 = None
 
     @torch.no_grad()
     def run(self, block, block_idx, input_feat, n_sample_token):
@@ -49,6 +54,15 @@ class AutoClipper:
                     m.register_buffer('buf_upbound_factor', None)
                     m.register_buffer('buf_lowbound_factor', None)
                 continue
+            # auto_clip.py:47-53, 78-81: a block-wise FP8 checkpoint weight (DeepSeek-V3 layout) is de-blocked to bf16 for the
+            # search and the clamp, and re-blocked afterwards. (The reference reads `self.fp8_block_size` here, which its
+            # AutoClipper never sets — as shipped it raises AttributeError on such checkpoints; the casts and the block size
+            # are handed over by the owning algorithm: BaseBlockwiseQuantization.set_quant_config.)
+            is_fp8_weight = m.weight.data.dtype == torch.float8_e4m3fn
+            if is_fp8_weight:
+                if self.fp8_to_bf16 is None:
+                    raise RuntimeError('AutoClipper: block-wise FP8 weight but no cast bound (fp8_to_bf16 / bf16_to_fp8)')
+                m.weight.data = self.fp8_to_bf16(m.weight, m.weight_scale_inv)
             inputs = [torch.cat(input_feat[n])] if len(input_feat[n]) != 1 else input_feat[n]
             max_val, min_val = self.auto_clip_layer(block_idx, n, m.weight, inputs, n_sample_token=n_sample_token)
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -56,6 +70,8 @@ class AutoClipper:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM)
                     t /= dist.get_world_size()
             self.apply_clip(block_idx, m, min_val, max_val, n)
+            if is_fp8_weight:
+                m.weight.data, m.weight_scale_inv.data = self.bf16_to_fp8(m.weight.data)
 
     def _sample_tokens(self, x, i, w, n_sample_token):
         """auto_clip.py:133-147: flatten, drop padded tokens, every step-th token."""

@@ -135,6 +135,10 @@ def linear_out(x, wq, bias=None, tiled=False, blocked=False):
 _FALLBACK_SEEN = set()
 
 
+KTILE_MIN_TOKENS = 256      # below one 256-token tile the two k-tile packs (x and W) cost more than they save:
+#                             such calls (per-token forwards of OriginFloatLinear / FakeQuantLinear) take the row-major kernel
+
+
 def linear_auto(x, w, bias=None, xcache=None):
     """F.linear(x, w, bias) on the best HIP GEMM the shapes allow — same bits on both HIP routes:
       * k-tiled operands + the one-wave-per-SIMD kernel (llmc_linear_eval_kt) when K % 128 == 0 and there are enough
@@ -146,7 +150,7 @@ def linear_auto(x, w, bias=None, xcache=None):
         per shape on stderr, never silently, never the CPU."""
     R, K = w.shape
     N = x.numel() // max(1, x.shape[-1])
-    if ktile_supported(x, w) and os.environ.get('LLMC_AWQ_KT', '1') != '0':
+    if N >= KTILE_MIN_TOKENS and ktile_supported(x, w) and _ffi.HOST_OPTIONS['awq_kt']:
         key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x._version)
         hit = xcache.get(key) if xcache is not None else None
         if hit is None:

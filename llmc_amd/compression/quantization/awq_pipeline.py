@@ -41,8 +41,8 @@ def search_scale_stacked(weights, x, wquantizer, trans_version='v2', n_grid=20, 
     # K % 128 == 0: the 21 products run on the k-tiled GEMM (llmc_linear_eval_kt), operands re-laid by llmc_ktile_pack.
     # The output rows are walked in chunks whose [N, R_c] reference output stays below the GEMM's 4-GiB offset range
     # (70B-class gate|up stacks at 65 536 tokens): the loss is a sum over outputs, so chunk sums add up.
-    kt_ok = x2.is_cuda and awq_ops.ktile_supported(x2, wcat[:min(R, 256)]) and os.environ.get('LLMC_AWQ_KT', '1') != '0'
-    lim = int(os.environ.get('LLMC_AWQ_Y_BYTES', str((1 << 32) - (1 << 20))))      # test hook: smaller chunks
+    kt_ok = x2.is_cuda and awq_ops.ktile_supported(x2, wcat[:min(R, 256)]) and _ffi.HOST_OPTIONS['awq_kt']
+    lim = int(_ffi.HOST_OPTIONS['awq_y_bytes'])      # test hook: smaller chunks
     rc = max(256, (lim // (2 * max(N, K))) // 256 * 256)
     chunks = [(r0, min(R, r0 + rc)) for r0 in range(0, R, rc)] if kt_ok else [(0, R)]
     kt = kt_ok and all(awq_ops.ktile_supported(x2, wcat[r0:r1]) for r0, r1 in chunks)

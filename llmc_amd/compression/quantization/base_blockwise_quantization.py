@@ -172,6 +172,10 @@ class BaseBlockwiseQuantization(BlockwiseOpt):
         if self.fp8_cast not in ('kernel', 'quantizer'):
             raise ValueError(f"special.fp8_cast must be 'kernel' or 'quantizer', got {self.fp8_cast!r}")
         self.fp8_cast_semantics = special.get('fp8_cast_semantics', 'qtorch')
+        if getattr(self, 'auto_clipper', None) is not None:       # auto_clip.py:47-53, 78-81 use the same casts
+            self.auto_clipper.fp8_block_size = self.fp8_block_size
+            self.auto_clipper.fp8_to_bf16 = self._fp8_to_bf16
+            self.auto_clipper.bf16_to_fp8 = self._bf16_to_fp8
         self.do_gqa_trans = special.get('do_gqa_trans', False)
         self.set_model_config()
 

@@ -75,9 +75,13 @@ def chol_inv_upper(H, check=True, return_info=False):
     return (H, info) if return_info else H
 
 
-def chol_inv_upper_rev(Hrev, check=True, return_info=False):
-    """chol_inv_upper for the index-reversed matrix of hessian_prep(..., reverse_h=True): Hrev is factored in place (destroyed),
-    U comes back in a new tensor — bit-identical to chol_inv_upper on the un-reversed matrix, one K^2 pass less."""
+def chol_inv_upper_rev(Hrev, check=True, return_info=False, in_workspace=True):
+    """chol_inv_upper for the index-reversed matrix of hessian_prep(..., reverse_h=True): Hrev is factored in place (destroyed) —
+    bit-identical to chol_inv_upper on the un-reversed matrix, one K^2 pass less.
+    ALIASING: by default (in_workspace=True) the returned U is a VIEW into the calling stream's factorisation workspace: it is
+    overwritten by the next chol_inv_upper / chol_inv_upper_rev on the same stream and must not be read from another stream
+    without an event. quantize_stacked / quantize_owq consume it at once. Callers that keep U (or factor a second Hessian before
+    using the first) pass in_workspace=False and get a private tensor (one K^2 device copy)."""
     _ffi.require_gpu(Hrev)
     L = _ffi.lib()
     K = Hrev.shape[0]
@@ -98,6 +102,8 @@ def chol_inv_upper_rev(Hrev, check=True, return_info=False):
         i = int(info.item())
         if i != 0:
             raise RuntimeError(f'chol_inv_upper: matrix is not positive definite (leading minor {i})')
+    if not in_workspace:
+        U = U.clone()
     return (U, info) if return_info else U
 
 

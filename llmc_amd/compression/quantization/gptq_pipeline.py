@@ -65,9 +65,8 @@ def _prep_and_factor(H, W, perm, percdamp, h_work):
     permuted matrix is gathered index-reversed (the same gather, the permutation read backwards) so that the factorisation
     starts from it directly — one pass over K^2 floats less on the chain of every subset (0.5 ms at K = 14336), same bits.
     The factor then lives in the calling stream's factorisation workspace: valid until that stream's next factorisation.
-    LLMC_K3_FUSED_PREP=0 keeps the two separate entry points."""
-    import os
-    if os.environ.get('LLMC_K3_FUSED_PREP', '1') != '0':
+    _ffi.option(k3_fused_prep=0) keeps the two separate entry points."""
+    if _ffi.HOST_OPTIONS['k3_fused_prep']:
         Hrev, Wp = gptq_ops.hessian_prep(H, W, perm, percdamp, want_h=True, h_out=h_work, reverse_h=True)
         U, info = gptq_ops.chol_inv_upper_rev(Hrev, check=False, return_info=True)
         return U, Wp, info

@@ -147,6 +147,8 @@ class HessianAccumulator:
                     self._diag64.mul_(self._flushed / (self._flushed + b_total))
             else:
                 self._H.zero_()                         # after reset() the buffer still holds the previous Hessian: 0 * n/(n+b)
+                if self._diag64 is not None:
+                    self._diag64.zero_()
             self._flushed += b_total
             return
         # the sequences of the whole flush enter the running mean with the first launch; the others add their products
@@ -226,6 +228,8 @@ class HessianAccumulator:
         """Start a new Hessian in the same buffers (the first launch overwrites H: n_before = 0)."""
         self.nsamples = 0
         self._flushed = 0
+        if self._diag64 is not None:
+            self._diag64.zero_()        # the fp64 running diagonal belongs to the Hessian that is being discarded
         self._drop_pending()
 
     def release_workspace(self):

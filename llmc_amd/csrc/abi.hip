@@ -10,6 +10,11 @@ static thread_local int g_helper_streams = 1;
 bool helper_streams_enabled() { return g_helper_streams != 0; }
 static thread_local int g_cu_reserve = 0;
 int cu_reserve() { return g_cu_reserve; }
+static thread_local int g_opt[OPT_COUNT] = {};
+int opt(int id) { return (id >= 0 && id < OPT_COUNT) ? g_opt[id] : 0; }
+static const char* const g_opt_names[OPT_COUNT] = {
+    "k3_fp32", "k3_no_gemm6", "k3_no_planes", "k3_split_far", "k4_split_far", "k4_err_rowmajor", "gptq_generic",
+    "gemm3_nospec", "gemm3s_min_tiles", "no_shortk", "linear_nosplit", "fp8_exact_div", "side_cu_mask", "k1_batch_off"};
 
 void set_last_error(const char* where, hipError_t e) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
@@ -51,6 +56,32 @@ extern "C" int llmc_hip_set_helper_streams(int enable) {
     int prev = llmc::g_helper_streams;
     llmc::g_helper_streams = enable ? 1 : 0;
     return prev;
+}
+
+extern "C" int llmc_hip_set_option(const char* key, int value) {
+    if (!key || value < 0) return LLMC_EINVAL;
+    for (int i = 0; i < llmc::OPT_COUNT; ++i)
+        if (strcmp(key, llmc::g_opt_names[i]) == 0) {
+            const int prev = llmc::g_opt[i];
+            llmc::g_opt[i] = value;
+            return prev;
+        }
+    llmc::set_last_error_msg("llmc_hip_set_option: unknown key");
+    return LLMC_EINVAL;
+}
+
+extern "C" int llmc_hip_get_option(const char* key) {
+    if (!key) return LLMC_EINVAL;
+    for (int i = 0; i < llmc::OPT_COUNT; ++i)
+        if (strcmp(key, llmc::g_opt_names[i]) == 0) return llmc::g_opt[i];
+    return LLMC_EINVAL;
+}
+
+extern "C" int llmc_hip_option_name(int index, char* buf_host, size_t n) {
+    if (index < 0 || index >= llmc::OPT_COUNT || !buf_host || n == 0) return LLMC_EINVAL;
+    strncpy(buf_host, llmc::g_opt_names[index], n - 1);
+    buf_host[n - 1] = 0;
+    return (int)strlen(buf_host);
 }
 
 extern "C" int llmc_hip_set_cu_reserve(int n_cus) {

@@ -675,7 +675,7 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
     float* Vbuf = (float*)((char*)ws + align256((size_t)K * K * 4));
     float* Xbuf = (float*)((char*)Vbuf + align256((size_t)ceil_div64(K, NB) * NB * NB * 4));
     void* G6buf = (char*)Xbuf + align256((size_t)(K / 2 + NB) * (K / 2 + NB) * 4);
-    const bool use_g6 = getenv("LLMC_K3_NO_GEMM6") == nullptr;
+    const bool use_g6 = !opt(OPT_K3_NO_GEMM6);
     LLMC_HIP_CHECK(hipMemsetAsync(info_dev, 0, 4, st));
     if (int rc = ensure_dynamic_lds((const void*)k_potrf_inv, (NB * PLD + 32 * PLD + 64) * (int)sizeof(float))) return rc;
 
@@ -691,15 +691,15 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
     // beyond it receive ONE symmetric update with Kd = 512 per outer block, which is where the flops are and
     // runs the fp32-MFMA GEMM at its long-K efficiency instead of its short-K one (tools/bench_sgemm.py).
     const int NBO = 4 * NB;
-    SideStream* side = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : side_stream_for(st);
+    SideStream* side = (!helper_streams_enabled()) ? nullptr : side_stream_for(st);
     bool pending_side = false;
     // The large products of K3 (far updates, triangular-inverse levels >= 512) run as split-bf16 products on the 16-bit
     // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
     // the fp32 MFMA path.
-    const bool k3_x3 = getenv("LLMC_K3_FP32") == nullptr;
+    const bool k3_x3 = !opt(OPT_K3_FP32);
     const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;
-    const bool use_planes = getenv("LLMC_K3_NO_PLANES") == nullptr;
-    const bool merge_far = getenv("LLMC_K3_SPLIT_FAR") == nullptr;
+    const bool use_planes = !opt(OPT_K3_NO_PLANES);
+    const bool merge_far = !opt(OPT_K3_SPLIT_FAR);
     const size_t xbuf_bytes = (size_t)(K / 2 + NB) * (K / 2 + NB) * 4;
     // Inside an outer block the columns split into NEAR (the block's own, which the next factor step needs) and FAR (all
     // the columns to its right, needed by the later far panel solves and by the block's far update). The near panel solve

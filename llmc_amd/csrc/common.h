@@ -44,7 +44,28 @@ static constexpr int LLMC_MAX_DEVICES = 64;
 int device_cu_count();                                  // CUs of the current device (256 on MI355X)
 int ensure_dynamic_lds(const void* fn, int bytes);
 int cu_reserve();                                       // llmc_hip_set_cu_reserve (per calling thread)
-bool helper_streams_enabled();                          // llmc_hip_set_helper_streams (per calling thread)      // hipFuncAttributeMaxDynamicSharedMemorySize, once per device
+bool helper_streams_enabled();                          // llmc_hip_set_helper_streams (per calling thread)
+
+// Explicit A/B switches (llmc_hip_set_option; per calling thread, all 0 by default, every value produces valid — and, unless
+// the table in include/llmc_hip.h says otherwise, bit-identical — results). The library reads NO environment variable.
+enum Opt : int {
+    OPT_K3_FP32 = 0,        // K3's large products on the fp32 MFMA pipe instead of split-bf16
+    OPT_K3_NO_GEMM6,        // deep levels of the triangular inverse on k_gemm3 instead of gemm6
+    OPT_K3_NO_PLANES,       // K3's far updates on k_gemm3 (split in every tile) instead of pre-split planes + k_gemm3s
+    OPT_K3_SPLIT_FAR,       // K3 far update of an outer block as two launches instead of one
+    OPT_K4_SPLIT_FAR,       // K4 far update of a column group as three launches instead of one
+    OPT_K4_ERR_ROWMAJOR,    // K4 error columns row-major instead of k-major
+    OPT_GPTQ_GENERIC,       // k_gptq_block: generic IEEE-division path for every wave
+    OPT_GEMM3_NOSPEC,       // never k_gemm3s
+    OPT_GEMM3S_MIN_TILES,   // tile-count threshold of k_gemm3s (0 = the built-in 48 / 256)
+    OPT_NO_SHORTK,          // short products through the general fp32 GEMM
+    OPT_LINEAR_NOSPLIT,     // k-tiled GEMM never cuts a small product into k-slices
+    OPT_FP8_EXACT_DIV,      // FP8 cast through the IEEE division + general encoder
+    OPT_SIDE_CU_MASK,       // helper streams created with a CU mask (read when a caller stream's helper set is first created)
+    OPT_K1_BATCH_OFF,       // llmc_hessian_accum_multi as one launch per problem instead of one tile queue
+    OPT_COUNT
+};
+int opt(int id);
 
 static inline int dtype_size(int dt) { return dt == LLMC_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == LLMC_F16 || dt == LLMC_BF16 || dt == LLMC_F32; }

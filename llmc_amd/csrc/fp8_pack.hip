@@ -373,8 +373,7 @@ extern "C" int llmc_fp8_quant(const void* W, int dt, int64_t G, int64_t g, int f
         int rc = llmc_minmax_qparams(W, dt, G, g, /*sym*/ 1, 1, -1.0f, 1.0f, amax, nullptr, ws2, stream);
         if (rc) return rc;
     }
-    static const bool exact_div_env = getenv("LLMC_FP8_EXACT_DIV") != nullptr;      // A/B switch, same results (include/llmc_hip.h)
-    if (exact_div_env) fake |= FP8_EXACT_DIV;
+    if (opt(OPT_FP8_EXACT_DIV)) fake |= FP8_EXACT_DIV;      // A/B switch, same results (include/llmc_hip.h)
     hipStream_t st = (hipStream_t)stream;
     switch (dt) {
         case LLMC_F16:

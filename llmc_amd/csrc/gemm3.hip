@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm3s(SgemmArgs a) {
 
 // the specialised kernel for large k-major products without operand hints; everything else stays on k_gemm3
 static bool gemm3s_eligible(const SgemmArgs& a) {
-    if (getenv("LLMC_GEMM3_NOSPEC")) return false;
+    if (opt(OPT_GEMM3_NOSPEC)) return false;
     if (a.a_upper || a.a_lower || a.b_upper) return false;
     if ((((uintptr_t)a.C) & 15) || a.ldc % 4 || a.sC % 4) return false;            // 16-B accesses to C
     if ((int64_t)S_BM * a.ldc * 4 >= (int64_t)0x7fffff00) return false;             // 32-bit offsets inside a C tile
@@ -588,8 +588,8 @@ static bool gemm3s_eligible(const SgemmArgs& a) {
     // one workgroup per CU: worth it once the tiles that do work come near filling the chip
     const int64_t tm = (a.M + S_BM - 1) / S_BM, tn = (a.N + S_BN - 1) / S_BN;
     const int64_t tiles = a.c_upper_only ? tm * tn - tm * (tm - 1) : tm * tn;      // row r of tiles skips its first 2r columns
-    const char* mt = getenv("LLMC_GEMM3S_MIN_TILES");      // read per launch: the tests lower it to reach the kernel with small shapes
-    const int min_tiles = mt ? atoi(mt) : (pre ? 48 : 256);   // bench: 48 -> 93.75, 160 -> 93.98 / 94.20, 600 -> 94.48, never -> 95.14 ms per step
+    const int mt = opt(OPT_GEMM3S_MIN_TILES);               // the tests lower it to reach the kernel with small shapes
+    const int min_tiles = mt > 0 ? mt : (pre ? 48 : 256);   // bench: 48 -> 93.75, 160 -> 93.98 / 94.20, 600 -> 94.48, never -> 95.14 ms per step
     return tiles * a.batch >= min_tiles;
 }
 
@@ -616,12 +616,21 @@ int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
     LLMC_REQUIRE((const void*)a.C != (const void*)a.B && (const void*)a.C != (const void*)a.A, "gemm3: no in-place product");
     if (TA && gemm3s_eligible(a)) {
         dim3 sgrid((a.N + S_BN - 1) / S_BN, (a.M + S_BM - 1) / S_BM, a.batch);
+#ifdef LLMC_LAB
         const char* dbg = getenv("LLMC_GEMM3S_DBG");
         const int d = dbg ? atoi(dbg) : 0;
+#else
+        const int d = 0;
+#endif
 #define LLMC_G3S(D, PRE) do { if (int rc = ensure_dynamic_lds((const void*)k_gemm3s<D, PRE>, S_LDS)) return rc; \
                               hipLaunchKernelGGL((k_gemm3s<D, PRE>), sgrid, dim3(512), S_LDS, st, a); } while (0)
+#ifdef LLMC_LAB
         if (a.planesA) { if (d == 2) LLMC_G3S(2, true); else if (d == 4) LLMC_G3S(4, true); else LLMC_G3S(0, true); }
         else { if (d == 2) LLMC_G3S(2, false); else if (d == 4) LLMC_G3S(4, false); else LLMC_G3S(0, false); }
+#else
+        (void)d;
+        if (a.planesA) LLMC_G3S(0, true); else LLMC_G3S(0, false);
+#endif
 #undef LLMC_G3S
         LLMC_LAUNCH_CHECK();
         return LLMC_OK;

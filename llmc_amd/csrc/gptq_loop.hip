@@ -476,7 +476,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     // a row-major one ([R][512]) through four scalar transposing writes per float4 (square 4096: 130 vs 122 TFLOP/s). The in-block
     // kernel's stores become 16-B segments (four rows of one column); the volume is 2 MB per block. LLMC_K4_ERR_ROWMAJOR=1: the old
     // layout (same bits).
-    const bool ekm = getenv("LLMC_K4_ERR_ROWMAJOR") == nullptr;
+    const bool ekm = !opt(OPT_K4_ERR_ROWMAJOR);
     const int64_t Rp = (R + 3) & ~(int64_t)3;
     const int64_t err_ld = ekm ? Rp : ELD;
     float* ErrBuf[3] = {(float*)ws, (float*)ws + (size_t)Rp * ELD, (float*)ws + 2 * (size_t)Rp * ELD};   // [R, GRP*128] or [GRP*128, Rp], x 3
@@ -487,8 +487,8 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     // every group's far update, so the chain stood still while ~430 us of fp32 far update drained. Per element the updates
     // still arrive in the reference's order (block 0, 1, 2, ...: bulk stream order, then the chain behind C1), from the
     // same kernels on the same tile grid: bit-identical to one stream (LLMC_NO_SIDE_STREAM=1), which tests compare.
-    PipeStreams* ps = (getenv("LLMC_NO_SIDE_STREAM") || !helper_streams_enabled()) ? nullptr : pipe_streams_for(caller);
-    const bool merge_far = getenv("LLMC_K4_SPLIT_FAR") == nullptr;
+    PipeStreams* ps = (!helper_streams_enabled()) ? nullptr : pipe_streams_for(caller);
+    const bool merge_far = !opt(OPT_K4_SPLIT_FAR);
     hipStream_t st = ps ? pipe_chain_stream(ps, caller) : caller;
     hipStream_t bulk = ps ? ps->bulk : st;
     if (ps) {
@@ -501,7 +501,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     hipEvent_t C1_prev = nullptr;                 // the previous group's far-far update has reached the next group's columns
     hipEvent_t C2_hist[3] = {nullptr, nullptr, nullptr};   // ... is complete (its err buffer may be rewritten)
     hipEvent_t bulk_tail = nullptr;               // behind the most recent launch on the bulk stream
-    const int force_generic = getenv("LLMC_GPTQ_GENERIC") ? 1 : 0;
+    const int force_generic = opt(OPT_GPTQ_GENERIC) ? 1 : 0;
     // Every weight receives the blocks' updates in the reference's order (block 0, 1, 2, ...), each as
     // "W -= chain over the block's 128 k" (gptq.py:244). Columns inside the current outer group get them right
     // after each block (the next block needs them); columns beyond the group get the group's GRP updates in one

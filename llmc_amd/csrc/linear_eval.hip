@@ -712,7 +712,7 @@ using namespace llmc;
 extern "C" size_t llmc_linear_eval_ws_bytes(int64_t N, int64_t K, int64_t R) {
     if (N <= 0 || R <= 0) return 0;
     const size_t loss = (size_t)(ceil_div64(N, LT) * ceil_div64(R, LT)) * sizeof(float);
-    const int sk = K > 0 && K % (L4_KS * L4_RING) == 0 ? lin_ksplit(N, K, R, 256) : 1;   // mode 0 of llmc_linear_eval_kt: fp32 slices
+    const int sk = K > 0 && K % (L4_KS * L4_RING) == 0 ? lin_ksplit(N, K, R, device_cu_count() & ~7) : 1;   // mode 0 of llmc_linear_eval_kt: fp32 slices
     const size_t split = sk > 1 ? (size_t)sk * N * R * sizeof(float) : 0;
     return loss > split ? loss : split;
 }
@@ -798,8 +798,8 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr; a.ksplit = 1; a.ntm_real = a.ntm;
     // split-K for products that leave CUs idle (mode 0, row-major output, workspace given): fp32 slices into ws, then one
     // reduction + rounding pass. LLMC_LINEAR_NOSPLIT=1 keeps the single-pass form (tests compare the two).
-    const int sk = (mode == 0 && !yblk && ws && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)Yout & 15) == 0 && !getenv("LLMC_LINEAR_NOSPLIT"))
-                       ? lin_ksplit(N, K, R, 256) : 1;
+    const int sk = (mode == 0 && !yblk && ws && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)Yout & 15) == 0 && !opt(OPT_LINEAR_NOSPLIT))
+                       ? lin_ksplit(N, K, R, grid) : 1;
     if (sk > 1) {
         a.mode = 3; a.C = (float*)ws; a.ldc = R; a.ksplit = sk; a.ntm = a.ntm_real * sk;
     }

@@ -97,8 +97,7 @@ inline PipeStreams* pipe_streams_for(hipStream_t main_st) {
     }
     PipeStreams* p = new PipeStreams();
     pool[key] = p;             // a failed set stays registered with ok = false (no retry storm), its partial resources released below
-    const char* e = getenv("LLMC_SIDE_CU_MASK");
-    const bool masked = e && e[0] == '1';
+    const bool masked = opt(OPT_SIDE_CU_MASK) != 0;
     p->masked = masked;
     auto fail = [&]() -> PipeStreams* {
         for (hipStream_t* s : {&p->fast, &p->bulk, &p->inv, &p->chain})

@@ -499,7 +499,7 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
                      (((uintptr_t)a.B & 15) == 0) && (a.sA % 4 == 0) && (a.sB % 4 == 0),
                  "sgemm: operands must be 16-B aligned with ld % 4 == 0");
     if (!TB && a.batch == 1 && a.Kd <= SKD && !a.a_upper && !a.b_upper && (a.phase_len == 0 || a.phase_len >= a.Kd) &&
-        !getenv("LLMC_NO_SHORTK")) {
+        !opt(OPT_NO_SHORTK)) {
         const bool in_place = (const void*)a.C == (const void*)a.B;
         dim3 sgrid((a.N + SB - 1) / SB, in_place ? 1 : (a.M + SB - 1) / SB, 1);
         if (TA) hipLaunchKernelGGL((k_sgemm_shortk<true>), sgrid, dim3(256), 0, st, a);
@@ -510,7 +510,7 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
     // few-tile phased products (phase = 128) on 64x64 tiles: the latency-critical slice of K4's far update
     if (!TB && a.batch == 1 && a.epilogue == SG_SUB && a.phase_len == SKD && a.Kd % SKD == 0 && a.Kd > SKD &&
         !a.a_upper && !a.a_lower && !a.b_upper && (TA || a.lda % 4 == 0) &&
-        (int64_t)((a.M + SB - 1) / SB) * ((a.N + SB - 1) / SB) <= 1024 && !getenv("LLMC_NO_SHORTK")) {
+        (int64_t)((a.M + SB - 1) / SB) * ((a.N + SB - 1) / SB) <= 1024 && !opt(OPT_NO_SHORTK)) {
         dim3 sgrid((a.N + SB - 1) / SB, (a.M + SB - 1) / SB, 1);
         if (TA) hipLaunchKernelGGL((k_sgemm_shortk_phased<true>), sgrid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_sgemm_shortk_phased<false>), sgrid, dim3(256), 0, st, a);

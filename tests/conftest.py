@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(autouse=True)
+def _llmc_options_back_to_defaults():
+    """A test that flips an A/B switch (llmc_amd._ffi.set_option / option) cannot leak it into the next test."""
+    yield
+    from llmc_amd import _ffi
+    _ffi.reset_options()
+
+
 class _Merged(dict):
     """Several golden files whose keys carry their case name as a prefix, read as one; `names` is the concatenation."""
     @property

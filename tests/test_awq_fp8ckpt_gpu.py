@@ -142,3 +142,44 @@ def test_search_on_fp8_checkpoint_layers_runs_the_general_route_and_restores_the
             l.weight.data, l.weight_scale_inv.data = w0, s0
     assert np.isfinite(losses).all() and len(set(losses)) > 10
     assert torch.equal(best, cands[int(np.argmin(losses))])
+
+
+def test_auto_clipper_runs_on_fp8_checkpoint_layers_deblocked_and_reblocks_them():
+    """AutoClipper.run on block-wise FP8 weights (auto_clip.py:47-53, 78-81): the weight is de-blocked to bf16 for
+    the clip search and the clamp and re-blocked afterwards — equal to doing the three steps by hand on a bf16 Linear; q / k
+    layers are skipped and keep their FP8 weights. (The reference itself raises AttributeError here: its AutoClipper never
+    receives fp8_block_size, so there is no golden; the three steps are each pinned on their own.)"""
+    from llmc_amd.compression.quantization import IntegerQuantizer
+    from llmc_amd.compression.quantization.auto_clip import AutoClipper
+    g = load_golden('awq_fp8ckpt')
+    p = 'w4g128_asym/'
+    bit, sym, gs, bsz, K = [int(v) for v in g[p + 'meta']]
+    a = _awq(bit, sym, gs, bsz, 'kernel')
+    wq = IntegerQuantizer(4, False, 'per_group', group_size=128)
+    clipper = AutoClipper(w_only=True, wquantizer=wq, aquantizer=None, clip_version='v1', clip_sym=False, save_clip=False,
+                          padding_mask=None)
+    clipper.fp8_block_size, clipper.fp8_to_bf16, clipper.bf16_to_fp8 = bsz, a._fp8_to_bf16, a._bf16_to_fp8
+    block = torch.nn.Module()
+    block.o_proj = _layer(g[p + 'w8_0'], g[p + 's8_0'], bsz)
+    block.k_proj = _layer(g[p + 'w8_1'], g[p + 's8_1'], bsz)
+    keep_k = (block.k_proj.weight.data.clone(), block.k_proj.weight_scale_inv.data.clone())
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn(2, 96, K, generator=gen) * torch.exp(0.8 * torch.randn(K, generator=gen))).to(torch.bfloat16).cuda()
+    feat = {'o_proj': [x], 'k_proj': [x]}
+    # by hand
+    w_bf16 = a._fp8_to_bf16(block.o_proj.weight, block.o_proj.weight_scale_inv)
+    assert w_bf16.dtype == torch.bfloat16
+    plain = torch.nn.Linear(K, w_bf16.shape[0], bias=False).cuda()
+    plain.weight.data = w_bf16.clone()
+    mx, mn = clipper.auto_clip_layer(0, 'o_proj', plain.weight, [x], n_sample_token=96)
+    clipper.apply_clip(0, plain, mn, mx, 'o_proj')
+    assert not torch.equal(plain.weight.data, w_bf16)                      # something was clipped
+    w8, s8 = a._bf16_to_fp8(plain.weight.data)
+    clipper.run(block, 0, feat, n_sample_token=96)
+    assert block.o_proj.weight.data.dtype == torch.float8_e4m3fn and block.o_proj.weight_scale_inv.data.dtype == torch.float32
+    assert torch.equal(block.o_proj.weight.data.view(torch.uint8), w8.view(torch.uint8))
+    assert torch.equal(block.o_proj.weight_scale_inv.data, s8)
+    assert torch.equal(block.k_proj.weight.data.view(torch.uint8), keep_k[0].view(torch.uint8))
+    assert torch.equal(block.k_proj.weight_scale_inv.data, keep_k[1])
+    y = block.o_proj(x)                                                    # the re-blocked layer still runs its fp8 forward
+    assert y.shape == (2, 96, w_bf16.shape[0]) and bool(torch.isfinite(y.float()).all())

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from conftest import load_golden
+from llmc_amd import _ffi
 from oracle import awq_ref as A
 from oracle import quant_ref as Q
 
@@ -126,7 +127,7 @@ def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape, monkeypatch
     and the same loss partials. (Products that would leave CUs idle are cut into k-slices since round 5 — a reordering of the
     fp32 sum; the single-pass form is what is bit-identical, the sliced one agrees to an ulp.)"""
     from llmc_amd.compression.quantization import awq_ops
-    monkeypatch.setenv('LLMC_LINEAR_NOSPLIT', '1')
+    _ffi.set_option('linear_nosplit', 1)
     N, K, R = shape
     gen = torch.Generator().manual_seed(N * 3 + R)
     x = torch.randn(N, K, generator=gen).to(TD[dt]).cuda()
@@ -143,9 +144,9 @@ def test_ktiled_linear_eval_is_bit_identical_to_row_major(dt, shape, monkeypatch
         y = awq_ops.linear_out(x, w, bias)
         yt = awq_ops.linear_out(xt, wt, bias, tiled=True)
         assert torch.equal(y.view(torch.int16), yt.view(torch.int16))
-        monkeypatch.delenv('LLMC_LINEAR_NOSPLIT')
+        _ffi.set_option('linear_nosplit', 0)
         ys = awq_ops.linear_out(xt, wt, bias, tiled=True)          # k-slices where the shape calls for them
-        monkeypatch.setenv('LLMC_LINEAR_NOSPLIT', '1')
+        _ffi.set_option('linear_nosplit', 1)
         eps_ = 2.0 ** -7 if dt == 'bf16' else 2.0 ** -10
         d = (ys.float() - y.float()).abs()
         assert bool((d <= eps_ * y.float().abs() + 1e-5 * y.float().abs().max()).all())       # one rounding step at most ...
@@ -433,9 +434,9 @@ def test_search_in_output_row_chunks_matches_unchunked(monkeypatch):
     x = (torch.randn(N, K, generator=gen) * torch.exp(0.5 * torch.randn(K, generator=gen))).to(torch.bfloat16).cuda()
     ws = [(torch.randn(r, K, generator=gen) * 0.03).to(torch.bfloat16).cuda() for r in (512, 256, 300)]
     wq = IntegerQuantizer(4, True, 'per_group', group_size=128)
-    monkeypatch.delenv('LLMC_AWQ_Y_BYTES', raising=False)
+    _ffi.set_option('awq_y_bytes', (1 << 32) - (1 << 20))
     s0, l0, b0 = search_scale_stacked(ws, x, wq, 'v2', return_losses=True)
-    monkeypatch.setenv('LLMC_AWQ_Y_BYTES', str(2 * N * 512))          # 512 output rows per chunk -> 3 chunks
+    _ffi.set_option('awq_y_bytes', 2 * N * 512)          # 512 output rows per chunk -> 3 chunks
     s1, l1, b1 = search_scale_stacked(ws, x, wq, 'v2', return_losses=True)
     assert b0 == b1 and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
     np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5)
@@ -485,12 +486,12 @@ def test_small_fake_quant_forward_stays_on_the_hip_gemm_in_k_slices(monkeypatch,
         monkeypatch.setattr(awq_ops, 'linear_out', lambda *a, **k: calls.append(1) or orig(*a, **k))
         for shp in shapes:
             x = torch.randn(*shp, K, generator=gen).to(torch.bfloat16).cuda()
-            monkeypatch.delenv('LLMC_LINEAR_NOSPLIT', raising=False)
+            _ffi.set_option('linear_nosplit', 0)
             n0 = len(calls)
             y = m(x)
             yo = mo(x)
             assert len(calls) == n0 + 2                      # both wrappers ran the HIP GEMM
-            monkeypatch.setenv('LLMC_LINEAR_NOSPLIT', '1')
+            _ffi.set_option('linear_nosplit', 1)
             y1 = m(x)
             ref = x.float() @ lin.weight.data.float().T + (lin.bias.data.float() if bias else 0.0)
             assert y.shape == (*shp, R) and y.dtype == torch.bfloat16 and torch.equal(y, yo)

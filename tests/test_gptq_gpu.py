@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
+from llmc_amd import _ffi
 from oracle import gptq_ref as G
 from oracle import quant_ref as Q
 
@@ -21,7 +22,6 @@ def cu(a, dtype=torch.float32):
 
 
 def sgemm(A, B, C, M, N, Kd, TA, TB, epi, hints=(0, 0, 0, 0)):
-    from llmc_amd import _ffi
     L = _ffi.lib()
     _ffi.check(L.llmc_test_sgemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
                                  M, N, Kd, int(TA), int(TB), epi, *hints, _ffi.stream()), 'sgemm')
@@ -62,7 +62,6 @@ def test_sgemm_bitwise_chain(shape):
 
 
 def gemm3(A, B, C, M, N, Kd, TA, epi, hints=(0, 0, 0)):
-    from llmc_amd import _ffi
     L = _ffi.lib()
     _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
                                  M, N, Kd, int(TA), epi, *hints, _ffi.stream()), 'gemm3')
@@ -117,12 +116,12 @@ def test_gemm3_specialised_kernel_is_bit_identical(shape, monkeypatch):
     A = big[:, 8:]
     B = big[:, 1200:]
     C0 = torch.randn(M, N, generator=gen).cuda()
-    monkeypatch.setenv('LLMC_GEMM3S_MIN_TILES', '1')
+    _ffi.set_option('gemm3s_min_tiles', 1)
     for epi in (0, 1, 2):
         for hints in ((0, 0, 0), (0, 0, 1)) if M == N else ((0, 0, 0),):
-            monkeypatch.delenv('LLMC_GEMM3_NOSPEC', raising=False)
+            _ffi.set_option('gemm3_nospec', 0)
             c_new = gemm3(A, B, C0.clone(), M, N, Kd, True, epi, hints)
-            monkeypatch.setenv('LLMC_GEMM3_NOSPEC', '1')
+            _ffi.set_option('gemm3_nospec', 1)
             c_old = gemm3(A, B, C0.clone(), M, N, Kd, True, epi, hints)
             if hints[2]:
                 iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
@@ -139,7 +138,6 @@ def test_gemm3_specialised_kernel_is_bit_identical(shape, monkeypatch):
 def test_gemm3_planes_form_is_bit_identical(shape, monkeypatch):
     """The far updates' form with the panels split once into bf16 planes in memory (k_split3_planes + k_gemm3s copying
     planes) against k_gemm3 splitting inside every tile: same bits, every epilogue, upper-only included."""
-    from llmc_amd import _ffi
     L = _ffi.lib()
     M, N, Kd = shape
     gen = torch.Generator().manual_seed(M * 5 + Kd)
@@ -153,14 +151,14 @@ def test_gemm3_planes_form_is_bit_identical(shape, monkeypatch):
     C0 = torch.randn(M, N, generator=gen).cuda()
     ldp = (max(M, N) + 7) // 8 * 8
     ws = torch.full((6 * Kd * ldp,), -1, dtype=torch.int16).cuda()
-    monkeypatch.setenv('LLMC_GEMM3S_MIN_TILES', '1')
+    _ffi.set_option('gemm3s_min_tiles', 1)
     for epi in (0, 1, 2):
         for upper in (0, 1) if M == N else (0,):
-            monkeypatch.delenv('LLMC_GEMM3_NOSPEC', raising=False)
+            _ffi.set_option('gemm3_nospec', 0)
             c_new = C0.clone()
             _ffi.check(L.llmc_test_gemm3_planes(A.data_ptr(), B.data_ptr(), c_new.data_ptr(), A.stride(0), B.stride(0), c_new.stride(0),
                                                 M, N, Kd, epi, upper, ws.data_ptr(), _ffi.stream()), 'gemm3 planes')
-            monkeypatch.setenv('LLMC_GEMM3_NOSPEC', '1')
+            _ffi.set_option('gemm3_nospec', 1)
             c_old = gemm3(A, B, C0.clone(), M, N, Kd, True, epi, (0, 0, upper))
             if upper:
                 iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
@@ -400,9 +398,9 @@ def test_split_bf16_factor_is_as_accurate_as_fp32_on_outlier_channels(monkeypatc
     H += 0.01 * H.diag().mean() * torch.eye(K, dtype=torch.float64)
     Hd = H.float().cuda()
     Uref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd.double().cpu())), upper=True)
-    monkeypatch.delenv('LLMC_K3_FP32', raising=False)
+    _ffi.set_option('k3_fp32', 0)
     U3 = chol_inv_upper(Hd.clone()).double().cpu()
-    monkeypatch.setenv('LLMC_K3_FP32', '1')
+    _ffi.set_option('k3_fp32', 1)
     U1 = chol_inv_upper(Hd.clone()).double().cpu()
     e3 = ((U3 - Uref).abs().max() / Uref.abs().max()).item()
     e1 = ((U1 - Uref).abs().max() / Uref.abs().max()).item()
@@ -446,18 +444,17 @@ def test_chol_inv_upper_far_updates_on_planes_keep_every_bit(K, monkeypatch):
     X[:, ::5] *= 4
     H = ((X.T @ X) / K).cuda()
     H += 0.01 * H.diag().mean() * torch.eye(K, device='cuda')
-    monkeypatch.delenv('LLMC_K3_NO_PLANES', raising=False)
+    _ffi.set_option('k3_no_planes', 0)
     u_planes = chol_inv_upper(H.clone())
-    monkeypatch.setenv('LLMC_K3_NO_PLANES', '1')
+    _ffi.set_option('k3_no_planes', 1)
     u_plain = chol_inv_upper(H.clone())
     assert torch.equal(u_planes, u_plain)
     # the far update of an outer block as two launches (next block's rows, the rest) instead of one, and with the library's
     # helper streams (always two launches, the second beside the next block's chain)
-    monkeypatch.delenv('LLMC_K3_NO_PLANES', raising=False)
-    monkeypatch.setenv('LLMC_K3_SPLIT_FAR', '1')
+    _ffi.set_option('k3_no_planes', 0)
+    _ffi.set_option('k3_split_far', 1)
     assert torch.equal(chol_inv_upper(H.clone()), u_planes)
-    monkeypatch.delenv('LLMC_K3_SPLIT_FAR', raising=False)
-    from llmc_amd import _ffi
+    _ffi.set_option('k3_split_far', 0)
     prev = _ffi.lib().llmc_hip_set_helper_streams(0)
     try:
         u_single = chol_inv_upper(H.clone())
@@ -582,7 +579,6 @@ def test_factorisation_helper_stream_changes_no_bit_and_failure_flag_survives(K)
     without: the same kernels in the same per-element order, so the factor must be equal bit for bit (a missing dependency
     would show as a difference or as run-to-run noise); also from a caller's side stream; and a non-positive pivot is
     reported through the flag."""
-    from llmc_amd import _ffi
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
     gen = torch.Generator(device='cuda').manual_seed(K)
     X = torch.randn(2 * K, K, generator=gen, device='cuda')
@@ -609,7 +605,6 @@ def test_factorisation_helper_stream_changes_no_bit_and_failure_flag_survives(K)
 @pytest.mark.parametrize('shape', [(512, 4096), (4096, 2048), (192, 5248)])
 def test_pipelined_column_loop_is_bit_identical_to_the_single_stream_schedule(shape):
     """K4's far updates on the bulk stream (columns of the group after next first) against everything on one stream."""
-    from llmc_amd import _ffi
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper, gptq_quantize
     R, K = shape
     gen = torch.Generator(device='cuda').manual_seed(R + K)
@@ -638,7 +633,6 @@ def test_pipelined_owq_column_loop_is_bit_identical_to_the_single_stream_schedul
     """OWQ (n_quant < K) with helper streams: the last group's per-block updates write the never-visited columns
     [n_quant, K), which earlier groups' far-far updates on the bulk stream write too (a missing dependency
     whenever last_group_start + 512 < K). Bit-identical to the single-stream schedule, repeatedly."""
-    from llmc_amd import _ffi
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper, gptq_quantize
     R, K, nq = shape
     gen = torch.Generator(device='cuda').manual_seed(R + K + nq)
@@ -693,11 +687,8 @@ def test_reversed_prep_and_in_place_factor_give_the_same_bits(K, with_perm):
     cfg = GptqConfig(bit=4, symmetric=False, group_size=128, actorder=with_perm, static_groups=False)
     outs = []
     for flag in ('0', '1'):
-        os.environ['LLMC_K3_FUSED_PREP'] = flag
-        try:
+        with _ffi.option(k3_fused_prep=int(flag)):
             r = quantize_stacked([W], H.clone(), cfg)[0]
-        finally:
-            os.environ.pop('LLMC_K3_FUSED_PREP', None)
         outs.append((r.weight.clone(), r.scales.clone(), r.zeros.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)

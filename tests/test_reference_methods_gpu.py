@@ -71,8 +71,12 @@ def _bind_hessian(a, H):
 def test_gptq_per_layer_flow_by_reference_names_on_the_goldens_with_a_hessian():
     """gptq.npz carries H: hessian_sorting -> process_hessian_and_weights -> weight_transform -> the layer's end state."""
     g = load_golden('gptq')
+    checked = 0
     for name in [str(n) for n in g['names']]:
         p = name + '/'
+        if (p + 'H') not in g.files:
+            continue
+        checked += 1
         a, layer, c = _gptq(g, p)
         H = torch.from_numpy(g[p + 'H'].copy()).cuda()
         _bind_hessian(a, H)
@@ -101,6 +105,7 @@ def test_gptq_per_layer_flow_by_reference_names_on_the_goldens_with_a_hessian():
             if not c['sym']:
                 np.testing.assert_array_equal(host(layer.buf_zeros).ravel(), g[p + 'buf_zeros'].ravel(), err_msg=name)
             assert layer.buf_scales.shape == (c['R'] * c['K'] // c['gs'], 1) and layer.buf_scales.dtype == torch.float32
+    assert checked >= 2
 
 
 def test_gptq_weight_transform_by_name_mutates_losses_tmp_and_groups_like_the_reference():
@@ -260,7 +265,7 @@ def test_static_activation_ranges_by_reference_names():
     one = torch.cat([t for t in samples[:1]] * 3, 0)                  # the bs = -1 form: one tensor, samples along dim 0
     lo1, hi1 = q.get_static_minmax_range([one])
     assert float(lo1[0]) == float(samples[0].float().min()) and float(hi1[0]) == float(samples[0].float().max())
-    r = q.get_mse_range(torch.randn(16, 256, generator=gen).cuda())
+    r = IntegerQuantizer(4, False, 'per_channel', calib_algo='mse').get_mse_range(torch.randn(16, 256, generator=gen).cuda())
     assert r[0].shape == (16, 1) and bool((r[0] <= 0).all()) and bool((r[1] >= 0).all())
     with pytest.raises(ValueError):
         IntegerQuantizer(8, True, 'per_tensor').get_batch_tensors_qparams(list(samples))      # 'minmax': quant.py:573-574
