@@ -1,25 +1,21 @@
 #!/usr/bin/env python
 """bench.py — layers/sec of the GPTQ W4A16 hot path on Llama-3-8B Linear shapes (BASELINE.json metric).
 
-One "step" = GPTQ of one transformer block's seven Linear layers (q,k,v,o,gate,up,down; four distinct
-inputs) from 128 x 2048 resident calibration tokens: Hessian (MFMA) -> actorder/dead/damp -> Cholesky +
-inverse -> blocked column loop -> scales/zeros/compensated weights.  Synthetic inputs.
+One "step" = GPTQ of one transformer block's seven Linear layers (q,k,v,o,gate,up,down; four distinct inputs) from 128 x 2048
+resident calibration tokens: Hessian (MFMA, exact fp64 diagonal) -> actorder/dead/damp -> Cholesky + inverse -> blocked column
+loop -> scales/zeros/compensated weights.  Synthetic inputs.
 
   python bench.py --gpus N --steps K --warmup W
-N > 1 without a launcher: bench.py re-executes itself under `python -m torch.distributed.run` with N ranks (one per
-GPU, RCCL); under a launcher (WORLD_SIZE set) it is a rank.
-  no --mode with N > 1 ("auto"): the timed region runs `independent` (the contract value: it cannot wedge); a few steps of
-          `handoff` and of `cooperative` follow outside it and are reported as handoff_value / cooperative_value (or *_error).
-  --mode handoff (weak scaling): every rank quantizes its own blocks; a block's OUTPUT (o_proj's quantized weights applied to
-          its calibration input, [n_seq, seq, hidden], 2 GiB) goes to the ring successor over RCCL send/recv on a side stream,
-          overlapped with the next step, and the tensor received becomes the input of the step after next.
-  --mode independent (weak scaling): every rank quantizes its own blocks, no data-path traffic at all.
-  --mode cooperative (strong scaling): all ranks work on ONE block per step (llmc_amd/dist/layer_shard.py):
-          subsets with K <= 8192 — rank 0 broadcasts the Hessian (layers sharing an input) or the activations over
-          RCCL and the subset's layers are dealt round-robin; wider subsets (down_proj) — every rank accumulates the
-          Hessian of its own sequences, ONE all_reduce, redundant factorisation, row-sharded column loop, all_gather.
-  --dry   GPU-less plumbing check (gloo, CPU stand-ins instead of kernels, tiny shapes): spawn, collectives, timing
-          and the JSON line are exercised by tests/test_bench_spawn.py; the number it prints means nothing.
+N > 1 without a launcher: bench.py re-executes itself under `python -m torch.distributed.run` with N ranks (one per GPU, RCCL);
+under a launcher (WORLD_SIZE set) it is a rank.
+  no --mode, N > 1: ONE hand-off step is tried first (every rank, agreement over a Gloo control group). If it works the timed
+          region runs `handoff` — north_star's partition: every rank owns its blocks, a block's calibration activations arrive
+          from the previous owner over RCCL send/recv (xGMI) — and `independent_value` / `cooperative_value` follow outside it;
+          if it fails the timed region runs `independent` and the line says why (`handoff_error`).
+  --mode handoff | independent | cooperative: that mode only (cooperative: all ranks share ONE block per step, strong scaling:
+          Hessian / activation broadcast, sample-sharded all_reduce for the wide subset, llmc_amd/dist/layer_shard.py).
+  --dry   GPU-less plumbing check (gloo, CPU stand-ins instead of kernels, tiny shapes): tests/test_bench_spawn.py.
+  --workload awq | fp8: BASELINE configs[2] / configs[4] (tools/bench_extras.py), also reported under "extra" of the default line.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value + roofline + cpu_baseline.
 """
@@ -34,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_16BIT = 2.5e15  # dense bf16/f16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PARITY_FILE = 'profiles/r06_parity_envelope_full_down.json'
+TRAFFIC_FILES = ('r06_pmc_traffic.json', 'r04_pmc_traffic.json')
 
 MODELS = {
     # name: (hidden, kv_out, ffn, n_blocks)
@@ -55,22 +53,20 @@ def block_groups(model):
 def parity_envelope_summary(args):
     """End-to-end agreement with the reference on the configuration the metric is quoted on, from the committed measurement
     (tools/parity_envelope.py --full-down on an MI355X: the reference's own GPTQ class on the host cores / on ROCm / llmc_amd on
-    identical weights and the full 128 x 2048 calibration set, down_proj 4096 x 14336). Reported with the line so that
-    "bit-identical given identical upstream bits, statistical end to end" is a number: north_star's 1e-4 on float scales holds
-    for the bulk of the dynamic-group scales, not for the maximum — in the reference against itself as well."""
+    identical weights and the full 128 x 2048 calibration set, down_proj 4096 x 14336). `parity_live` of the same line is what THIS
+    run measured itself."""
     if args.model != 'llama3-8b':
         return None
     try:
-        src = 'profiles/r05_parity_envelope_full_down.json'
-        j = json.load(open(os.path.join(ROOT, src)))
+        j = json.load(open(os.path.join(ROOT, PARITY_FILE)))
         pr = j['shapes'][0]['pairs']['w_only' if args.variant == 'w_only' else 'vllm']
         pick = lambda m: {k: m[k] for k in ('codes_equal', 'scales_within_1e-4', 'scales_within_1e-2', 'zeros_equal', 'perm_equal',
                                             'perm_diff_within_4x_noise', 'H_diag_rel_max') if k in m}
-        ours = 'ours_exactdiag' if getattr(args, 'exact_diag', 0) else 'ours'
-        return {'layer': j['shapes'][0]['title'], 'source': src,
-                'precomputed': 'NOT measured by this run: read from the committed file (tools/parity_envelope.py --full-down on an MI355X, round 5)',
-                'arm': ours + (' (diag(H) re-formed in fp64: --exact-diag 1 / special.hessian_exact_diag)' if ours != 'ours' else
-                               ' (default; the exact-diagonal arm of the same file reaches the reference-vs-itself values: extra.gptq_exact_hessian_diag)'),
+        ours = 'ours' if args.exact_diag else 'ours_fp32diag'
+        return {'layer': j['shapes'][0]['title'], 'source': PARITY_FILE,
+                'precomputed': 'read from the committed file (tools/parity_envelope.py --full-down on an MI355X, round 6)',
+                'arm': ours + (' (the default: diag(H) folded into fp64 inside the Hessian kernel)' if args.exact_diag else
+                               ' (--exact-diag 0: the fp32 chain\'s own diagonal, rounds 1-5\'s default)'),
                 'ours_vs_reference_cpu': pick(pr['ref_cpu_32t vs ' + ours]),
                 'reference_cpu_vs_reference_rocm': pick(pr['ref_cpu_32t vs ref_rocm'])}
     except Exception:       # noqa: BLE001
@@ -86,49 +82,30 @@ def parse_args(argv=None):
     ap.add_argument('--n-seq', type=int, default=128)
     ap.add_argument('--seq-len', type=int, default=2048)
     ap.add_argument('--calib-bs', type=int, default=1,
-                    help='sequences per add_batch call (reference calib.bs). 1 (default) = the reference config\'s calling '
-                         'pattern (gptq_w_only.yml:12): 128 hook calls of [1, seq, K] per input, each sample its own '
-                         'allocation, walked by ONE kernel launch through the sample table; n_seq = one call on one tensor')
+                    help='sequences per add_batch call (reference calib.bs). 1 (default) = the reference config\'s calling pattern '
+                         '(gptq_w_only.yml:12): 128 hook calls of [1, seq, K] per input, each its own allocation, walked by ONE kernel '
+                         'launch through the sample table; n_seq = one call on one tensor')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
     ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
                     help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
                          'vllm: sym g128 static groups + INT4 pack (configs/quantization/backend/vllm/gptq_w4a16.yml)')
-    ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq', 'fp8'],
-                    help='gptq: the BASELINE.json metric (configs[1]); awq: configs[2], AWQ W4A16 g128 scale search + '
-                         'fake-quant evaluation on the same shapes, 128 x 512 calibration tokens, one batch; fp8: configs[4], FP8 '
-                         '(e4m3) per-tensor weight quantization + static per-tensor activation ranges on the Linear shapes of one '
-                         'Mixtral-8x7B block (8 experts)')
-    ap.add_argument('--mode', default=None, choices=['independent', 'handoff', 'cooperative'],
-                    help='N > 1 (default handoff): independent = every rank quantizes its own blocks, no data-path traffic; '
-                         'handoff = the same ownership, and the calibration activations entering a block arrive from the '
-                         'rank that owns the previous block over RCCL send/recv (xGMI), overlapped with compute; '
-                         'cooperative = all ranks share ONE block (broadcast / sample-sharded all_reduce, strong scaling)')
-    ap.add_argument('--helpers', choices=['none', 'wide', 'all'], default=None,
-                    help='which chains may use the internal helper streams of K3 / K4 (pipelined schedules, round 4): none, the widest (down_proj), all')
-    ap.add_argument('--wide-helper', type=int, default=0, help='1: the widest chain (down_proj) keeps its internal helper stream (measured 94.5 vs 93.7 ms per step without: the three other chains already fill the gaps)')
-    ap.add_argument('--reserve', type=int, default=32, help='--order shadow: CUs the widest Hessian leaves to the other chains')
-    ap.add_argument('--order', choices=['chain', 'k1first', 'shadow'], default='k1first',
-                    help='subset schedule when --overlap > 1 (see step_independent)')
-    ap.add_argument('--exact-diag', type=int, default=0,
-                    help='1: diag(H) re-formed in fp64 by a second pass over the samples (GPTQ special.hessian_exact_diag); off by default')
-    ap.add_argument('--small-streams', type=int, default=0,
-                    help='k1first order: 0 = one stream per chain (default); n > 0 = the widest chain (largest K) alone on stream 0 and the '
-                         'other chains dealt round-robin over n further streams (1 = serialised behind each other)')
+    ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq', 'fp8'])
+    ap.add_argument('--mode', default=None, choices=['independent', 'handoff', 'cooperative'])
+    ap.add_argument('--exact-diag', type=int, default=1, help='0: keep the MFMA kernel\'s fp32 diagonal of H (A/B; rounds 1-5\'s default)')
+    ap.add_argument('--merge-k1', type=int, default=1,
+                    help='1 (default): the Hessians of one width (three K = 4096 inputs) in ONE launch (one unit queue); 0: one launch each')
     ap.add_argument('--overlap', type=int, default=4,
-                    help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); '
-                         '0 = one after the other on the current stream')
+                    help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); 0 = serial')
     ap.add_argument('--dry', action='store_true', help='GPU-less plumbing check (gloo + CPU stand-ins)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
-                    help='skip the secondary workloads reported under "extra" (N = 1 only): AWQ (BASELINE configs[2]), the '
-                         'vLLM-exportable GPTQ variant with INT4 packing, Llama-3-70B shapes, FP8 on Mixtral shapes (configs[4])')
+                    help='skip the secondary workloads reported under "extra" (N = 1 only): AWQ (configs[2]), the INT4-packing GPTQ '
+                         'variant, Llama-3-70B shapes (configs[3]), FP8 on Mixtral shapes (configs[4])')
     return ap.parse_args(argv)
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# self-spawn: `python bench.py --gpus N` on a bare shell launches N ranks of itself
-# ---------------------------------------------------------------------------------------------------------------
 def maybe_spawn(args):
+    """`python bench.py --gpus N` on a bare shell launches N ranks of itself."""
     if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
         return None
     import socket
@@ -143,9 +120,7 @@ def maybe_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# synthetic inputs
-# ---------------------------------------------------------------------------------------------------------------
+# ---- synthetic inputs ------------------------------------------------------------------------------------
 def synth_weight(R, K, seed, device, dtype):
     import torch
     g = torch.Generator(device=device).manual_seed(1000 + seed)
@@ -170,9 +145,7 @@ def synth_acts(n_seq, seq, K, seed, device, dtype):
     return x
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# CPU baseline: the reference itself (oracle/_ref, built by __graft_entry__.build()) or, failing that, the port
-# ---------------------------------------------------------------------------------------------------------------
+# ---- CPU baseline: the reference itself (oracle/_ref, built by __graft_entry__.build()) or, failing that, the port ---------
 def _block_model(model, n_seq, t_h_seq, t_chol, t_loop, K):
     """One block as the reference executes it (7 Hessians / factorisations / loops), pieces scaled by flop count."""
     t_block, layers = 0.0, 0
@@ -185,9 +158,7 @@ def _block_model(model, n_seq, t_h_seq, t_chol, t_loop, K):
 
 def cpu_baseline_reference(model, n_seq, seq):
     cores = os.cpu_count() or 1
-    h = MODELS[model][0]
-    K = min(h, 4096)
-    nb = 4
+    K, nb = min(MODELS[model][0], 4096), 4
     script = os.path.join(ROOT, 'oracle', 'ref_baseline.py')
     if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'llmc')):
         raise RuntimeError('oracle/_ref missing (built by __graft_entry__.build() where /root/reference exists)')
@@ -202,44 +173,14 @@ def cpu_baseline_reference(model, n_seq, seq):
         'unit': 'layers/s', 'cores': t['threads'], 'kind': 'reference',
         'host_cores': t.get('host_cores', cores), 'hessian_thread_sweep_s': t.get('hessian_thread_sweep_s'),
         'hessian_gflops': t.get('hessian_gflops'),
-        'sample': (f"llmc's own GPTQ (oracle/_ref = /root/reference after its ci_check/change_files.py CPU rewrite), torch "
-                   f"CPU, {t['threads']} threads for the Hessian GEMM (the best of a sweep over 8..{t.get('host_cores', cores)} threads: "
-                   f"{t.get('hessian_gflops', 0.0):.0f} GFLOP/s) and {t.get('threads_small_ops', t['threads'])} for the "
-                   f"factorisations / column loop (more threads make those slower): add_batch on {nb} of {n_seq} sequences of one {K}-channel input "
-                   f"({t['t_hessian_per_seq']:.3f} s/seq), process_hessian_and_weights ({t['t_factor']:.2f} s) and "
-                   f"weight_transform ({t['t_loop']:.2f} s) of one {K}x{K} layer in full; other shapes scaled by flop "
-                   'count; 7 Hessians per block as the reference executes them'),
+        'sample': (f"llmc's own GPTQ (oracle/_ref = /root/reference after its ci_check/change_files.py CPU rewrite), torch CPU, "
+                   f"{t['threads']} threads for the Hessian GEMM (the best of a sweep over 8..{t.get('host_cores', cores)} threads: "
+                   f"{t.get('hessian_gflops', 0.0):.0f} GFLOP/s) and {t.get('threads_small_ops', t['threads'])} for the factorisations / "
+                   f"column loop (more threads make those slower): add_batch on {nb} of {n_seq} sequences of one {K}-channel input "
+                   f"({t['t_hessian_per_seq']:.3f} s/seq), process_hessian_and_weights ({t['t_factor']:.2f} s) and weight_transform "
+                   f"({t['t_loop']:.2f} s) of one {K}x{K} layer in full; other shapes scaled by flop count; 7 Hessians per block as the "
+                   'reference executes them'),
     }
-
-
-def cpu_baseline_reference_awq(groups, N):
-    """The reference's own AWQ grid step (oracle/ref_baseline.py --workload awq: Awq.get_scales / fake_quantize_weight /
-    inspect_module_forward / calculate_loss of oracle/_ref) on two token counts of one 4096 x 4096 layer: t = a + b * tokens
-    separates the per-weight work from the per-token work; a block = 4 searches of 21 evaluations, scaled by R * K."""
-    script = os.path.join(ROOT, 'oracle', 'ref_baseline.py')
-    if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'llmc')):
-        raise RuntimeError('oracle/_ref missing (built by __graft_entry__.build() where /root/reference exists)')
-    K0, ts = 4096, {}
-    thr = min(os.cpu_count() or 1, 32)      # 256 threads: 3.4 s per step whatever the token count (thread overhead); 16-32 suit these ops
-    for tok in (2048, 4096):
-        r = subprocess.run([sys.executable, script, '--workload', 'awq', '--K', str(K0), '--tokens', str(tok), '--threads', str(thr)],
-                           capture_output=True, text=True, timeout=200)
-        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
-        if r.returncode != 0 or not line:
-            raise RuntimeError('reference AWQ baseline failed: ' + (r.stderr or r.stdout)[-300:])
-        ts[tok] = json.loads(line[-1])
-    b = max(0.0, (ts[4096]['t_grid_step'] - ts[2048]['t_grid_step']) / 2048)
-    a = max(0.0, ts[2048]['t_grid_step'] - b * 2048)
-    t_block, layers = 0.0, 0
-    for _, K, ls in groups:
-        rk = sum(r for _, r in ls) * K / (K0 * K0)
-        t_block += 21 * (a + b * N) * rk
-        layers += len(ls)
-    return {'value': layers / t_block, 'unit': 'layers/s', 'cores': ts[2048]['threads'], 'kind': 'reference',
-            'sample': (f"llmc's own Awq methods (oracle/_ref), torch CPU, {ts[2048]['threads']} threads: 3 grid steps (get_scales, x / s, "
-                       f"fake_quantize_weight, F.linear through inspect_module_forward, calculate_loss, state-dict restore) of one "
-                       f"{K0}x{K0} layer on 2048 and 4096 tokens ({ts[2048]['t_grid_step']:.2f} s and {ts[4096]['t_grid_step']:.2f} s per "
-                       f'step); linear in tokens and in R*K to {N} tokens and the 4 stacked subsets, 21 evaluations per search')}
 
 
 def cpu_baseline_port(model, n_seq, seq, cfg):
@@ -249,33 +190,26 @@ def cpu_baseline_port(model, n_seq, seq, cfg):
     from oracle import gptq_ref as G
     from oracle import quant_ref as Q
     cores = os.cpu_count() or 1
-    K = min(MODELS[model][0], 4096)
+    K, nb = min(MODELS[model][0], 4096), 4
     rng = np.random.RandomState(0)
-    nb = 4
-    H = np.zeros((K, K), dtype=np.float32)
-    n = 0
+    H, n = np.zeros((K, K), dtype=np.float32), 0
     t0 = time.time()
     for _ in range(nb):
-        x = rng.standard_normal((seq, K)).astype(np.float32)
-        H, n = G.add_batch(H, n, x)
+        H, n = G.add_batch(H, n, rng.standard_normal((seq, K)).astype(np.float32))
     t_h_seq = (time.time() - t0) / nb
     H += np.eye(K, dtype=np.float32) * 0.1
     W = (rng.standard_normal((K, K)) * 0.02).astype(np.float32)
     t0 = time.time()
-    perm = G.hessian_sorting(H)
-    Wp, U = G.process_hessian_and_weights(W, H, perm, cfg.percdamp)
+    Wp, U = G.process_hessian_and_weights(W, H, G.hessian_sorting(H), cfg.percdamp)
     t_chol = time.time() - t0
     qmin, qmax = Q.int_range(cfg.bit, cfg.symmetric)
     t0 = time.time()
     G.weight_transform(Wp, U, cfg.symmetric, qmin, qmax, cfg.group_size)
     t_loop = time.time() - t0
-    return {
-        'value': _block_model(model, n_seq, t_h_seq, t_chol, t_loop, K), 'unit': 'layers/s', 'cores': cores,
-        'kind': 'port',
-        'sample': (f'numpy/C oracle on {cores} host threads: Hessian = {nb} of {n_seq} sequences of one {K}-channel '
-                   f'input ({t_h_seq:.3f} s/seq), factorisation ({t_chol:.2f} s) and column loop ({t_loop:.2f} s) of '
-                   f'one {K}x{K} layer in full; other shapes scaled by flop count'),
-    }
+    return {'value': _block_model(model, n_seq, t_h_seq, t_chol, t_loop, K), 'unit': 'layers/s', 'cores': cores, 'kind': 'port',
+            'sample': (f'numpy/C oracle on {cores} host threads: Hessian = {nb} of {n_seq} sequences of one {K}-channel input '
+                       f'({t_h_seq:.3f} s/seq), factorisation ({t_chol:.2f} s) and column loop ({t_loop:.2f} s) of one {K}x{K} layer '
+                       'in full; other shapes scaled by flop count')}
 
 
 def cpu_baseline(model, n_seq, seq, cfg):
@@ -287,20 +221,17 @@ def cpu_baseline(model, n_seq, seq, cfg):
         return out
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# compute back ends: the HIP path (product) and CPU stand-ins for --dry
-# ---------------------------------------------------------------------------------------------------------------
+# ---- compute back ends: the HIP path (product) and CPU stand-ins for --dry ---------------------------------------------------
 class HipOps:
     """The product path: llmc_amd classes over libllmc_hip.so. Raises without an MI355X."""
 
-    def __init__(self, dev, cfg, variant, exact_diag=False):
+    def __init__(self, dev, cfg, variant, exact_diag=True):
         import torch
-        self.exact_diag = bool(exact_diag)
 
         from llmc_amd.compression.quantization import IntegerQuantizer, pack_lsb
         from llmc_amd.compression.quantization import gptq_pipeline as P
         from llmc_amd.compression.quantization.hessian import HessianAccumulator
-        self.torch, self.dev, self.cfg, self.variant = torch, dev, cfg, variant
+        self.torch, self.dev, self.cfg, self.variant, self.exact_diag = torch, dev, cfg, variant, bool(exact_diag)
         self.P, self.Acc, self.pack_lsb = P, HessianAccumulator, pack_lsb
         self.wq = IntegerQuantizer(cfg.bit, cfg.symmetric, 'per_group', group_size=cfg.group_size)
         self.accs, self.hwork, self.streams = {}, {}, {}
@@ -314,7 +245,8 @@ class HipOps:
         a.timing = self.timing
         return a
 
-    def hessian(self, name, K, x, calib_bs):
+    def feed(self, name, K, x, calib_bs):
+        """add_batch calls of one input (deferred: nothing is launched yet)"""
         a = self.acc(name, K)
         a.reset()
         if isinstance(x, (list, tuple)):          # per-call tensors, each its own allocation (hook calls)
@@ -323,7 +255,17 @@ class HipOps:
         else:
             for i in range(0, x.shape[0], calib_bs):
                 a.add(x[i:i + calib_bs])
-        return a.H
+        return a
+
+    def hessian(self, name, K, x, calib_bs):
+        return self.feed(name, K, x, calib_bs).H
+
+    def hessians(self, items, calib_bs, merge=True):
+        """items: [(name, K, x)] -> {name: H}. merge: inputs of one width share ONE launch (HessianAccumulator.flush_many)."""
+        accs = [self.feed(n, K, x, calib_bs) for n, K, x in items]
+        if merge:
+            self.Acc.flush_many(accs)
+        return {n: a.H for (n, _, _), a in zip(items, accs)}
 
     def static_qparams(self, weights):
         if not self.cfg.static_groups:
@@ -355,18 +297,12 @@ class HipOps:
 
     def stream(self, i):
         if i not in self.streams:
-            # stream 0 carries the longest chain: its many short kernels go ahead of the other chains' in the queues
-            prio = -1 if (i == 0 and os.environ.get('LLMC_BENCH_PRIO', '0') == '1') else 0   # measured: no effect
-            self.streams[i] = self.torch.cuda.Stream(device=self.dev, priority=prio)
+            self.streams[i] = self.torch.cuda.Stream(device=self.dev)
         return self.streams[i]
 
     def helper_streams(self, enable):
         from llmc_amd import _ffi
         return _ffi.helper_streams(enable)
-
-    def cu_reserve(self, n):
-        from llmc_amd import _ffi
-        return _ffi.cu_reserve(n)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -384,6 +320,9 @@ class DryOps:
             x = self.torch.cat(list(x), 0)
         xf = x.reshape(-1, K).float()
         return (xf.T @ xf) * (2.0 / x.shape[0])
+
+    def hessians(self, items, calib_bs, merge=True):
+        return {n: self.hessian(n, K, x, calib_bs) for n, K, x in items}
 
     def quantize(self, name, weights, H, rows=None):
         w = self.torch.cat([t.float() for t in weights], 0)
@@ -404,231 +343,20 @@ class DryOps:
         pass
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# AWQ workload (BASELINE.json configs[2]): per block, the four subsets' 20-point scale searches (awq.py:179-253) with
-# inspect = the subset's Linear layers, N = 128 x 512 tokens in one batch, W4 symmetric g128, trans v2
-# ---------------------------------------------------------------------------------------------------------------
-def run_awq(args):
-    import torch
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback in llmc_amd)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=dev)
-    from llmc_amd.compression.quantization import IntegerQuantizer, awq_ops
-    from llmc_amd.compression.quantization.awq_pipeline import search_scale_stacked
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
-    n_seq, seq = 128, 512                                  # configs/quantization/methods/Awq/awq_w_only.yml:12-14
-    N = n_seq * seq
-    wq = IntegerQuantizer(4, True, 'per_group', group_size=128)
-    groups = block_groups(args.model)
-    acts = {name: synth_acts(n_seq, seq, K, rank * 64 + gi, dev, dtype).reshape(N, K) for gi, (name, K, _) in enumerate(groups)}
-    weights = {name: [synth_weight(R, K, rank * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
-               for gi, (name, K, layers) in enumerate(groups)}
-    gemm_ev = []
-
-    def step(record):
-        out = []
-        for name, K, layers in groups:
-            out.append(search_scale_stacked(weights[name], acts[name], wq, 'v2', timing=gemm_ev if record else None))
-        return out
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    # weight_clip: True in awq_w_only.yml runs AutoClipper after the scale search (auto_clip.py:37-77: every Linear except q / k,
-    # n_sample_token = calib seq_len = 512). Not part of configs[2]'s metric (scale search + fake-quant evaluation); timed once,
-    # outside the timed region, and reported beside it.
-    clip_ms = None
-    try:
-        step_tok = max(1, N // seq)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for name, K, layers in groups:
-            xs = acts[name][0::step_tok]
-            for (lname, R), w in zip(layers, weights[name]):
-                if lname in ('q_proj', 'k_proj'):
-                    continue
-                awq_ops.clip_search(w, xs, wq, True)
-        e1.record()
-        torch.cuda.synchronize()
-        clip_ms = e0.elapsed_time(e1)
-    except Exception:
-        clip_ms = None
-    n_layers = sum(len(ls) for _, _, ls in groups)
-    fl_eval = sum(2.0 * N * sum(r for _, r in ls) * K for _, K, ls in groups)        # one evaluation of every subset
-    fl = sum(f for _, _, f in gemm_ev)
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_ev)
-    if rank == 0:
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        awq_traffic = awq_traffic_src = None
-        tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_awq.json')
-        if args.model == 'llama3-8b' and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))['k_linear_eval4']
-                awq_traffic, awq_traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r02_pmc_traffic_awq.json (' + tj['note'] + ')'
-            except Exception:
-                pass
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                cpu = cpu_baseline_reference_awq(groups, N)
-            except Exception as e:
-                cpu = {'value': None, 'unit': 'layers/s', 'cores': os.cpu_count(), 'kind': 'reference',
-                       'sample': f'failed: {type(e).__name__}: {str(e)[:160]}'}
-        print(json.dumps({
-            'metric': 'layers/sec (AWQ W4A16 g128 scale search + fake-quant eval, %s Linear shapes, 128x512 calib)' % args.model,
-            'value': n_layers * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'AWQ W4A16 g128 sym, trans v2, 20-point scale search with inspect = the Linear layers, '
-                                   f'{args.model}-shaped random-init layers, 1 block (7 Linear, 4 subsets) per step per GPU',
-                       'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'layer-sharded x{world}' if world > 1 else 'single GPU',
-                       'auto_clip_ms_per_block_not_in_value': clip_ms},
-            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
-                         'frac': ach * 1e12 / PEAK_MFMA_16BIT, 'traffic': awq_traffic, 'traffic_source': awq_traffic_src,
-                         'kernel': 'k_linear_eval4 (llmc_linear_eval_kt, the 21 products of a search; k_linear_eval when K % 128 != 0)', 'launches': len(gemm_ev),
-                         'algorithmic_flops_per_launch': fl / max(1, len(gemm_ev)), 'avg_launch_ms': ms / max(1, len(gemm_ev)),
-                         'whole_search_tflops': 21 * fl_eval * args.steps / dt / 1e12},
-            'cpu_baseline': cpu,
-        }), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
-
-
-PEAK_HBM = 8.0e12   # spec, /opt/skills/guides/MI355X_MICROARCH.md (about 6.3e12 measured)
-
-
-def run_fp8(args):
-    """BASELINE configs[4]: FP8 (e4m3) per-tensor weight + activation quantization on Mixtral-8x7B expert Linear shapes
-    (configs/quantization/backend/vllm/fp8/*.yml with per_tensor granularity). Quantization time, per block: every Linear's
-    weight -> absmax -> scale -> e4m3 codes (FloatQuantizer.real_quant_weight_dynamic: llmc_minmax_qparams + llmc_fp8_quant),
-    and the static per-tensor range of every Linear input over the calibration tokens (mean of per-sample min / max,
-    base_blockwise_quantization.py:253-263: llmc_minmax_samples, one launch pair per input)."""
-    import torch
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback in llmc_amd)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=dev)
-    from llmc_amd.compression.quantization import FloatQuantizer
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
-    h, kv, ffn, n_exp = 4096, 1024, 14336, 8              # Mixtral-8x7B: llmc/models/mixtral.py:43-86
-    layers = [('q_proj', h, h), ('k_proj', kv, h), ('v_proj', kv, h), ('o_proj', h, h)]
-    for e in range(n_exp):
-        layers += [(f'experts.{e}.w1', ffn, h), (f'experts.{e}.w3', ffn, h), (f'experts.{e}.w2', h, ffn)]
-    n_seq, seq = 128, 512
-    wq = FloatQuantizer('e4m3', True, 'per_tensor', use_qtorch=True)
-    weights = [synth_weight(R, K, rank * 64 + i, dev, dtype) for i, (_, R, K) in enumerate(layers)]
-    # inputs: attention in, o_proj in (all tokens); an expert sees top-2 of 8 = a quarter of the tokens on average
-    acts = {'attn_in': synth_acts(n_seq, seq, h, rank * 64 + 1, dev, dtype), 'o_in': synth_acts(n_seq, seq, h, rank * 64 + 2, dev, dtype)}
-    for e in range(n_exp):
-        acts[f'e{e}_in'] = synth_acts(n_seq // 4, seq, h, rank * 64 + 8 + e, dev, dtype)
-        acts[f'e{e}_mid'] = synth_acts(n_seq // 4, seq, ffn, rank * 64 + 24 + e, dev, dtype)
-
-    from llmc_amd.compression.quantization.hist_range import sample_minmax
-    samples = {k: [x[i] for i in range(x.shape[0])] for k, x in acts.items()}      # what the hooks deliver: one tensor per sample
-
-    def step():
-        out = [wq.real_quant_weight_dynamic(w) for w in weights]
-        for k in acts:                # static_minmax: mean over samples of the per-sample range (register_act_qparams)
-            mn, mx = sample_minmax(samples[k])
-            out.append(torch.max(mx.mean().abs(), mn.mean().abs()).clamp(min=1e-5) / 448.0)
-        return out
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    # the dominant kernel alone: the cast of one 14336 x 4096 weight, HIP events on the current stream
-    w = weights[4]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    wq.real_quant_weight_dynamic(w)
-    e0.record()
-    for _ in range(reps):
-        wq.real_quant_weight_dynamic(w)
-    e1.record()
-    torch.cuda.synchronize()
-    t_w = e0.elapsed_time(e1) * 1e-3 / reps
-    wbytes = 5.0 * w.numel()          # 2 B min/max pass + 2 B cast pass + 1 B codes
-    if rank == 0:
-        elems = sum(R * K for _, R, K in layers)
-        abytes = sum(2.0 * x.numel() for x in acts.values())
-        print(json.dumps({
-            'metric': 'layers/sec (FP8 e4m3 per-tensor weight quantization + static activation ranges, Mixtral-8x7B block shapes)',
-            'value': len(layers) * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f8e4m3 codes from ' + args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'FP8 e4m3 symmetric per-tensor RTN: 28 Linear weights of one Mixtral-8x7B block (4 attention + 8 experts '
-                                   'x 3) -> absmax, scale, codes; static per-tensor ranges of their 18 inputs (128 x 512 calibration '
-                                   'tokens, experts a quarter each), 1 block per step per GPU',
-                       'n_seq': n_seq, 'seq_len': seq, 'parallelism': f'block-sharded x{world}' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'hbm', 'achieved': wbytes / t_w / 1e9, 'peak': PEAK_HBM / 1e9, 'unit': 'GB/s',
-                         'frac': wbytes / t_w / PEAK_HBM, 'traffic': None,
-                         'kernel': 'k_minmax_partial + k_fp8_cast on a 14336 x 4096 weight (5 B per element: two 16-bit reads, one code '
-                                   'written); the Python call, events on the launch stream',
-                         'launches': reps, 'algorithmic_bytes_per_launch': wbytes, 'avg_launch_ms': t_w * 1e3,
-                         'whole_step_gbps': (5.0 * elems + abytes) * args.steps / dt / 1e9},
-            'cpu_baseline': None,
-        }), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
-
-
 def run_extras(args):
-    """The secondary workloads, a few steps each, as child runs of this script (same code path as their own bench
-    lines): value / ms_per_step / roofline of each go under "extra" of the one JSON line."""
+    """The secondary workloads, a few steps each, as child runs (same code path as their own bench lines)."""
+    extras = os.path.join(ROOT, 'tools', 'bench_extras.py')
+    me = os.path.abspath(__file__)
     runs = {
-        'awq_llama3_8b': ['--workload', 'awq', '--steps', '2', '--warmup', '1'],
-        'gptq_vllm_variant_packed': ['--variant', 'vllm', '--steps', '3', '--warmup', '1'],
-        # the same workload with diag(H) re-formed in fp64 (GPTQ special.hessian_exact_diag): what the reference-level parity
-        # envelope costs (config.parity_envelope of this entry carries the measured agreement of that arm)
-        'gptq_exact_hessian_diag': ['--exact-diag', '1', '--steps', '3', '--warmup', '1'],
-        'gptq_llama3_70b_shapes': ['--model', 'llama3-70b', '--steps', '2', '--warmup', '1'],
-        'fp8_mixtral_8x7b_shapes': ['--workload', 'fp8', '--steps', '3', '--warmup', '1'],
+        'awq_llama3_8b': (me, ['--workload', 'awq', '--steps', '2', '--warmup', '1']),
+        'gptq_vllm_variant_packed': (me, ['--variant', 'vllm', '--steps', '3', '--warmup', '1']),
+        'gptq_llama3_70b_shapes': (me, ['--model', 'llama3-70b', '--steps', '2', '--warmup', '1']),
+        'fp8_mixtral_8x7b_shapes': (me, ['--workload', 'fp8', '--steps', '3', '--warmup', '1']),
     }
     out = {}
-    for key, flags in runs.items():
-        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-cpu-baseline', '--no-extras',
-               '--dtype', args.dtype] + flags
+    assert os.path.exists(extras)
+    for key, (script, flags) in runs.items():
+        cmd = [sys.executable, script, '--gpus', '1', '--no-cpu-baseline', '--no-extras', '--dtype', args.dtype] + flags
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -636,8 +364,7 @@ def run_extras(args):
                 out[key] = {'error': (r.stderr or r.stdout)[-300:]}
                 continue
             j = json.loads(line[-1])
-            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline')
-                        if k in j}
+            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline') if k in j}
         except Exception as e:
             out[key] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
     return out
@@ -648,10 +375,10 @@ def main():
     rc = maybe_spawn(args)
     if rc is not None:
         sys.exit(rc)
-    if args.workload == 'awq':
-        return run_awq(args)
-    if args.workload == 'fp8':
-        return run_fp8(args)
+    if args.workload in ('awq', 'fp8'):
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_extras
+        return bench_extras.run_awq(args) if args.workload == 'awq' else bench_extras.run_fp8(args)
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -669,22 +396,16 @@ def main():
             raise SystemExit(f'rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
-    # N > 1 without --mode ("auto"): the CONTRACT value is measured with block-sharded ownership and no data-path traffic
-    # (`independent`: it cannot wedge), and two secondary values follow outside the timed region, each behind a
-    # try / except and an agreement over a Gloo control group: `handoff_value` (the same ownership with the block outputs
-    # handed owner-to-owner over RCCL send/recv) and `cooperative_value` (north_star's partition: one block shared by all
-    # ranks, activations / Hessians broadcast, the wide subset sample-sharded + all_reduce). ADVICE r03: a wedged transfer
-    # must not take the contract line with it.
-    auto = args.mode is None and world > 1
+    auto = args.mode is None and world > 1          # north_star's partition if its pre-flight step works, else block-sharded without traffic
     if args.mode is None:
-        args.mode = 'independent'
+        args.mode = 'handoff' if auto else 'independent'
     ctl = None          # control-plane group (flags, max-over-ranks times): Gloo, CPU tensors — never the data path's RCCL
     if world > 1:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # a bounded collective timeout, and on expiry the watchdog aborts the COMMUNICATOR, not the process: the blocked
-        # call raises, the secondary measurement is recorded as failed, the line is still printed
+        # a bounded collective timeout, and on expiry the watchdog aborts the COMMUNICATOR, not the process: the blocked call
+        # raises, the measurement is recorded as failed, the line is still printed
         os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '2')
         if args.dry:
             dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))
@@ -704,30 +425,26 @@ def main():
     from llmc_amd.compression.quantization.gptq_pipeline import GptqConfig
     from llmc_amd.dist import layer_shard as LS
 
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
-    if args.dry:
-        dtype = torch.float32
-    if args.variant == 'w_only':
-        cfg = GptqConfig(bit=4, symmetric=False, group_size=128, actorder=True, static_groups=False)
-    else:
-        cfg = GptqConfig(bit=4, symmetric=True, group_size=128, actorder=True, static_groups=True)
+    dtype = torch.float32 if args.dry else (torch.bfloat16 if args.dtype == 'bf16' else torch.float16)
+    cfg = GptqConfig(bit=4, symmetric=args.variant != 'w_only', group_size=128, actorder=True, static_groups=args.variant != 'w_only')
     groups = block_groups(args.model)
     ops = DryOps(cfg) if args.dry else HipOps(dev, cfg, args.variant, exact_diag=bool(args.exact_diag))
     n_layers_block = sum(len(ls) for _, _, ls in groups)
     timing = []
-    # payload each mode moves between ranks per step (per rank; a ring all-reduce moves 2 (N - 1) / N of its payload):
-    # handoff = the block's first input; cooperative = per subset the broadcast Hessian (stacked subsets), the broadcast
-    # activations (single-layer subsets) or the all-reduced Hessian (sample-sharded wide subset)
+    # payload each mode moves between ranks per step and rank (a ring all-reduce moves 2 (N - 1) / N of its payload): handoff =
+    # the block's first input; cooperative = per subset the broadcast Hessian (stacked subsets), the broadcast activations
+    # (single-layer subsets) or the all-reduced Hessian (sample-sharded wide subset)
     esz = 4 if args.dry else 2
     interrank_bytes = {
+        'independent': 0,
         'handoff': args.n_seq * args.seq_len * groups[0][1] * esz,
         'cooperative': sum((K * K * 4) if (K > 8192 or len(ls) > 1) else args.n_seq * args.seq_len * K * esz for _, K, ls in groups),
     }
 
     def prepare(mode):
-        """Resident synthetic data and the step function of one mode. independent / handoff: every rank owns different
-        blocks (different seeds). cooperative: one block; rank 0 holds the full activations of the broadcast subsets, every
-        rank holds its own sequences (rank::world) of the sample-sharded ones; weights are the same on every rank."""
+        """Resident synthetic data and the step function of one mode. independent / handoff: every rank owns different blocks
+        (different seeds). cooperative: one block; rank 0 holds the full activations of the broadcast subsets, every rank holds
+        its own sequences (rank::world) of the sample-sharded ones; weights are the same on every rank."""
         coop = mode == 'cooperative' and world > 1
         handoff = mode == 'handoff' and world > 1
         acts, weights, plan = {}, {}, {}
@@ -735,8 +452,7 @@ def main():
             seed_r = 0 if coop else rank
             plan[name] = ('sample' if K > 8192 else 'broadcast') if coop else 'local'
             if plan[name] == 'sample':
-                n_mine = len(range(rank, args.n_seq, world))
-                acts[name] = synth_acts(n_mine, args.seq_len, K, 64 * rank + gi, dev, dtype)
+                acts[name] = synth_acts(len(range(rank, args.n_seq, world)), args.seq_len, K, 64 * rank + gi, dev, dtype)
             elif plan[name] == 'broadcast':
                 acts[name] = synth_acts(args.n_seq, args.seq_len, K, gi, dev, dtype) if rank == 0 else None
             else:
@@ -750,79 +466,24 @@ def main():
             weights[name] = [synth_weight(R, K, seed_r * 64 + gi * 8 + li, dev, dtype) for li, (_, R) in enumerate(layers)]
 
         def step_independent(record):
+            """K1 first — the MFMA kernel owns every CU, nothing overlaps with it: the Hessians of one width in one launch — then
+            the four subsets' factorisations and column loops, independent latency-bound chains, on one stream each, widest
+            first, the library's internal helper streams off (measured schedules: profiles/NOTES.md, r05_schedule_experiments.txt)."""
             ops.timing = timing if record else None
-            outs = []
-            Hs = {}
+            Hs = ops.hessians([(name, K, acts[name]) for name, K, _ in groups], args.calib_bs, merge=bool(args.merge_k1))
             if args.overlap <= 1 or args.dry:
-                for name, K, layers in groups:      # K1 first: the MFMA kernel owns every CU, nothing overlaps with it
-                    Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-                for name, K, layers in groups:
-                    outs.append(ops.quantize(name, weights[name], Hs[name]))
-                return outs
-            # the four subsets' factorisations and column loops are independent latency-bound chains: one stream each.
-            # --order k1first (default): all four Hessians, then the four chains, widest first.
-            # --order chain: the subset with the longest K1 -> K3 -> K4 chain (down: 39 + 22 + 11 ms) goes first and its
-            # chain starts the moment its Hessian is done, the other Hessians and chains behind it. Measured on one box:
-            # 99.2 ms/step against 98.0 for k1first (K1 drops from 0.564 to 0.535 of peak): a k_syrk4 block owns its CU
-            # (512 VGPRs, 128 KiB LDS) and its tile list is static, so every CU a chain kernel holds when a Hessian starts
-            # delays that Hessian's tail, and the chain in turn waits for whole Hessians to retire.
+                return [ops.quantize(name, weights[name], Hs[name]) for name, _, _ in groups]
             cur = torch.cuda.current_stream()
             order = sorted(range(len(groups)), key=lambda i: -groups[i][1] * sum(r for _, r in groups[i][2]))
-            evs = []
-            slot = {}
-
-            def chain(si, gi, helper=False):
+            slot, used = {}, []
+            for si, gi in enumerate(order):
                 name = groups[gi][0]
                 st = ops.stream(si % args.overlap)
                 st.wait_stream(cur)
-                # one stream per chain and no internal helper streams: measured 94.5 ms/step, against 96.3 with a helper for
-                # the longest chain and 108 without overlap (more streams than hardware queues start to serialise)
-                with torch.cuda.stream(st), ops.helper_streams(helper):
+                with torch.cuda.stream(st), ops.helper_streams(False):
                     slot[gi] = ops.quantize(name, weights[name], Hs[name])
-                evs.append(st)
-
-            if args.order == 'shadow':
-                # the subsets with the short Hessians first: their Hessians (3 x 3.4 ms on every CU), their chains on streams 1..,
-                # and BEHIND them the WIDEST input's Hessian (down_proj: K = 14336, 39 ms) with --reserve CUs left free: K1 is
-                # power-limited, so it loses little on fewer CUs, and the other chains run in its shadow on the free ones; the
-                # widest chain has the device to itself afterwards (round 5: rounds 2-4 shadowed the subset with the largest
-                # K x rows = gate|up, a 3.4-ms Hessian, by mistake)
-                wide = max(range(len(groups)), key=lambda i: (groups[i][1], sum(r for _, r in groups[i][2])))
-                others = [gi for gi in order if gi != wide]
-                for gi in others:
-                    Hs[groups[gi][0]] = ops.hessian(groups[gi][0], groups[gi][1], acts[groups[gi][0]], args.calib_bs)
-                for si, gi in enumerate(others):
-                    chain(si + 1, gi)
-                g0 = groups[wide]
-                with ops.cu_reserve(args.reserve):
-                    Hs[g0[0]] = ops.hessian(g0[0], g0[1], acts[g0[0]], args.calib_bs)
-                chain(0, wide, helper=args.helpers in ('all', 'wide') or bool(args.wide_helper))
-            else:
-                if args.order == 'k1first':
-                    for name, K, layers in groups:
-                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-                if args.order == 'k1first' and args.small_streams > 0:
-                    wide = max(range(len(groups)), key=lambda i: (groups[i][1], sum(r for _, r in groups[i][2])))
-                    chain(0, wide, helper=(args.helpers in ('all', 'wide')) or bool(args.wide_helper))
-                    for j, gi in enumerate([g for g in order if g != wide]):
-                        st_i = 1 + j % args.small_streams
-                        name = groups[gi][0]
-                        st = ops.stream(st_i)
-                        st.wait_stream(cur)
-                        with torch.cuda.stream(st), ops.helper_streams(args.helpers == 'all'):
-                            slot[gi] = ops.quantize(name, weights[name], Hs[name])
-                        evs.append(st)
-                    for st in set(evs):
-                        cur.wait_stream(st)
-                    return [slot[gi] for gi in range(len(groups))]
-                for si, gi in enumerate(order):
-                    name, K = groups[gi][0], groups[gi][1]
-                    if args.order != 'k1first':
-                        Hs[name] = ops.hessian(name, K, acts[name], args.calib_bs)
-                    # one stream per chain, internal helper streams off (--helpers wide gives the widest chain its helper:
-                    # measured 94.5 against 93.7 ms per step, gpurun_out/r03g: the other chains already fill its gaps)
-                    chain(si, gi, helper=(args.helpers == 'all') or ((args.helpers == 'wide' or bool(args.wide_helper)) and si == 0))
-            for st in set(evs):
+                used.append(st)
+            for st in set(used):
                 cur.wait_stream(st)
             return [slot[gi] for gi in range(len(groups))]      # in block order (o_proj's result is outs[1])
 
@@ -837,38 +498,33 @@ def main():
                         hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs),
                         quantize_rows_fn=lambda ws, H, rows, n=name: ops.quantize(n, ws, H, rows=rows)))
                 else:
-                    ids = list(range(len(layers)))
                     share = 'hessian' if len(layers) > 1 else 'activations'
                     outs.append(LS.run_block_cooperative(
-                        ids, acts[name], 0,
+                        list(range(len(layers))), acts[name], 0,
                         lambda li, shared, n=name, k=K, sh=share: ops.quantize(
                             n + str(li), [weights[n][li]],
                             shared if sh == 'hessian' else ops.hessian(n, k, shared, args.calib_bs)),
                         (shape, dtype, dev), share=share,
-                        hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=None, to_cpu=False))   # results stay with their owners: the gather for saving is not on the step's path
+                        hessian_fn=lambda x, n=name, k=K: ops.hessian(n, k, x, args.calib_bs), gather_to=None, to_cpu=False))   # results stay with their owners
             return outs
 
         # ---- handoff: block-sharded ownership with a block's OUTPUT handed to the owner of the next block. In a model run the
-        # inputs of block b are the outputs of block b - 1 (base_blockwise_quantization.py:367-402; with quant_out the outputs
-        # of the QUANTIZED block): whoever owns block b - 1 produces them and sends them on. Here every rank sends a tensor it
-        # has just computed from this step's result — o_proj's quantized weights applied to o_proj's calibration input,
-        # [n_seq, seq, hidden] in the model dtype (ops.block_output: the HIP GEMM of FakeQuantLinear.forward) — to its ring
-        # successor and receives what its step after next consumes from its predecessor: the transfer of step t's output runs
-        # on its own stream under step t + 1's kernels (double-buffered). The payload is produced by the step, so it cannot
-        # be elided, and it changes every step.
+        # inputs of block b are the outputs of block b - 1 (base_blockwise_quantization.py:367-402): whoever owns block b - 1
+        # produces them and sends them on. Here every rank sends a tensor it has just computed from this step's result — o_proj's
+        # quantized weights applied to o_proj's calibration input, [n_seq, seq, hidden] in the model dtype (ops.block_output: the
+        # HIP GEMM of FakeQuantLinear.forward) — to its ring successor and receives what its step after next consumes from its
+        # predecessor: the transfer of step t's output runs on its own stream under step t + 1's kernels (double-buffered). The
+        # payload is produced by the step, so it cannot be elided, and it changes every step.
         hand = {}
         if handoff:
             name0 = groups[0][0]
-            hand['cur'] = acts[name0]
-            hand['nxt'] = torch.empty_like(acts[name0])
-            hand['out'] = acts[name0]              # what the first transfer sends: the synthetic input itself
-            hand['bytes'] = acts[name0].numel() * acts[name0].element_size()
-            hand['stream'] = None if args.dry else torch.cuda.Stream(device=dev)
+            hand.update(cur=acts[name0], nxt=torch.empty_like(acts[name0]), out=acts[name0],
+                        bytes=acts[name0].numel() * acts[name0].element_size(),
+                        stream=None if args.dry else torch.cuda.Stream(device=dev))
 
         def handoff_start():
             import torch.distributed as dist
-            nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
-            p2p = [dist.P2POp(dist.isend, hand['out'], nxt_rank), dist.P2POp(dist.irecv, hand['nxt'], prv_rank)]
+            p2p = [dist.P2POp(dist.isend, hand['out'], (rank + 1) % world), dist.P2POp(dist.irecv, hand['nxt'], (rank - 1) % world)]
             if hand['stream'] is None:
                 hand['reqs'] = dist.batch_isend_irecv(p2p)
                 return
@@ -894,14 +550,12 @@ def main():
                 raise RuntimeError('injected hand-off failure (dry-run test of the fallback)')
             handoff_start()
             out = step_independent(record)
-            x_o = acts[groups[1][0]]
-            y = ops.block_output(x_o, out[1][0]['weight'], dtype)         # this step's block output: sent during the next step
+            y = ops.block_output(acts[groups[1][0]], out[1][0]['weight'], dtype)   # this step's block output: sent during the next step
             handoff_finish(y.reshape(hand['cur'].shape))
             return out
 
         step = step_cooperative if coop else (step_handoff if handoff else step_independent)
-        return step, {'coop': coop, 'handoff': handoff, 'hand': hand, 'acts': acts, 'weights': weights, 'plan': plan,
-                      'step_independent': step_independent}
+        return step, {'coop': coop, 'handoff': handoff, 'hand': hand, 'acts': acts, 'weights': weights, 'plan': plan}
 
     def barrier():
         if world > 1:
@@ -911,20 +565,53 @@ def main():
     def release(ctx):
         for k in ('acts', 'weights', 'hand', 'plan'):
             ctx[k].clear()
-        ops.accs.clear() if hasattr(ops, 'accs') else None
-        ops.hwork.clear() if hasattr(ops, 'hwork') else None
+        for k in ('accs', 'hwork'):
+            if hasattr(ops, k):
+                getattr(ops, k).clear()
         import gc
         gc.collect()
         if not args.dry:
             torch.cuda.empty_cache()
 
+    def try_steps(mode, n_warm, n_timed):
+        """A few steps of `mode` behind a try / except and an agreement over the control group: (layers/s | None, error | None).
+        An RCCL failure on one rank cannot hang the others' line."""
+        ok, val, err, ctx2 = 1, None, None, None
+        try:
+            step2, ctx2 = prepare(mode)
+            for _ in range(n_warm):
+                step2(False)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_timed):
+                step2(False)
+            barrier()
+            val = time.perf_counter() - t1
+        except Exception as e:      # noqa: BLE001
+            ok, err = 0, f'{type(e).__name__}: {str(e)[:200]}'
+        ok = ctl_reduce(ok, torch.distributed.ReduceOp.MIN)
+        try:
+            if ctx2 is not None:
+                release(ctx2)
+        except Exception:           # noqa: BLE001
+            pass
+        if not ok:
+            return None, err or 'failed on another rank'
+        t = ctl_reduce(val, torch.distributed.ReduceOp.MAX)
+        return n_layers_block * (1 if mode == 'cooperative' else world) * n_timed / t, None
+
+    handoff_error = None
+    if auto:
+        # pre-flight: ONE hand-off step on every rank. Only if all of them succeed does the timed region exercise north_star's
+        # partition; otherwise it runs the same ownership without data-path traffic and the line records why.
+        v, handoff_error = try_steps('handoff', 1, 1)
+        if v is None:
+            args.mode = 'independent'
     step, ctx = prepare(args.mode)
     coop, handoff, hand = ctx['coop'], ctx['handoff'], ctx['hand']
     last = None
-    handoff_error = None
-    if handoff:
-        # Safety net for an explicit --mode handoff: if the owner-to-owner transfer raises, all ranks agree (over the control
-        # group) to fall back to the same ownership without the hand-off, and the line says so.
+    if handoff and not auto:
+        # an explicit --mode handoff keeps its safety net: if the transfer raises, all ranks agree to drop it
         ok = 1
         try:
             step(False)
@@ -933,8 +620,9 @@ def main():
             ok, handoff_error = 0, f'{type(e).__name__}: {str(e)[:200]}'
         if ctl_reduce(ok, torch.distributed.ReduceOp.MIN) == 0:
             handoff_error = handoff_error or 'the hand-off failed on another rank'
-            handoff = False
-            step = ctx['step_independent']
+            release(ctx)
+            step, ctx = prepare('independent')
+            coop, handoff, hand = ctx['coop'], ctx['handoff'], ctx['hand']
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -954,15 +642,14 @@ def main():
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
     med_ms = (step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])) if step_ms else None
-    # round barriers of the last step's SYRK launches that gave up (no longer silent)
-    barrier_timeouts = None
-    if not args.dry and hasattr(ops, 'accs') and ops.accs:
+    barrier_timeouts = None       # round barriers of the last step's SYRK launches that gave up (never silent)
+    if not args.dry and getattr(ops, 'accs', None):
         try:
             barrier_timeouts = sum(a.barrier_timeouts() for a in ops.accs.values())
         except Exception:        # noqa: BLE001
             barrier_timeouts = None
-    # deferred positive-definiteness check of the factorisations (the classes check once per subset; here after timing)
-    def _infos(o):
+
+    def _infos(o):    # deferred positive-definiteness check of the factorisations (the classes check once per subset; here after timing)
         if isinstance(o, dict):
             if torch.is_tensor(o.get('info')):
                 yield o['info']
@@ -974,59 +661,58 @@ def main():
     bad = [int(t.item()) for t in _infos(last) if int(t.item()) != 0]
     if bad:
         raise SystemExit(f'bench.py: a Hessian was not positive definite (leading minors {bad}): results invalid')
+    # what THIS run's last step computed, against fp64 on the same resident samples: diag(H) is the only part of the chain
+    # whose last bits are used before the factorisation (actorder's sort key, the damping mean) and is not the reference's
+    # arithmetic bit for bit; everything downstream is bit-exact given H (tests). One narrow and the wide input.
+    parity_live = None
+    if not args.dry and not coop and getattr(ops, 'accs', None):
+        try:
+            parity_live = {}
+            for name in (groups[1][0], groups[-1][0]):
+                x = ctx['acts'][name]
+                xs = list(x) if isinstance(x, (list, tuple)) else [x]
+                d = sum((xi.reshape(-1, xi.shape[-1])[i:i + 16384].double() ** 2).sum(0) for xi in xs
+                        for i in range(0, xi.reshape(-1, xi.shape[-1]).shape[0], 16384)) * (2.0 / args.n_seq)
+                h = torch.diagonal(ops.accs[name].H).double()
+                parity_live[name] = {'K': int(h.numel()), 'H_diag_rel_max_vs_fp64': float(((h - d).abs() / d).max())}
+            parity_live['note'] = ('measured by this run after the timed region: diag(H) of the last step against the fp64 sum over '
+                                   'the same samples (an fp32 rounding of the exact value is <= 6e-8; the reference\'s own sgemm leaves '
+                                   '1.2-1.7e-6 at K = 14336, profiles/r05_parity_envelope_full_down.txt)')
+        except Exception as e:       # noqa: BLE001
+            parity_live = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
     dt = ctl_reduce(dt, torch.distributed.ReduceOp.MAX) if world > 1 else dt
-    primary_parallelism = None
+    value_mode = 'cooperative' if coop else ('handoff_rccl' if handoff else 'independent_no_comm')
+    if args.dry and handoff:
+        value_mode = 'handoff_gloo_dry'
+    parallelism = 'single GPU'
     if world > 1:
-        primary_parallelism = (
+        parallelism = (
             f'cooperative x{world}: Hessian/activation broadcast + sample-sharded all_reduce, row-sharded column loop' if coop else
-            (f'block-sharded x{world}, every block\'s output ({hand["bytes"] / 2**30:.2f} GiB per step and rank: o_proj\'s quantized '
-             f'weights applied to its calibration input) handed owner-to-owner over RCCL send/recv (xGMI ring), overlapped with '
-             f'the next step' if handoff else f'layer-sharded x{world}, no data-path traffic'))
+            (f'block-sharded x{world}, every block\'s output ({hand["bytes"] / 2**30:.2f} GiB per step and rank: o_proj\'s quantized weights '
+             f'applied to its calibration input) handed owner-to-owner over RCCL send/recv (xGMI ring), overlapped with the next step'
+             if handoff else f'layer-sharded x{world}, no data-path traffic'))
 
-    # ---- secondary values of the N > 1 default, outside the timed region
+    # ---- the other modes, a few steps each, outside the timed region (N > 1 default only)
     secondary = {}
     if auto:
         last = None
         release(ctx)
         k2 = max(2, min(4, args.steps))
-        for m in ('handoff', 'cooperative'):
-            val, err = None, None
-            ok = 1
-            try:
-                step2, ctx2 = prepare(m)
-                step2(False)
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(k2):
-                    step2(False)
-                barrier()
-                val = time.perf_counter() - t1
-            except Exception as e:      # noqa: BLE001
-                ok, err = 0, f'{type(e).__name__}: {str(e)[:200]}'
-            ok = ctl_reduce(ok, torch.distributed.ReduceOp.MIN)
-            if ok:
-                t = ctl_reduce(val, torch.distributed.ReduceOp.MAX)
-                layers2 = n_layers_block * (1 if m == 'cooperative' else world) * k2
-                secondary[m + '_value'] = layers2 / t
-            else:
-                secondary[m + '_error'] = err or 'failed on another rank'
-            try:
-                release(ctx2)
-            except Exception:           # noqa: BLE001
-                pass
+        for m in (['independent'] if handoff else []) + ['cooperative']:
+            v, err = try_steps(m, 1, k2)
+            secondary[m + ('_value' if v is not None else '_error')] = v if v is not None else err
 
     # ---- roofline of the dominant kernel (k_syrk4), HIP events on the launch stream, this rank
-    fl = sum(T * K * (K + 1) for (_, _, _, T, K) in timing)
+    fl = sum(f for (_, _, _, f, _) in timing)
     ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _, _) in timing)
     ms_fix = sum(e1.elapsed_time(e2) for (_, e1, e2, _, _) in timing)
     n_launch = len(timing)
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     achieved_fix = fl / ((ms + ms_fix) * 1e-3) / 1e12 if ms > 0 else 0.0
-
-    # HBM-side bytes of the dominant kernel come from PMC passes that cannot run inside the timed process
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_bench.sh); the committed summary is reported with its source.
+    # HBM-side bytes of the dominant kernel come from PMC passes that cannot run inside the timed process (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate passes, tools/gpu_job.sh pmc); the committed summary is reported with its source
     traffic, traffic_src = None, None
-    for tname in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for tname in TRAFFIC_FILES:
         tpath = os.path.join(ROOT, 'profiles', tname)
         if args.model == 'llama3-8b' and args.n_seq == 128 and args.seq_len == 2048 and os.path.exists(tpath):
             try:
@@ -1038,12 +724,10 @@ def main():
 
     if rank == 0:
         layers_step = n_layers_block * (1 if coop else world)
-        total_layers = layers_step * args.steps
         out = {
             'metric': 'layers/sec (GPTQ W4A16, %s Linear shapes, %dx%d calib)' % (
-                {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B'}.get(args.model, args.model), args.n_seq,
-                args.seq_len),
-            'value': total_layers / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
+                {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B'}.get(args.model, args.model), args.n_seq, args.seq_len),
+            'value': layers_step * args.steps / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'ms_per_step_median': med_ms, 'ms_per_step_min_max': [step_ms[0], step_ms[-1]] if step_ms else None,
             'value_at_median_step': (layers_step / (med_ms * 1e-3)) if med_ms else None,      # this rank's steps; `value` is the contract's mean
@@ -1055,22 +739,23 @@ def main():
                              + ('1 transformer block (7 Linear, 4 distinct inputs) per step shared by all GPUs'
                                 if coop else '1 transformer block (7 Linear, 4 distinct inputs) per step per GPU')),
                 'n_seq': args.n_seq, 'seq_len': args.seq_len, 'calib_bs': args.calib_bs,
-                'hessian_feed': (f'{-(-args.n_seq // args.calib_bs)} add_batch calls per input (calib.bs = {args.calib_bs}, '
-                                 'one allocation per call), one launch through the sample table, no staging copy'
+                'hessian_feed': (f'{-(-args.n_seq // args.calib_bs)} add_batch calls per input (calib.bs = {args.calib_bs}, one allocation '
+                                 'per call), the inputs of one width walked by ONE launch through the sample table, no staging copy'
                                  if args.calib_bs < args.n_seq else 'one add_batch call per input on one resident tensor'),
-                # w_only: a layer ends at compensated weights + scales / zeros (the reference cannot export actorder +
-                # dynamic groups either, gptq.py:455-457); vllm: + INT4 codes packed (SURVEY 8d's full definition)
+                # w_only: a layer ends at compensated weights + scales / zeros (the reference cannot export actorder + dynamic
+                # groups either, gptq.py:455-457); vllm: + INT4 codes packed (SURVEY 8d's full definition) = `value_packed`
                 'packs_codes': args.variant == 'vllm',
                 'symmetric': cfg.symmetric, 'actorder': cfg.actorder, 'static_groups': cfg.static_groups,
                 'subset_overlap_streams': 0 if (args.dry or coop) else args.overlap,
-                'hessian_exact_diag': bool(args.exact_diag),
-                'parallelism': 'single GPU' if world == 1 else primary_parallelism,
+                'hessian_exact_diag': bool(args.exact_diag), 'hessians_of_one_width_in_one_launch': bool(args.merge_k1),
+                'parallelism': parallelism,
                 'parity_envelope': parity_envelope_summary(args),
             },
+            'parity_live': parity_live,
             'roofline': {
                 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_MFMA_16BIT / 1e12, 'unit': 'TFLOP/s',
                 'frac': achieved * 1e12 / PEAK_MFMA_16BIT, 'traffic': traffic, 'traffic_source': traffic_src,
-                'kernel': 'k_syrk4 (llmc_hessian_accum_partials)', 'launches': n_launch,
+                'kernel': 'k_syrk4 (llmc_hessian_accum_multi_partials)', 'launches': n_launch,
                 'algorithmic_flops_per_launch': fl / max(1, n_launch),
                 'avg_launch_ms': ms / max(1, n_launch),
                 'achieved_incl_fixup': achieved_fix, 'avg_fixup_ms': ms_fix / max(1, n_launch),
@@ -1078,26 +763,20 @@ def main():
             },
         }
         if world > 1:
-            # No number of this script has been measured on more than one GPU yet (no multi-GPU box in rounds 1-5): the modes
-            # are covered by Gloo runs at world sizes 2, 4 and 8 (tests/test_bench_spawn.py) and a 2-GPU RCCL test.
-            out['config']['multi_gpu_status'] = 'unmeasured on hardware before this run'
-            # what the timed value exercised: `independent` moves no byte between ranks
-            out['value_mode'] = ('cooperative' if coop else 'handoff' if handoff else 'independent_no_comm')
+            out['value_mode'] = value_mode       # what the timed value exercised
             out['rccl_world'] = (torch.distributed.get_world_size() if not args.dry else None)        # ranks of the nccl (= RCCL) group
             out['data_backend'] = 'gloo (dry run)' if args.dry else torch.distributed.get_backend()
-            out['interrank_bytes_per_step_per_rank'] = {
-                'independent': 0,
-                'handoff': interrank_bytes['handoff'],
-                'cooperative': interrank_bytes['cooperative'],
-            }
-            out.update(secondary)    # handoff_value / cooperative_value (layers/s, a few steps each, outside the timed region) or *_error
+            out['interrank_bytes_per_step_per_rank'] = interrank_bytes
+            out.update(secondary)    # independent_value / cooperative_value (layers/s, a few steps each, outside the timed region) or *_error
         if handoff_error is not None:
             out['handoff_error'] = handoff_error              # the run fell back to the ownership without the hand-off
         if world == 1 and not args.no_extras and not args.dry and args.model == 'llama3-8b' and args.variant == 'w_only':
-            # free this run's tensors first: the secondary workloads are child processes on the same GPU
             last = None
-            release(ctx)
+            release(ctx)            # the secondary workloads are child processes on the same GPU
             out['extra'] = run_extras(args)
+            pk = out['extra'].get('gptq_vllm_variant_packed', {})
+            # SURVEY 8d's full layer definition (... -> INT4 codes packed), first-class beside `value` (a few steps of the same script)
+            out['value_packed'], out['ms_per_step_packed'] = pk.get('value'), pk.get('ms_per_step')
         if world == 1 and not args.no_cpu_baseline and not args.dry:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.model, args.n_seq, args.seq_len, cfg)
@@ -1108,7 +787,7 @@ def main():
     if world > 1:
         try:
             torch.distributed.destroy_process_group()
-        except Exception:      # noqa: BLE001 (a communicator aborted by a failed secondary measurement)
+        except Exception:      # noqa: BLE001 (a communicator aborted by a failed measurement)
             pass
 
 

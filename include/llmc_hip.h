@@ -86,6 +86,7 @@ int llmc_hip_set_cu_reserve(int n_cus);
  *   fp8_exact_div     FP8 casts through the IEEE division + general encoder; same bits
  *   side_cu_mask      helper streams created with a CU mask (read when a caller stream's helper set is first created)
  *   k1_batch_off      llmc_hessian_accum_multi as one launch per problem instead of one tile queue; same bits
+ *   k1_fp32_diag      diag(H) as the MFMA kernel's fp32 chain leaves it instead of the fp64-folded one (other diagonal)
  * set: returns the previous value, or LLMC_EINVAL for an unknown key / negative value. get: the value, or LLMC_EINVAL.
  * option_name: the key of index 0, 1, ... (copied into buf), LLMC_EINVAL past the last one. No reference counterpart. */
 int llmc_hip_set_option(const char* key, int value);
@@ -211,7 +212,7 @@ int llmc_hessian_accum_reduce(float* H, int64_t T, int64_t K, int64_t ldx, doubl
  * sequences in the list. X_list_host / T_list_host: HOST arrays of n device pointers (16-B aligned rows, common row
  * stride ldx and dtype dt) and their token counts (> 0; any lengths: every sample is walked in 128-token groups and
  * the last group of a sample is zero-filled by its buffer descriptor). n <= llmc_hessian_max_samples(). The host arrays
- * are consumed before the call returns (they travel in the kernel arguments). The result is bit-identical to
+ * are consumed before the call returns (they travel in the kernel arguments: up to 8 KiB of them). The result is bit-identical to
  * llmc_hessian_accum on the concatenation of the samples whenever every T_i is a multiple of 128. ws from
  * llmc_hessian_accum_ptrs_ws_bytes (0 = invalid arguments). */
 int llmc_hessian_max_samples(void);
@@ -222,14 +223,38 @@ int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, const int64
                                      int64_t K, int64_t ldx, void* ws, llmc_stream_t stream);
 int llmc_hessian_accum_ptrs_reduce(float* H, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
                                    double n_before, double n_after, const void* ws, llmc_stream_t stream);
-/* Optional exact diagonal (opt-in: one more HBM pass over the samples, 2 T K bytes): the MFMA kernel accumulates in fp32 over tens of
- * thousands of tokens and leaves 2-3e-6 of relative noise on diag(H), twice the reference's sgemm; diag(H) is what actorder sorts
- * (gptq.py:58-83) and the damping averages (gptq.py:169). This call re-forms sum_t X[t][j]^2 in fp64, keeps the running value in
- * dstate [K] (fp64, carried across calls; overwritten when n_before == 0) and writes its fp32 rounding onto H's diagonal. Call it
- * after the llmc_hessian_accum* call of the same samples with the same n_before / n_after. ws: llmc_hessian_diag_ws_bytes(K). */
-size_t llmc_hessian_diag_ws_bytes(int64_t K);
-int llmc_hessian_diag_accum_ptrs(float* H, double* dstate, const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,
-                                 int64_t K, int64_t ldx, double n_before, double n_after, void* ws, llmc_stream_t stream);
+/* Several Hessians in ONE launch pair (one unit queue): the problems' triangular tile grids fill the persistent grid's
+ * rounds together — the three K = 4096 inputs of a Llama block pay one partially filled last round instead of three — and
+ * the exact diagonal below. A problem = one llmc_hessian_accum_ptrs call: H [K, K], its sample list (host arrays of n device
+ * pointers / token counts, consumed before the call returns), K, the common row stride ldx, the running-mean weights.
+ * Up to llmc_hessian_max_problems() problems and llmc_hessian_max_samples() samples (all problems together) per call; one
+ * dtype per call. The one-problem entry points above are wrappers of these (dstate = NULL).
+ *
+ * Exact diagonal (always on; no extra pass over the samples): in a DIAGONAL 256 x 256 tile of the kernel the upper-right
+ * quadrant is the transpose of the lower-left one, so the reduction mirrors that one and the quadrant's wave spends its
+ * MFMAs on the eight 32 x 32 blocks ON the diagonal, restarting its accumulators every 128 tokens and folding each block's
+ * diagonal into fp64. diag(H) — what actorder sorts (gptq.py:58-83) and the damping averages (gptq.py:169) — then carries
+ * ~1e-8 of relative error before its one rounding to fp32, instead of the 2-3e-6 an fp32 chain over a whole token chunk
+ * leaves (twice the reference's sgemm; rounds 1-5 offered a second fp64 pass over the samples for this). dstate [K] fp64 (may
+ * be NULL) carries the unrounded running diagonal across calls (overwritten when n_before == 0); without it H's own fp32
+ * diagonal is the carried value. llmc_hip_set_option("k1_fp32_diag", 1) keeps the MFMA kernel's fp32 diagonal (A/B). */
+typedef struct {
+    float* H;
+    double* dstate;
+    const void* const* X_list_host;
+    const int64_t* T_list_host;
+    int n;
+    int64_t K;
+    int64_t ldx;
+    double n_before;
+    double n_after;
+} llmc_hessian_problem_t;
+int llmc_hessian_max_problems(void);
+size_t llmc_hessian_accum_multi_ws_bytes(const llmc_hessian_problem_t* probs_host, int P);
+int llmc_hessian_accum_multi_partials(const llmc_hessian_problem_t* probs_host, int P, int dt, void* ws, llmc_stream_t stream);
+int llmc_hessian_accum_multi_reduce(const llmc_hessian_problem_t* probs_host, int P, const void* ws, llmc_stream_t stream);
+int llmc_hessian_accum_multi_barrier_timeouts(const llmc_hessian_problem_t* probs_host, int P, const void* ws, unsigned* out_host,
+                                              llmc_stream_t stream);
 /* Diagnostic: how many round barriers of the LAST llmc_hessian_accum*_partials launch on `ws` (same T list, K, ldx) gave
  * up waiting because workgroups of its persistent grid were kept off their CUs by other streams. Synchronises `stream`
  * and writes the count to *out_host. 0 in a healthy run; > 0 leaves the result correct but the launch slower. */

@@ -51,8 +51,11 @@ SIGNATURES = {
     'llmc_hessian_accum_ptrs_partials': (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
     'llmc_hessian_accum_ptrs_reduce': (_i32, [_vp, _vp, _i32, _i64, _i64, _f64, _f64, _vp, _vp]),
     'llmc_hessian_accum_barrier_timeouts': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
-    'llmc_hessian_diag_ws_bytes': (_sz, [_i64]),
-    'llmc_hessian_diag_accum_ptrs': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _f64, _f64, _vp, _vp]),
+    'llmc_hessian_max_problems': (_i32, []),
+    'llmc_hessian_accum_multi_ws_bytes': (_sz, [_vp, _i32]),
+    'llmc_hessian_accum_multi_partials': (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    'llmc_hessian_accum_multi_reduce': (_i32, [_vp, _i32, _vp, _vp]),
+    'llmc_hessian_accum_multi_barrier_timeouts': (_i32, [_vp, _i32, _vp, _vp, _vp]),
     'llmc_gather_cols': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'llmc_hessian_prep_ws_bytes': (_sz, [_i64]),
     'llmc_hessian_prep': (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
@@ -101,6 +104,14 @@ SIGNATURES = {
     'llmc_test_gemm3_planes': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'llmc_test_gemm3s_stamps': (_i32, [_vp]),
 }
+
+
+
+class HessianProblem(C.Structure):
+    """llmc_hessian_problem_t (include/llmc_hip.h)"""
+    _fields_ = [('H', _vp), ('dstate', _vp), ('X_list_host', _vp), ('T_list_host', _vp), ('n', _i32), ('K', _i64),
+                ('ldx', _i64), ('n_before', _f64), ('n_after', _f64)]
+
 
 _lib = None
 

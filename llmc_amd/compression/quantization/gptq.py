@@ -49,9 +49,9 @@ class GPTQ(BaseBlockwiseQuantization):
         # not a reference key: False makes the Hessian accumulators copy every hooked sample instead of keeping a
         # reference to it until the subset's single launch (hessian.py)
         self.hessian_defer = bool(special.get('hessian_defer', True))
-        # diag(H) re-formed in fp64 by a second pass over the calibration samples (hessian.py: exact_diag): the sort key of
-        # actorder with the noise of the reference's own sgemm instead of twice that; costs one more HBM pass per Hessian
-        self.hessian_exact_diag = bool(special.get('hessian_exact_diag', False))
+        # not a reference key: diag(H) — actorder's sort key, the damping mean — folded into fp64 inside the Hessian kernel (default;
+        # hessian.py: exact_diag). False keeps the fp32 chain's own diagonal (rounds 1-5's default), for A/B
+        self.hessian_exact_diag = bool(special.get('hessian_exact_diag', True))
         self.owq = bool(special.get('owq', False))
         if self.owq:                                   # gptq.py:47-50: OWQ fixes dynamic groups and no actorder
             self.n_outs = special['n_outs']
@@ -97,7 +97,7 @@ class GPTQ(BaseBlockwiseQuantization):
     def _new_group(self, names, K, device):
         gid = self._next_gid = getattr(self, '_next_gid', 0) + 1
         acc = HessianAccumulator(K, device, defer=getattr(self, 'hessian_defer', True),
-                                 exact_diag=getattr(self, 'hessian_exact_diag', False))
+                                 exact_diag=getattr(self, 'hessian_exact_diag', True))
         self._groups[gid] = {'acc': acc, 'pass': None, 'passes': 0, 'members': list(names)}
         for n in names:
             self._group_of[n] = gid
@@ -257,6 +257,10 @@ class GPTQ(BaseBlockwiseQuantization):
     def block_transform(self, block, input_feat, block_kwargs):
         if self.owq and not hasattr(self, 'n_out_dict'):       # gptq.py:89-93: n_outs follow get_block_linears' order
             self.n_out_dict = {n: self.n_outs[i] for i, n in enumerate(self.model.get_block_linears(block))}
+        if not getattr(self, 'true_sequential', False) and _world() == 1:
+            # one block forward has fed every subset's accumulator: the Hessians of one width (q|k|v, o and gate|up of a Llama
+            # block) are formed by ONE launch (HessianAccumulator.flush_many) instead of one launch per subset
+            HessianAccumulator.flush_many([g['acc'] for g in self._groups.values()])
         super().block_transform(block, input_feat, block_kwargs)
 
     def _transform_owq(self, gid, layers, names):

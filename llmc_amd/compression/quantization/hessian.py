@@ -33,14 +33,14 @@ class HessianAccumulator:
     _global_pending = 0            # bytes of deferred references held by all accumulators
     COPY_FLUSH_TOKENS = 65536      # defer=False: private copies are flushed at this many tokens
 
-    def __init__(self, columns, device, defer=True, max_pending_tokens=None, exact_diag=False):
+    def __init__(self, columns, device, defer=True, max_pending_tokens=None, exact_diag=True):
         self.K = int(columns)
-        # exact_diag (GPTQ: special.hessian_exact_diag): diag(H) re-formed in fp64 by a second pass over the samples
-        # (llmc_hessian_diag_accum_ptrs): the MFMA kernel's fp32 accumulation leaves 2-3e-6 of relative noise there, twice the
-        # reference's sgemm, and diag(H) is what actorder sorts. One more HBM pass (2 T K bytes): off by default.
-        self.exact_diag = bool(exact_diag) and self.K % 8 == 0
+        # exact_diag (GPTQ: special.hessian_exact_diag, default True since round 6): diag(H) — what actorder sorts and the damping
+        # averages — is folded into fp64 every 128 tokens by the MFMA kernel's otherwise redundant diagonal-tile wave
+        # (hessian_syrk.hip: no extra pass over the samples) and keeps its unrounded running value in `_diag64` across launches.
+        # False: the fp32 chain's own diagonal (2-3e-6 of relative noise, twice the reference's sgemm), for A/B.
+        self.exact_diag = bool(exact_diag)
         self._diag64 = None
-        self._diag_ws = None
         self._H = torch.zeros((self.K, self.K), dtype=torch.float32, device=device)
         self.nsamples = 0         # sequences added (pending ones included)
         self._flushed = 0         # sequences already in H
@@ -114,10 +114,9 @@ class HessianAccumulator:
         HessianAccumulator._global_pending = max(0, HessianAccumulator._global_pending - self._pending_bytes)
         self._pending, self._pending_tok, self._pending_bytes = [], 0, 0
 
-    def flush(self):
-        """One launch per (dtype, row stride) for everything pending (no-op when nothing is)."""
-        if not self._pending:
-            return
+    def _take_pending(self):
+        """Validate and take everything pending: returns (launch groups [[x, ...], ...] — one per (dtype, row stride) —, b_total).
+        Nothing is dropped when the validation raises."""
         # validate BEFORE anything is dropped: a caller that catches this still holds a consistent accumulator (the pending
         # samples and nsamples agree; reset() discards them)
         for x, _, src, ver in self._pending:
@@ -139,7 +138,13 @@ class HessianAccumulator:
         for dtp, xs in short.items():
             packed = self._compact(torch.cat(xs, 0)) if len(xs) > 1 else xs[0]
             by_key.setdefault((dtp, packed.stride(0)), []).append(packed)
-        groups = list(by_key.values())
+        return list(by_key.values()), b_total
+
+    def flush(self):
+        """One launch per (dtype, row stride) for everything pending (no-op when nothing is)."""
+        if not self._pending:
+            return
+        groups, b_total = self._take_pending()
         if not groups:                                  # only empty calls: H <- H * n/(n+b)
             if self._flushed:
                 self._H.mul_(self._flushed / (self._flushed + b_total))
@@ -157,6 +162,47 @@ class HessianAccumulator:
             self._launch(xs, b_total if first else 0)
             first = False
 
+    @staticmethod
+    def flush_many(accs):
+        """Flush several accumulators together: those whose pending samples form ONE launch each (one dtype, one row stride —
+        the hook calls of a block forward) share launches of up to llmc_hessian_max_problems() Hessians of the same width
+        (llmc_hessian_accum_multi_*: one unit queue, the triangular tails fill rounds together — the three K = 4096 inputs
+        of a Llama block); everything else is flushed on its own. The token-chunk count of a launch is chosen for the problems that
+        share it, so against one-by-one launches the fp32 sums are formed in another order (summation-order noise, <= 1e-6)."""
+        L = _ffi.lib()
+        pmax, nmax = L.llmc_hessian_max_problems(), L.llmc_hessian_max_samples()
+        singles, seen = {}, set()
+        for a in accs:
+            if id(a) in seen or not a._pending:
+                continue
+            seen.add(id(a))
+            groups, b_total = a._take_pending()
+            if len(groups) == 1 and len(groups[0]) <= nmax // 2:
+                xs = groups[0]
+                singles.setdefault((a.K, xs[0].dtype, xs[0].device), []).append((a, xs, b_total))
+                continue
+            # not one launch: put it back the simple way
+            if not groups:
+                a._pending = [(None, b_total, None, 0)]
+                a.flush()
+                continue
+            first = True
+            for xs in groups:
+                a._launch(xs, b_total if first else 0)
+                first = False
+        for items in singles.values():
+            batch, nsmp = [], 0
+            for it in items + [None]:
+                if it is None or len(batch) == pmax or nsmp + len(it[1]) > nmax:
+                    if len(batch) == 1:
+                        batch[0][0]._launch(batch[0][1], batch[0][2])
+                    elif batch:
+                        HessianAccumulator._launch_multi(batch)
+                    batch, nsmp = [], 0
+                if it is not None:
+                    batch.append(it)
+                    nsmp += len(it[1])
+
     def _launch(self, xs, b):
         """xs: [T_i, K] tensors of one dtype and one row stride; b sequences enter the running mean with this launch."""
         L = _ffi.lib()
@@ -164,64 +210,99 @@ class HessianAccumulator:
         for i in range(0, len(xs), nmax):
             self._launch_some(xs[i:i + nmax], b if i == 0 else 0)
 
-    def _launch_some(self, xs, b):
-        L = _ffi.lib()
+    def _problem(self, pr, xs, b):
+        """Fill `pr` (llmc_hessian_problem_t) for one launch of this accumulator; returns the ctypes arrays it points at (the
+        caller keeps them alive until the call has returned)."""
         n, K, ldx = len(xs), self.K, xs[0].stride(0)
         Ts = (C.c_int64 * n)(*[x.shape[0] for x in xs])
         Xs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
-        need = L.llmc_hessian_accum_ptrs_ws_bytes(Ts, n, K, ldx)
-        if need == 0:
-            # the samples are too short / too many for one walk: pack them into one tensor
-            xs = [self._compact(torch.cat(xs, 0))]
-            n, ldx = 1, xs[0].stride(0)
-            Ts = (C.c_int64 * 1)(xs[0].shape[0])
-            Xs = (C.c_void_p * 1)(xs[0].data_ptr())
-            need = L.llmc_hessian_accum_ptrs_ws_bytes(Ts, n, K, ldx)
-            if need == 0:
-                _ffi.check(-22, 'llmc_hessian_accum_ptrs_ws_bytes')
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = _ffi.workspace(need, xs[0].device)
-        st = _ffi.stream()
-        T = sum(x.shape[0] for x in xs)
-        if self.timing is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _ffi.check(L.llmc_hessian_accum_ptrs_partials(Xs, Ts, n, _ffi.dt(xs[0]), K, ldx, _ffi.ptr(self._ws), st),
-                   'llmc_hessian_accum_ptrs_partials')
-        if self.timing is not None:
-            e1.record()
         # b = 0: a further launch of the same flush adds its products with the weights of the first (n stays)
         nb, na = float(self._flushed), float(self._flushed + b)
         if b == 0:
             nb = na = float(self._flushed)
-        _ffi.check(L.llmc_hessian_accum_ptrs_reduce(_ffi.ptr(self._H), Ts, n, K, ldx, nb, na, _ffi.ptr(self._ws), st),
-                   'llmc_hessian_accum_ptrs_reduce')
-        if self.timing is not None:
+        if self.exact_diag and self._diag64 is None:
+            self._diag64 = torch.zeros(K, dtype=torch.float64, device=xs[0].device)
+        pr.H, pr.dstate = _ffi.ptr(self._H), (_ffi.ptr(self._diag64) if self.exact_diag else None)
+        pr.X_list_host, pr.T_list_host = C.cast(Xs, C.c_void_p), C.cast(Ts, C.c_void_p)
+        pr.n, pr.K, pr.ldx, pr.n_before, pr.n_after = n, K, ldx, nb, na
+        return Ts, Xs
+
+    def _launch_some(self, xs, b):
+        L = _ffi.lib()
+        arr = (_ffi.HessianProblem * 1)()
+        keep = self._problem(arr[0], xs, b)
+        need = L.llmc_hessian_accum_multi_ws_bytes(arr, 1)
+        if need == 0:
+            # the samples are too short / too many for one walk: pack them into one tensor
+            xs = [self._compact(torch.cat(xs, 0))]
+            keep = self._problem(arr[0], xs, b)
+            need = L.llmc_hessian_accum_multi_ws_bytes(arr, 1)
+            if need == 0:
+                _ffi.check(-22, 'llmc_hessian_accum_multi_ws_bytes')
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = None
+            self._ws = _ffi.workspace(need + 256, xs[0].device)
+        HessianAccumulator._run([self], arr, 1, [xs], [b], self._ws, self.timing, keep)
+
+    @staticmethod
+    def _launch_multi(batch):
+        """batch: [(accumulator, xs, b)] of one width / dtype: ONE launch pair for all of them."""
+        L = _ffi.lib()
+        P = len(batch)
+        arr = (_ffi.HessianProblem * P)()
+        keep = [a._problem(arr[i], xs, b) for i, (a, xs, b) in enumerate(batch)]
+        need = L.llmc_hessian_accum_multi_ws_bytes(arr, P)
+        if need == 0:
+            for a, xs, b in batch:
+                a._launch(xs, b)
+            return
+        owner = batch[0][0]
+        if owner._ws is None or owner._ws.numel() < need + 256:
+            owner._ws = None
+            owner._ws = _ffi.workspace(need + 256, batch[0][1][0].device)
+        HessianAccumulator._run([a for a, _, _ in batch], arr, P, [xs for _, xs, _ in batch], [b for _, _, b in batch], owner._ws,
+                                owner.timing, keep)
+
+    @staticmethod
+    def _run(accs, probs, P, xs_list, bs, ws, timing, keep):
+        L = _ffi.lib()
+        st = _ffi.stream()
+        dtc = _ffi.dt(xs_list[0][0])
+        wsp = ws.data_ptr() + ((-ws.data_ptr()) % 256)
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _ffi.check(L.llmc_hessian_accum_multi_partials(probs, P, dtc, wsp, st), 'llmc_hessian_accum_multi_partials')
+        if timing is not None:
+            e1.record()
+        fp32_diag = [a for a in accs if not a.exact_diag]
+        if fp32_diag and len(fp32_diag) != len(accs):
+            raise ValueError('hessian: accumulators with and without exact_diag cannot share a launch')
+        with _ffi.option(k1_fp32_diag=1 if fp32_diag else 0):
+            _ffi.check(L.llmc_hessian_accum_multi_reduce(probs, P, wsp, st), 'llmc_hessian_accum_multi_reduce')
+        if timing is not None:
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
-            self.timing.append((e0, e1, e2, T, K))
-        if self.exact_diag:
-            if self._diag64 is None:
-                self._diag64 = torch.zeros(K, dtype=torch.float64, device=xs[0].device)
-                self._diag_ws = _ffi.workspace(L.llmc_hessian_diag_ws_bytes(K), xs[0].device)
-            _ffi.check(L.llmc_hessian_diag_accum_ptrs(_ffi.ptr(self._H), _ffi.ptr(self._diag64), Xs, Ts, n, _ffi.dt(xs[0]), K, ldx,
-                                                      nb, na, _ffi.ptr(self._diag_ws), st), 'llmc_hessian_diag_accum_ptrs')
-        self._flushed += b
-        self._last_launch = (Ts, n, K, ldx)
+            flops = sum(sum(x.shape[0] for x in xs) * a.K * (a.K + 1) for a, xs in zip(accs, xs_list))
+            timing.append((e0, e1, e2, flops, P))
+        for a, b in zip(accs, bs):
+            a._flushed += b
+        for a in accs:
+            a._last_launch = (probs, P, ws, keep)
         # the tensors of xs may be released by the caller once this returns: the launches are stream-ordered and torch's
         # allocator keeps a freed block out of other streams' hands until this stream has passed
 
     def barrier_timeouts(self):
         """Diagnostic (synchronises the current stream): round barriers of the most recent SYRK launch that gave up waiting
-        for workgroups other streams kept off their CUs (llmc_hessian_accum_barrier_timeouts). 0 in a healthy run."""
+        for workgroups other streams kept off their CUs (llmc_hessian_accum_multi_barrier_timeouts). 0 in a healthy run."""
         last = getattr(self, '_last_launch', None)
-        if last is None or self._ws is None:
+        if last is None:
             return 0
-        Ts, n, K, ldx = last
+        probs, P, ws, _keep = last
         out = C.c_uint(0)
-        _ffi.check(_ffi.lib().llmc_hessian_accum_barrier_timeouts(_ffi.ptr(self._ws), Ts, n, K, ldx, C.byref(out), _ffi.stream()),
-                   'llmc_hessian_accum_barrier_timeouts')
+        wsp = ws.data_ptr() + ((-ws.data_ptr()) % 256)
+        _ffi.check(_ffi.lib().llmc_hessian_accum_multi_barrier_timeouts(probs, P, wsp, C.byref(out), _ffi.stream()),
+                   'llmc_hessian_accum_multi_barrier_timeouts')
         return int(out.value)
 
     def reset(self):

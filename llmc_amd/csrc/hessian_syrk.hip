@@ -41,9 +41,10 @@ namespace llmc {
 static constexpr int TM = 256;       // tile edge (channels)
 static constexpr int TILE_FLOATS = TM * TM;
 static constexpr int GROUP_TOK = 128;            // tokens per group = one turn of the 4-slot ring of 32-token stages
-static constexpr int SYRK_MAX_SAMPLES = 192;     // table entries per launch (the whole argument block stays < 4 KiB)
+static constexpr int SYRK_MAX_SAMPLES = 512;     // table entries per launch, all problems together (8 KiB of kernel arguments)
 static constexpr int SYRK_MAX_CHUNKS = 32;
 static constexpr int SYRK_UNIT_SAMPLES = 64;     // samples one unit may cross (one per lane; the kernel clamps at 63)
+static constexpr int SYRK_MAX_PROBS = 4;         // Hessians (problems) one launch may carry in its unit queue
 
 struct TileIdx {
     int bi, bj;
@@ -93,18 +94,29 @@ struct SyrkSample {
     uint32_t g0;     // its first group on the padded token axis
 };
 
-struct SyrkArgs {
+// One Hessian of a launch. A launch carries up to SYRK_MAX_PROBS of them in ONE unit queue (the three K = 4096 inputs of a
+// Llama block: one triangular tail instead of three); units of problem p are [unit0, unit0 + S * ntiles_p).
+struct SyrkProb {
     int64_t ldx;       // row stride of every sample, elements
+    float* part;       // [S * ntiles_p][256*256] fp32, fragment order
+    double* dpart;     // [S][nb * 256] fp64: per (chunk, channel) sum of squares from the diagonal tiles (see "exact diagonal")
     int K;
     int nb;            // ceil(K / 256)
     int ntiles_p;      // padded tile count (tiles_padded(nb))
     int S;             // token chunks
     int n;             // samples
+    int smp0;          // index of its first sample in SyrkArgs::smp
+    int unit0;         // its first unit in the launch's queue
     int pad_;
-    float* part;       // [S * ntiles_p][256*256] fp32, fragment order
-    unsigned* sync;    // round barrier counter (zeroed before the launch), or null
     uint32_t cb[SYRK_MAX_CHUNKS + 1];   // chunk s = groups [cb[s], cb[s + 1]) of the padded token axis (even boundaries)
-    uint32_t ci[SYRK_MAX_CHUNKS + 1];   // the sample that holds group cb[s]
+    uint32_t ci[SYRK_MAX_CHUNKS + 1];   // the sample (relative to smp0) that holds group cb[s]
+};
+
+struct SyrkArgs {
+    int P;             // problems
+    int nunits;        // units of all problems
+    unsigned* sync;    // round barrier counter (zeroed before the launch), or null
+    SyrkProb pr[SYRK_MAX_PROBS];
     SyrkSample smp[SYRK_MAX_SAMPLES];
 };
 
@@ -183,8 +195,6 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
     const int row_lo = 2 * wv + lr;                       // token row inside the 8-row slab of a piece index q
     const int u_log = (c16 >> 2) ^ (row_lo & 3);          // 8-row slabs keep (row & 3)
     const int ch_off = (u_log * 4 + (c16 & 3)) * 8;
-    const int64_t row_bytes = a.ldx * 2;
-    const int64_t group_bytes = (int64_t)GROUP_TOK * row_bytes;
 
     // fragment addresses: slot j lives at j * 32 KiB; the ds_read offset field reaches 64 KiB, so one base register
     // per PAIR of slots (+ immediate 0 / 32 KiB) covers the ring
@@ -203,10 +213,8 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
 
     const int G = gridDim.x;
     const int lw = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // XCD-contiguous logical id
-    const int nunits = a.S * a.ntiles_p;
+    const int nunits = a.nunits;
     const int nrounds = (nunits + G - 1) / G;
-    const uint32_t slab = (uint32_t)(8 * row_bytes);
-    const uint32_t stage_bytes = (uint32_t)(S4_TOK * row_bytes);
     const uint32_t wvoff = (uint32_t)wv * 1024u;
 
     for (int round = 0; round < nrounds; ++round) {
@@ -232,21 +240,38 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
         }
         const int u = lw + round * G;
         if (u >= nunits) continue;
-        const int s = u / a.ntiles_p;
-        const int ti = u - s * a.ntiles_p;
-        const TileIdx t = decode_tile(ti, a.nb);
+        int pi = 0;
+#pragma unroll
+        for (int q = 1; q < SYRK_MAX_PROBS; ++q)
+            if (q < a.P && u >= a.pr[q].unit0) pi = q;
+        const SyrkProb& pr = a.pr[pi];
+        const int ul = u - pr.unit0;
+        const int s = ul / pr.ntiles_p;
+        const int ti = ul - s * pr.ntiles_p;
+        const TileIdx t = decode_tile(ti, pr.nb);
         if (!t.valid) continue;
-        const uint32_t gb = a.cb[s];
-        const int ngroups = (int)(a.cb[s + 1] - gb);
-        const int i0 = (int)a.ci[s];
+        const int64_t row_bytes = pr.ldx * 2;
+        const int64_t group_bytes = (int64_t)GROUP_TOK * row_bytes;
+        const uint32_t slab = (uint32_t)(8 * row_bytes);
+        const uint32_t stage_bytes = (uint32_t)(S4_TOK * row_bytes);
+        const uint32_t gb = pr.cb[s];
+        const int ngroups = (int)(pr.cb[s + 1] - gb);
+        const int i0 = (int)pr.ci[s];
+        // Exact diagonal. In a DIAGONAL tile the upper-right 128 x 128 quadrant (wave wm = 0, wn = 1) is the transpose of the
+        // lower-left one: k_syrk_fixup mirrors that one instead, and this wave spends its MFMAs on the eight 32 x 32 blocks ON
+        // the diagonal (A fragment x the same A fragment, B x the same B), restarting the accumulators every 256 tokens (a pair
+        // of groups) and folding each block's diagonal into fp64: diag(H) then carries the rounding of 16 chained MFMAs and an
+        // fp64 sum over the pairs (~1e-8 relative) instead of an fp32 chain over the whole chunk (2-3e-6, twice the
+        // reference's sgemm) — diag(H) is what GPTQ's actorder sorts and what the damping averages (gptq.py:63, 169).
+        const bool dwave = t.bi == t.bj && wv == 1;
 
         // lane table: descriptor words of sample i0 + lane as this unit sees it (file header, "sample table")
         int v0, v1, v2, vend;
         {
             int li = i0 + lane;
-            const bool ok = li < a.n;
-            if (!ok) li = a.n - 1;
-            const SyrkSample e = a.smp[li];
+            const bool ok = li < pr.n;
+            if (!ok) li = pr.n - 1;
+            const SyrkSample e = a.smp[pr.smp0 + li];
             const int64_t srel = ((int64_t)e.g0 - (int64_t)gb) * group_bytes;   // unit-relative offset of its first row
             const uint64_t vb = e.base - (uint64_t)srel;
             int64_t endb = srel + (int64_t)e.T * row_bytes;                     // ... of the end of its last row
@@ -287,6 +312,9 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
         const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
         const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
 
+        double dsum[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) dsum[b] = 0.0;
         f32x16 acc[4][4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -351,14 +379,28 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             // of slot RSL into (na, nb) (all eight are back six MFMAs before the burst ends); i in {3,7,11,15} ->
             // LDS-DMA piece D0 + i/4 of slot DSL (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread);
             // i in {10,12,13,14} -> `extra(i)`: scalar bookkeeping that must not cost an issue slot of its own
-            auto burst = [&](const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, int rd_kk,
+            // DW (the diagonal wave of a diagonal tile): 0 = the 4x4 block walk, 1 = the eight blocks on the diagonal, 2 = the same
+            // with fresh accumulators (first burst of a 128-token group). The diagonal blocks take slots whose operand is already
+            // in registers in the walk's fragment order: 0..3 -> fb[i] x fb[i], 4 -> fa[1], 5 -> fa[0], 8 -> fa[2], 12 -> fa[3];
+            // every slot keeps its fragment read / DMA piece (the wave still stages its share of the tile).
+            auto burst = [&](auto dwc, const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, int rd_kk,
                              auto dslc, auto d0c, const i32x4& rs, auto&& extra) {
                 constexpr int D0 = decltype(d0c)::value;
+                constexpr int DW = decltype(dwc)::value;
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     // serpentine walk of the 4x4 accumulator block: one operand changes per step
                     constexpr int mi = i >> 2, ni = (mi & 1) ? 3 - (i & 3) : (i & 3);
-                    acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
+                    if constexpr (DW == 0) {
+                        acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
+                    } else {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if constexpr (i < 4) acc[0][i] = Mfma<DT>::run(fb[i], fb[i], DW == 2 ? zero : acc[0][i]);
+                        else if constexpr (i == 4) acc[1][0] = Mfma<DT>::run(fa[1], fa[1], DW == 2 ? zero : acc[1][0]);
+                        else if constexpr (i == 5) acc[1][1] = Mfma<DT>::run(fa[0], fa[0], DW == 2 ? zero : acc[1][1]);
+                        else if constexpr (i == 8) acc[2][0] = Mfma<DT>::run(fa[2], fa[2], DW == 2 ? zero : acc[2][0]);
+                        else if constexpr (i == 12) acc[3][0] = Mfma<DT>::run(fa[3], fa[3], DW == 2 ? zero : acc[3][0]);
+                    }
                     if constexpr ((i & 3) == 3) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{}, rs);
                     else if constexpr (i < 10) frag(rslc, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
                     else extra(ic);
@@ -368,14 +410,18 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             auto nothing = [](auto) {};
             // one group (ring turn) g: `cur` = descriptor of group g, `nxt` = of group g + 1; `cur` is rebuilt for group
             // g + 2 behind the second burst of the group's first stage
-            auto group = [&](i32x4& cur, const i32x4& nxt, int g) {
+            auto group = [&](auto dwg, i32x4& cur, const i32x4& nxt, int g) {
+                constexpr int DWG = decltype(dwg)::value;               // 0: the block walk; diagonal wave: 1 = first group of a pair
+                //                                                         (fresh accumulators), 2 = second (folded into fp64 at its end)
                 static_for<0, NSLOT>([&](auto jc) {
                     constexpr int J = decltype(jc)::value;              // stage st = g*NSLOT + J sits in slot J
                     constexpr int JN = (J + 1) % NSLOT;                 // slot of stage st+1
                     constexpr int JP = (J + NSLOT - 1) % NSLOT;         // slot of stage st+NSLOT-1 (= st-1)
+                    constexpr auto dw1 = std::integral_constant<int, DWG ? 1 : 0>{};
+                    constexpr auto dw0 = std::integral_constant<int, (DWG == 1 && J == 0) ? 2 : (DWG ? 1 : 0)>{};   // a pair starts from zero
                     // slice 0 of stage st; fetches slice 1; requests the B half of stage st+NSLOT-1 (J = 0: the last
                     // stage of this group, otherwise a stage of the next group)
-                    burst(fa0, fb0, fa1, fb1, jc, 1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{},
+                    burst(dw0, fa0, fb0, fa1, fb1, jc, 1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{},
                           J == 0 ? cur : nxt, nothing);
                     // this wave's pieces of stage st+1 have landed (NSLOT-2 later stages may still be in flight);
                     // every wave has read the whole of stage st once its lgkmcnt(0) is behind the barrier
@@ -387,7 +433,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                     // slice 1; fetches slice 0 of stage st+1; requests the A half of stage st+NSLOT (next group) into slot J
                     if constexpr (J == 0) {
                         int rc = 0;
-                        burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{}, nxt,
+                        burst(dw1, fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{}, nxt,
                               [&](auto ic) {
                                   constexpr int i = decltype(ic)::value;
                                   if constexpr (i == 10) {      // group g + 2 starts a new sample iff it lies at or past the end
@@ -403,10 +449,54 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                                   }
                               });
                     } else {
-                        burst(fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{}, nxt,
+                        burst(dw1, fa1, fb1, fa0, fb0, std::integral_constant<int, JN>{}, 0, jc, std::integral_constant<int, 0>{}, nxt,
                               nothing);
                     }
                 });
+                if constexpr (DWG == 2) {
+                    // the pair's eight block diagonals into fp64 (the accumulators restart from zero with the next pair's first
+                    // burst). Lane l of a 32x32 accumulator holds column j = l & 31 and rows 8 q + 4 (l >> 5) + r in register
+                    // 4 q + r: element (j, j) sits in register k = (j & 3) + 4 (j >> 3) of lane j + 32 ((j >> 2) & 1) — every
+                    // register carries the diagonal in exactly two lanes, so sixteen accumulator reads under a two-lane EXEC
+                    // mask each collect the block's diagonal into one VGPR (no per-lane select chain, no mask registers).
+                    // s_nop: an MFMA result must be 11+ wait states old before a VALU reads it (invisible to the compiler in asm).
+                    auto dg = [&](const f32x16& c) -> float {
+                        float t = 0.0f;
+                        uint64_t save;
+                        asm volatile(
+                            "s_nop 15\n\ts_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b32 exec_lo, 0x00000001\n\ts_mov_b32 exec_hi, 0x00000010\n\tv_accvgpr_read_b32 %[t], %[c0]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000002\n\ts_mov_b32 exec_hi, 0x00000020\n\tv_accvgpr_read_b32 %[t], %[c1]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000004\n\ts_mov_b32 exec_hi, 0x00000040\n\tv_accvgpr_read_b32 %[t], %[c2]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000008\n\ts_mov_b32 exec_hi, 0x00000080\n\tv_accvgpr_read_b32 %[t], %[c3]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000100\n\ts_mov_b32 exec_hi, 0x00001000\n\tv_accvgpr_read_b32 %[t], %[c4]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000200\n\ts_mov_b32 exec_hi, 0x00002000\n\tv_accvgpr_read_b32 %[t], %[c5]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000400\n\ts_mov_b32 exec_hi, 0x00004000\n\tv_accvgpr_read_b32 %[t], %[c6]\n\t"
+                            "s_mov_b32 exec_lo, 0x00000800\n\ts_mov_b32 exec_hi, 0x00008000\n\tv_accvgpr_read_b32 %[t], %[c7]\n\t"
+                            "s_mov_b32 exec_lo, 0x00010000\n\ts_mov_b32 exec_hi, 0x00100000\n\tv_accvgpr_read_b32 %[t], %[c8]\n\t"
+                            "s_mov_b32 exec_lo, 0x00020000\n\ts_mov_b32 exec_hi, 0x00200000\n\tv_accvgpr_read_b32 %[t], %[c9]\n\t"
+                            "s_mov_b32 exec_lo, 0x00040000\n\ts_mov_b32 exec_hi, 0x00400000\n\tv_accvgpr_read_b32 %[t], %[c10]\n\t"
+                            "s_mov_b32 exec_lo, 0x00080000\n\ts_mov_b32 exec_hi, 0x00800000\n\tv_accvgpr_read_b32 %[t], %[c11]\n\t"
+                            "s_mov_b32 exec_lo, 0x01000000\n\ts_mov_b32 exec_hi, 0x10000000\n\tv_accvgpr_read_b32 %[t], %[c12]\n\t"
+                            "s_mov_b32 exec_lo, 0x02000000\n\ts_mov_b32 exec_hi, 0x20000000\n\tv_accvgpr_read_b32 %[t], %[c13]\n\t"
+                            "s_mov_b32 exec_lo, 0x04000000\n\ts_mov_b32 exec_hi, 0x40000000\n\tv_accvgpr_read_b32 %[t], %[c14]\n\t"
+                            "s_mov_b32 exec_lo, 0x08000000\n\ts_mov_b32 exec_hi, 0x80000000\n\tv_accvgpr_read_b32 %[t], %[c15]\n\t"
+                            "s_mov_b64 exec, %[sv]"
+                            : [t] "+v"(t), [sv] "=&s"(save)
+                            : [c0] "a"(c[0]), [c1] "a"(c[1]), [c2] "a"(c[2]), [c3] "a"(c[3]), [c4] "a"(c[4]), [c5] "a"(c[5]),
+                              [c6] "a"(c[6]), [c7] "a"(c[7]), [c8] "a"(c[8]), [c9] "a"(c[9]), [c10] "a"(c[10]), [c11] "a"(c[11]),
+                              [c12] "a"(c[12]), [c13] "a"(c[13]), [c14] "a"(c[14]), [c15] "a"(c[15]));
+                        return t;
+                    };
+                    dsum[0] += (double)dg(acc[0][0]);
+                    dsum[1] += (double)dg(acc[0][1]);
+                    dsum[2] += (double)dg(acc[0][2]);
+                    dsum[3] += (double)dg(acc[0][3]);
+                    dsum[4] += (double)dg(acc[1][0]);
+                    dsum[5] += (double)dg(acc[1][1]);
+                    dsum[6] += (double)dg(acc[2][0]);
+                    dsum[7] += (double)dg(acc[3][0]);
+                }
             };
             // prologue: stages 0 .. NSLOT-2 and the A half of stage NSLOT-1 (all of group 0) requested, stage 0 published
             static_for<0, NSLOT - 1>([&](auto slc) { static_for<0, 8>([&](auto dc) { piece(slc, dc, dA); }); });
@@ -415,9 +505,16 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             __builtin_amdgcn_s_barrier();
             static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, 0, fc, fa0, fb0); });
             // groups in pairs (the descriptor sets swap roles); an odd chunk gets one padding group of zeros
-            for (int g = 0; g < ngroups; g += 2) {
-                group(dA, dB, g);
-                group(dB, dA, g + 1);
+            if (dwave) {
+                for (int g = 0; g < ngroups; g += 2) {
+                    group(std::integral_constant<int, 1>{}, dA, dB, g);
+                    group(std::integral_constant<int, 2>{}, dB, dA, g + 1);
+                }
+            } else {
+                for (int g = 0; g < ngroups; g += 2) {
+                    group(std::integral_constant<int, 0>{}, dA, dB, g);
+                    group(std::integral_constant<int, 0>{}, dB, dA, g + 1);
+                }
             }
             lds_wait_all();                  // the trailing fragment reads
             __builtin_amdgcn_s_barrier();    // ... of every wave, before the next unit's prologue overwrites the ring
@@ -425,31 +522,61 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
 
         // partial tile in fragment order of a 2x4 wave grid with 4x2 accumulators per wave (what k_syrk_fixup decodes):
         // wave (wm, wn) x accumulator (m, n) of the 2x2 / 4x4 layout is wave (wm, 2*wn + n/2) x accumulator (m, n%2)
-        float* slot = a.part + (int64_t)u * TILE_FLOATS;
+        if (dwave) {
+            // sum over this chunk's tokens of x^2 for the tile's 256 channels: block -> channels as the fragments were read
+            // (fb[n]: 128 + 32 n .., fa[m]: 32 m ..); the quadrant itself is mirrored from the lower-left one by k_syrk_fixup
+            const int dj = lane & 31;
+            if ((((dj >> 2) & 1) == (lane >> 5))) {                  // the lanes that hold a diagonal element
+                double* dp = pr.dpart + ((int64_t)s * pr.nb + t.bi) * TM + dj;
+                dp[128] = dsum[0];
+                dp[160] = dsum[1];
+                dp[192] = dsum[2];
+                dp[224] = dsum[3];
+                dp[32] = dsum[4];
+                dp[0] = dsum[5];
+                dp[64] = dsum[6];
+                dp[96] = dsum[7];
+            }
+        } else {
+            float* slot = pr.part + (int64_t)ul * TILE_FLOATS;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2],
-                               acc[m][n][4 * q + 3]};
-                    const int wv8 = wm * 4 + wn * 2 + (n >> 1);
-                    int idx = ((((wv8 * 4 + m) * 2 + (n & 1)) * 4 + q) * 64 + lane);
-                    *reinterpret_cast<f32x4*>(slot + (int64_t)idx * 4) = v;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2],
+                                   acc[m][n][4 * q + 3]};
+                        const int wv8 = wm * 4 + wn * 2 + (n >> 1);
+                        int idx = ((((wv8 * 4 + m) * 2 + (n & 1)) * 4 + q) * 64 + lane);
+                        *reinterpret_cast<f32x4*>(slot + (int64_t)idx * 4) = v;
+                    }
+        }
         // the stores share the VM counter with the next unit's LDS-DMA: drain them (and the trailing requests)
         dma_wait_all();
     }
 }
 
-// Sum the S partials of each tile (chunk order), H <- alpha*H + beta*sum, mirror to the upper triangle.
-// One thread per float4 of the fragment-order tile: idx -> (wv,m,n,q,lane) -> rows i0..i0+3, column j.
-__global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ part, float* __restrict__ H,
-                                                    int K, int nb, int ntiles_p, int S, float alpha,
-                                                    float beta) {
+// Sum the S partials of each tile (chunk order), H <- alpha*H + beta*sum, mirror to the upper triangle. One thread per float4
+// of the fragment-order tile: idx -> (wv,m,n,q,lane) -> rows i0..i0+3, column j. grid.z = problem.
+// Diagonal tiles: their upper-right quadrant was not computed (its wave formed the exact diagonal instead): the lower-left
+// quadrant is mirrored into it like an off-diagonal tile. skip_diag: the diagonal entries are left to k_diag_apply.
+struct FixupProb {
+    const float* part;
+    float* H;
+    int K, nb, ntiles_p, S;
+    float alpha, beta;
+};
+struct FixupArgs {
+    FixupProb pr[SYRK_MAX_PROBS];
+    int skip_diag;
+};
+
+__global__ __launch_bounds__(256) void k_syrk_fixup(const FixupArgs fa) {
+    const FixupProb& a = fa.pr[blockIdx.z];
     const int ti = blockIdx.y;
-    const TileIdx t = decode_tile(ti, nb);
+    if (ti >= a.ntiles_p) return;
+    const TileIdx t = decode_tile(ti, a.nb);
     if (!t.valid) return;
     const int idx = blockIdx.x * 256 + threadIdx.x;  // 0 .. 16383
     const int lane = idx & 63;
@@ -458,12 +585,16 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
     const int m = (idx >> 9) & 3;
     const int wv = idx >> 11;
     const int wm = wv >> 2, wn = wv & 3;
+    const bool dtile = t.bi == t.bj;
+    if (dtile && wm == 0 && wn >= 2) return;         // mirrored from the lower-left quadrant below
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-        const float* slot = part + ((int64_t)s * ntiles_p + ti) * TILE_FLOATS;
+    for (int s = 0; s < a.S; ++s) {
+        const float* slot = a.part + ((int64_t)s * a.ntiles_p + ti) * TILE_FLOATS;
         f32x4 v = *reinterpret_cast<const f32x4*>(slot + (int64_t)idx * 4);
         sum += v;
     }
+    const int K = a.K;
+    float* H = a.H;
     const int i0 = t.bi * TM + wm * 128 + m * 32 + 8 * q + 4 * (lane >> 5);
     const int j = t.bj * TM + wn * 64 + n * 32 + (lane & 31);
     if (j >= K) return;
@@ -472,106 +603,62 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const float* __restrict__ pa
     for (int r = 0; r < 4; ++r) {
         int i = i0 + r;
         if (i < K) {
-            float h = beta * sum[r];
-            if (alpha != 0.0f) h += alpha * H[(int64_t)i * K + j];
+            float h = a.beta * sum[r];
+            if (a.alpha != 0.0f) h += a.alpha * H[(int64_t)i * K + j];
             o[r] = h;
-            H[(int64_t)i * K + j] = h;
+            if (!(fa.skip_diag && i == j)) H[(int64_t)i * K + j] = h;
         }
     }
-    if (t.bi != t.bj) {
+    if (!dtile || (wm == 1 && wn < 2)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (i0 + r < K) H[(int64_t)j * K + i0 + r] = o[r];
     }
 }
 
+// Exact diagonal: d[j] = (n_before / n_after) d_old[j] + (2 / n_after) * sum over chunks of dpart[s][j] in fp64, H[j][j] = (float) d[j].
+// d_old is the caller's fp64 running diagonal (dstate, then updated) or, without one, H's own fp32 diagonal (which k_syrk_fixup
+// left untouched): half an ulp of extra rounding per launch, nothing when a Hessian is accumulated in one launch.
+struct DiagProb {
+    const double* dpart;
+    double* dstate;
+    float* H;
+    int K, nbK, S, pad_;
+    double alpha, beta;
+};
+struct DiagArgs {
+    DiagProb pr[SYRK_MAX_PROBS];
+};
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Exact diagonal (round 5, opt-in): d[j] = (n_before / n_after) d[j] + (2 / n_after) sum_t X[t][j]^2 with the sum formed in
-// fp64 (squares of 16-bit values are exact in fp32; eight of them are added in fp32 — 19 bits of a 24-bit significand unless
-// their exponents differ by more than 5 — then folded into an fp64 accumulator), and H[j][j] = (float) d[j].
-// k_syrk4 accumulates 16 products per MFMA into fp32 over 30 - 65 k tokens per unit: its diagonal carries 2 - 3e-6 of relative
-// noise, twice what the reference's sgemm leaves (profiles/r04_parity_envelope_full_down.txt); diag(H) is what GPTQ's actorder
-// sorts and what the damping averages. One more pass over X (HBM-bound: 2 T K bytes), which is why it is opt-in.
-// Grid: x = 512-column blocks, y = token slices; a wave reads whole 1-KiB row segments (16 B per lane).
-// ---------------------------------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void k_diag_sumsq(const SyrkArgs a, double* __restrict__ part /* [gridDim.y][K] */) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t c0 = (int64_t)blockIdx.x * 512 + lane * 8;
-    double acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
-    if (c0 < a.K) {
-        const int nslice = gridDim.y;
-        for (int si = 0; si < a.n; ++si) {
-            const char* base = (const char*)(uintptr_t)a.smp[si].base;
-            const int64_t T = a.smp[si].T;
-            // rows of this sample dealt to (slice, wave) round-robin in runs of 8 (one fp32 partial per run)
-            for (int64_t r0 = ((int64_t)blockIdx.y * 4 + wv) * 8; r0 < T; r0 += (int64_t)nslice * 32) {
-                float f[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (r0 + r < T) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(base + ((r0 + r) * a.ldx + c0) * 2);
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float x0, x1;
-                            if constexpr (DT == LLMC_BF16) {
-                                x0 = __uint_as_float(w[q] << 16);
-                                x1 = __uint_as_float(w[q] & 0xffff0000u);
-                            } else {
-                                x0 = f16_bits_to_f32((uint16_t)(w[q] & 0xffffu));
-                                x1 = f16_bits_to_f32((uint16_t)(w[q] >> 16));
-                            }
-                            f[2 * q] = __builtin_fmaf(x0, x0, f[2 * q]);
-                            f[2 * q + 1] = __builtin_fmaf(x1, x1, f[2 * q + 1]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (double)f[e];
-            }
-        }
-    }
-    // the four waves of the workgroup hold disjoint rows of the same columns: sum them through LDS
-    __shared__ double red[4][512];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[wv][lane * 8 + e] = acc[e];
-    __syncthreads();
-    for (int c = threadIdx.x; c < 512; c += 256) {
-        const int64_t col = (int64_t)blockIdx.x * 512 + c;
-        if (col < a.K) part[(int64_t)blockIdx.y * a.K + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_diag_apply(const double* __restrict__ part, int nslice, int K, double alpha, double beta,
-                                                    double* __restrict__ dstate, float* __restrict__ H) {
+__global__ __launch_bounds__(256) void k_diag_apply(const DiagArgs da) {
+    const DiagProb& a = da.pr[blockIdx.y];
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= K) return;
+    if (j >= a.K) return;
     double s = 0.0;
-    for (int i = 0; i < nslice; ++i) s += part[(int64_t)i * K + j];
-    const double d = alpha * (alpha != 0.0 ? dstate[j] : 0.0) + beta * s;
-    dstate[j] = d;
-    H[(int64_t)j * K + j] = (float)d;
+    for (int i = 0; i < a.S; ++i) s += a.dpart[(int64_t)i * a.nbK + j];
+    double d = a.beta * s;
+    if (a.alpha != 0.0) d += a.alpha * (a.dstate ? a.dstate[j] : (double)a.H[(int64_t)j * a.K + j]);
+    if (a.dstate) a.dstate[j] = d;
+    a.H[(int64_t)j * a.K + j] = (float)d;
 }
 
-static inline int choose_chunks(int ntiles_real, int64_t ngroups, int64_t x_bytes, int ncu) {
-    // pick S >= Smin minimising a simple time model (microseconds):
-    //   rounds * (groups per unit * t_group + t_unit) + fixup traffic (S partial tiles written + read)
+static inline double chunk_cost(int64_t units, int64_t ngroups, int S, int ncu) {
+    // a simple time model (microseconds): rounds * (groups per unit * t_group + t_unit) + fixup traffic (S partial tiles
+    // written + read)
     const double t_group = 1.8, t_unit = 6.0, fix_us_per_tile = 0.13;  // 2 x 256 KiB at ~4 TB/s
+    const double rounds = (double)ceil_div64(units, ncu);
+    return rounds * ((double)ceil_div64(ngroups, S) * t_group + t_unit) + fix_us_per_tile * (double)units;
+}
+
+// pick S >= Smin minimising the model; `copies` identical problems share the queue (their units fill rounds together)
+static inline int choose_chunks(int ntiles_real, int64_t ngroups, int64_t x_bytes, int ncu, int copies) {
     int smin = (int)(x_bytes / (1ll << 31)) + 1;   // unit-relative byte offsets stay below 2^31
     if (smin > ngroups) smin = (int)ngroups;
     if (smin < 1) smin = 1;
     int best = smin;
     double best_cost = 1e30;
     for (int S = smin; S <= SYRK_MAX_CHUNKS && S <= ngroups; ++S) {
-        int64_t units = (int64_t)ntiles_real * S;
-        double rounds = (double)ceil_div64(units, ncu);
-        double cost = rounds * ((double)ceil_div64(ngroups, S) * t_group + t_unit) + fix_us_per_tile * (double)units;
+        const double cost = chunk_cost((int64_t)ntiles_real * S * copies, ngroups, S, ncu);
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = S;
@@ -584,28 +671,27 @@ static inline int choose_chunks(int ntiles_real, int64_t ngroups, int64_t x_byte
 
 using namespace llmc;
 
-// Geometry of one launch: the padded token axis, the chunks, and which sample each chunk starts in. Fills the
-// geometry fields of `a` (not the pointers). Returns 0, or LLMC_EINVAL with the message set.
-static int syrk_plan(const int64_t* T_list, int n, int64_t K, int64_t ldx, SyrkArgs* a) {
+// Geometry of one problem: the padded token axis, the chunks, and which sample each chunk starts in. Fills the geometry
+// fields of `p` (not the pointers) and its samples' T / g0 in smp[0 .. n). Returns 0, or LLMC_EINVAL with the message set.
+static int syrk_plan(const int64_t* T_list, int n, int64_t K, int64_t ldx, int copies, SyrkProb* p, SyrkSample* smp) {
     LLMC_REQUIRE(T_list && n >= 1, "hessian_accum: empty sample list");
-    LLMC_REQUIRE(n <= SYRK_MAX_SAMPLES, "hessian_accum: more than LLMC_HESSIAN_MAX_SAMPLES samples in one call");
     LLMC_REQUIRE(K > 0 && K < (1 << 30) && ldx >= K && ldx % 8 == 0, "hessian_accum: rows must be 16-B aligned, K < 2^30");
     int64_t G = 0;
     for (int i = 0; i < n; ++i) {
         LLMC_REQUIRE(T_list[i] > 0 && T_list[i] < (1ll << 31), "hessian_accum: every sample needs 0 < tokens < 2^31");
-        a->smp[i].T = (uint32_t)T_list[i];
-        a->smp[i].g0 = (uint32_t)G;
+        smp[i].T = (uint32_t)T_list[i];
+        smp[i].g0 = (uint32_t)G;
         G += ceil_div64(T_list[i], GROUP_TOK);
     }
     LLMC_REQUIRE(G < (1ll << 31), "hessian_accum: too many tokens in one call");
-    a->ldx = ldx;
-    a->K = (int)K;
-    a->nb = (int)ceil_div64(K, TM);
-    a->ntiles_p = tiles_padded(a->nb);
-    a->n = n;
-    a->pad_ = 0;
-    const int real = a->nb * (a->nb + 1) / 2;
-    int S = choose_chunks(real, G, G * GROUP_TOK * ldx * 2, 256);
+    p->ldx = ldx;
+    p->K = (int)K;
+    p->nb = (int)ceil_div64(K, TM);
+    p->ntiles_p = tiles_padded(p->nb);
+    p->n = n;
+    p->pad_ = 0;
+    const int real = p->nb * (p->nb + 1) / 2;
+    int S = choose_chunks(real, G, G * GROUP_TOK * ldx * 2, 256, copies);
 #ifdef LLMC_LAB
     if (const char* e = getenv("LLMC_SYRK_S")) S = atoi(e);   // lab: force the token-chunk count
 #endif
@@ -617,54 +703,72 @@ static int syrk_plan(const int64_t* T_list, int n, int64_t K, int64_t ldx, SyrkA
         bool fits = true;
         for (int s = 0; s <= S; ++s) {
             const int64_t g = s == S ? G : (s * G / S) & ~(int64_t)1;   // interior boundaries even: the kernel walks group pairs
-            a->cb[s] = (uint32_t)g;
-            while (i + 1 < n && (int64_t)a->smp[i + 1].g0 <= g) ++i;
-            a->ci[s] = (uint32_t)i;
+            p->cb[s] = (uint32_t)g;
+            while (i + 1 < n && (int64_t)smp[i + 1].g0 <= g) ++i;
+            p->ci[s] = (uint32_t)i;
             // a unit walks the samples ci[s] .. (the one holding group cb[s + 1], whose first stages it requests)
-            if (s > 0 && (int)a->ci[s] - (int)a->ci[s - 1] + 1 > SYRK_UNIT_SAMPLES) fits = false;
+            if (s > 0 && (int)p->ci[s] - (int)p->ci[s - 1] + 1 > SYRK_UNIT_SAMPLES) fits = false;
         }
         if (fits) break;
     }
-    a->S = S;
+    p->S = S;
     return LLMC_OK;
 }
 
-static size_t syrk_ws_bytes(const SyrkArgs& a) {
-    return (size_t)a.S * a.ntiles_p * TILE_FLOATS * sizeof(float) + 256;
+static inline size_t align256z(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// The whole launch: every problem's geometry, its slices of the workspace (partial tiles, fp64 diagonal partials) and the
+// round-barrier words behind them. ws may be null (sizes only). Problems with the same shape share the chunk-count search.
+static int syrk_plan_multi(const llmc_hessian_problem_t* probs, int P, void* ws, SyrkArgs* a, size_t* total) {
+    LLMC_REQUIRE(probs && P >= 1 && P <= SYRK_MAX_PROBS, "hessian_accum_multi: 1 .. LLMC_HESSIAN_MAX_PROBLEMS problems per call");
+    int nsmp = 0, unit0 = 0;
+    size_t off = 0;
+    for (int q = 0; q < P; ++q) {
+        const llmc_hessian_problem_t& h = probs[q];
+        LLMC_REQUIRE(h.n >= 1 && nsmp + h.n <= SYRK_MAX_SAMPLES, "hessian_accum: more than LLMC_HESSIAN_MAX_SAMPLES samples in one call");
+        int copies = 0;      // problems of the same shape (K and token lists) fill rounds together
+        for (int r = 0; r < P; ++r) {
+            bool same = probs[r].K == h.K && probs[r].n == h.n && probs[r].ldx == h.ldx;
+            for (int i = 0; same && i < h.n; ++i) same = probs[r].T_list_host && h.T_list_host && probs[r].T_list_host[i] == h.T_list_host[i];
+            copies += same ? 1 : 0;
+        }
+        SyrkProb* p = &a->pr[q];
+        int rc = syrk_plan(h.T_list_host, h.n, h.K, h.ldx, copies < 1 ? 1 : copies, p, a->smp + nsmp);
+        if (rc) return rc;
+        p->smp0 = nsmp;
+        p->unit0 = unit0;
+        nsmp += h.n;
+        unit0 += p->S * p->ntiles_p;
+        p->part = ws ? (float*)((char*)ws + off) : nullptr;
+        off += align256z((size_t)p->S * p->ntiles_p * TILE_FLOATS * sizeof(float));
+        p->dpart = ws ? (double*)((char*)ws + off) : nullptr;
+        off += align256z((size_t)p->S * p->nb * TM * sizeof(double));
+    }
+    a->P = P;
+    a->nunits = unit0;
+    a->sync = ws ? (unsigned*)((char*)ws + off) : nullptr;
+    off += 256;
+    if (total) *total = off;
+    return LLMC_OK;
 }
 
 extern "C" int llmc_hessian_max_samples(void) { return SYRK_MAX_SAMPLES; }
+extern "C" int llmc_hessian_max_problems(void) { return SYRK_MAX_PROBS; }
 
-extern "C" size_t llmc_hessian_accum_ptrs_ws_bytes(const int64_t* T_list_host, int n, int64_t K, int64_t ldx) {
+extern "C" size_t llmc_hessian_accum_multi_ws_bytes(const llmc_hessian_problem_t* probs_host, int P) {
     SyrkArgs a;
-    if (syrk_plan(T_list_host, n, K, ldx, &a)) return 0;
-    return syrk_ws_bytes(a);
+    size_t total = 0;
+    if (syrk_plan_multi(probs_host, P, nullptr, &a, &total)) return 0;
+    return total;
 }
 
-extern "C" size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx) {
-    return llmc_hessian_accum_ptrs_ws_bytes(&T, 1, K, ldx);
-}
-
-extern "C" int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,
-                                                int64_t K, int64_t ldx, void* ws, llmc_stream_t stream) {
-    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_accum: X must be f16 or bf16");
-    LLMC_REQUIRE(X_list_host && ws, "hessian_accum: null argument");
-    SyrkArgs a;
-    int rc = syrk_plan(T_list_host, n, K, ldx, &a);
-    if (rc) return rc;
-    for (int i = 0; i < n; ++i) {
-        LLMC_REQUIRE(X_list_host[i] && ((uintptr_t)X_list_host[i] & 15) == 0, "hessian_accum: X rows must be 16-B aligned");
-        a.smp[i].base = (uint64_t)(uintptr_t)X_list_host[i];
-    }
-    hipStream_t st = (hipStream_t)stream;
-    a.part = (float*)ws;
-    a.sync = (unsigned*)((char*)ws + (size_t)a.S * a.ntiles_p * TILE_FLOATS * sizeof(float));
+static int syrk_launch(const SyrkArgs& a, int dt, hipStream_t st) {
     int abl = 0;
+    SyrkArgs b = a;
 #ifdef LLMC_LAB
-    if (getenv("LLMC_SYRK_NOSYNC")) a.sync = nullptr;
+    if (getenv("LLMC_SYRK_NOSYNC")) b.sync = nullptr;
     if (const char* e = getenv("LLMC_SYRK_ABL")) abl = atoi(e);   // wrong results by design
 #endif
-    if (a.sync) LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 8, st));     // round counter + time-out counter
     // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous), minus the CUs the caller keeps free for
     // kernels of other streams (llmc_hip_set_cu_reserve): a k_syrk4 workgroup owns its CU, nothing co-resides with it
     int grid = (device_cu_count() - cu_reserve()) & ~7;
@@ -684,76 +788,137 @@ extern "C" int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, 
 #endif
     (void)abl;
     const int lds_bytes = NSLOT * S4_STAGE;
-    rc = ensure_dynamic_lds(fn, lds_bytes);
+    int rc = ensure_dynamic_lds(fn, lds_bytes);
     if (rc) return rc;
-    void* kargs[] = {(void*)&a};
+    void* kargs[] = {(void*)&b};
     LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(grid), dim3(S4_THREADS), kargs, (size_t)lds_bytes, st));
     LLMC_LAUNCH_CHECK();
+    return LLMC_OK;
+}
+
+// One launch for the partial tiles of every problem (one unit queue: the problems' triangular tails fill rounds together).
+// k1_batch_off (llmc_hip_set_option): one launch per problem instead — same units, same bits.
+extern "C" int llmc_hessian_accum_multi_partials(const llmc_hessian_problem_t* probs_host, int P, int dt, void* ws,
+                                                 llmc_stream_t stream) {
+    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_accum: X must be f16 or bf16");
+    LLMC_REQUIRE(ws && ((uintptr_t)ws & 255) == 0, "hessian_accum: workspace must be 256-B aligned");
+    SyrkArgs a;
+    int rc = syrk_plan_multi(probs_host, P, ws, &a, nullptr);
+    if (rc) return rc;
+    for (int q = 0; q < P; ++q) {
+        LLMC_REQUIRE(probs_host[q].X_list_host, "hessian_accum: null sample list");
+        for (int i = 0; i < probs_host[q].n; ++i) {
+            const void* x = probs_host[q].X_list_host[i];
+            LLMC_REQUIRE(x && ((uintptr_t)x & 15) == 0, "hessian_accum: X rows must be 16-B aligned");
+            a.smp[a.pr[q].smp0 + i].base = (uint64_t)(uintptr_t)x;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LLMC_HIP_CHECK(hipMemsetAsync(a.sync, 0, 8 * SYRK_MAX_PROBS, st));     // per launch: round counter + time-out counter
+    if (P > 1 && opt(OPT_K1_BATCH_OFF)) {
+        for (int q = 0; q < P; ++q) {
+            SyrkArgs one = a;
+            one.P = 1;
+            one.pr[0] = a.pr[q];
+            one.pr[0].unit0 = 0;
+            one.nunits = a.pr[q].S * a.pr[q].ntiles_p;
+            one.sync = a.sync + 2 * q;
+            rc = syrk_launch(one, dt, st);
+            if (rc) return rc;
+        }
+        return LLMC_OK;
+    }
+    return syrk_launch(a, dt, st);
+}
+
+// The ordered reduction of every problem's partial tiles into its H (running mean weights from n_before / n_after) and the
+// exact diagonal (k_diag_apply). k1_fp32_diag (llmc_hip_set_option): keep the MFMA kernel's own fp32 diagonal instead.
+extern "C" int llmc_hessian_accum_multi_reduce(const llmc_hessian_problem_t* probs_host, int P, const void* ws, llmc_stream_t stream) {
+    LLMC_REQUIRE(ws, "hessian_accum_reduce: null workspace");
+    SyrkArgs a;
+    int rc = syrk_plan_multi(probs_host, P, (void*)ws, &a, nullptr);
+    if (rc) return rc;
+    FixupArgs f;
+    DiagArgs d;
+    const bool exact = !opt(OPT_K1_FP32_DIAG);
+    int max_tiles = 0, max_k = 0;
+    for (int q = 0; q < P; ++q) {
+        const llmc_hessian_problem_t& h = probs_host[q];
+        LLMC_REQUIRE(h.H && h.n_after > 0, "hessian_accum_reduce: bad argument");
+        const SyrkProb& p = a.pr[q];
+        f.pr[q].part = p.part; f.pr[q].H = h.H; f.pr[q].K = p.K; f.pr[q].nb = p.nb; f.pr[q].ntiles_p = p.ntiles_p; f.pr[q].S = p.S;
+        f.pr[q].alpha = (float)(h.n_before / h.n_after);
+        f.pr[q].beta = (float)(2.0 / h.n_after);
+        d.pr[q].dpart = p.dpart; d.pr[q].dstate = h.dstate; d.pr[q].H = h.H; d.pr[q].K = p.K; d.pr[q].nbK = p.nb * TM; d.pr[q].S = p.S;
+        d.pr[q].pad_ = 0;
+        d.pr[q].alpha = h.n_before / h.n_after;
+        d.pr[q].beta = 2.0 / h.n_after;
+        if (p.ntiles_p > max_tiles) max_tiles = p.ntiles_p;
+        if (p.K > max_k) max_k = p.K;
+    }
+    f.skip_diag = exact ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_syrk_fixup, dim3(TILE_FLOATS / 4 / 256, max_tiles, P), dim3(256), 0, st, f);
+    LLMC_LAUNCH_CHECK();
+    if (exact) {
+        hipLaunchKernelGGL(k_diag_apply, dim3((unsigned)ceil_div64(max_k, 256), P), dim3(256), 0, st, d);
+        LLMC_LAUNCH_CHECK();
+    }
     return LLMC_OK;
 }
 
 // Number of round barriers of the LAST launch on this workspace that gave up waiting (device word behind the partials):
 // copies it to *out_host after synchronising `stream`. 0 in a healthy run; > 0 means another stream kept workgroups of the
 // persistent grid off their CUs (results stay correct, the kernel re-fetches its panels: slower).
-extern "C" int llmc_hessian_accum_barrier_timeouts(const void* ws, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
-                                                   unsigned* out_host, llmc_stream_t stream) {
+extern "C" int llmc_hessian_accum_multi_barrier_timeouts(const llmc_hessian_problem_t* probs_host, int P, const void* ws,
+                                                         unsigned* out_host, llmc_stream_t stream) {
     LLMC_REQUIRE(ws && out_host, "hessian_accum_barrier_timeouts: null argument");
     SyrkArgs a;
-    int rc = syrk_plan(T_list_host, n, K, ldx, &a);
+    int rc = syrk_plan_multi(probs_host, P, (void*)ws, &a, nullptr);
     if (rc) return rc;
-    const char* p = (const char*)ws + (size_t)a.S * a.ntiles_p * TILE_FLOATS * sizeof(float) + 4;
-    LLMC_HIP_CHECK(hipMemcpyAsync(out_host, p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    unsigned w[2 * SYRK_MAX_PROBS] = {};
+    LLMC_HIP_CHECK(hipMemcpyAsync(w, a.sync, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
     LLMC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    unsigned t = 0;
+    for (int q = 0; q < SYRK_MAX_PROBS; ++q) t += w[2 * q + 1];
+    *out_host = t;
     return LLMC_OK;
 }
 
-static constexpr int DIAG_SLICES = 96;       // token slices: 96 x ceil(K / 512) workgroups
-
-extern "C" size_t llmc_hessian_diag_ws_bytes(int64_t K) {
-    return K > 0 ? (size_t)DIAG_SLICES * K * sizeof(double) : 0;
+// ---- one problem: the entry points of rounds 1-5, now thin wrappers -------------------------------------------------------
+static llmc_hessian_problem_t one_problem(float* H, const void* const* X, const int64_t* T, int n, int64_t K, int64_t ldx,
+                                          double n_before, double n_after) {
+    llmc_hessian_problem_t h;
+    h.H = H; h.dstate = nullptr; h.X_list_host = X; h.T_list_host = T; h.n = n; h.K = K; h.ldx = ldx;
+    h.n_before = n_before; h.n_after = n_after;
+    return h;
 }
 
-// Optional second pass of an accumulation step (see k_diag_sumsq): dstate [K] fp64 carries the exact running diagonal across
-// calls (ignored and overwritten when n_before == 0); H's diagonal is overwritten with its fp32 rounding. Call it AFTER the
-// llmc_hessian_accum* call of the same samples, with the same n_before / n_after. ws: llmc_hessian_diag_ws_bytes(K).
-extern "C" int llmc_hessian_diag_accum_ptrs(float* H, double* dstate, const void* const* X_list_host, const int64_t* T_list_host,
-                                            int n, int dt, int64_t K, int64_t ldx, double n_before, double n_after, void* ws,
-                                            llmc_stream_t stream) {
-    LLMC_REQUIRE(dt == LLMC_F16 || dt == LLMC_BF16, "hessian_diag: X must be f16 or bf16");
-    LLMC_REQUIRE(H && dstate && X_list_host && T_list_host && ws && n_after > 0, "hessian_diag: null argument");
-    LLMC_REQUIRE(n >= 1 && n <= SYRK_MAX_SAMPLES, "hessian_diag: 1 .. LLMC_HESSIAN_MAX_SAMPLES samples per call");
-    LLMC_REQUIRE(K > 0 && K % 8 == 0 && ldx >= K && ldx % 8 == 0, "hessian_diag: K and the row stride must be multiples of 8");
-    SyrkArgs a;
-    a.K = (int)K; a.ldx = ldx; a.n = n;
-    for (int i = 0; i < n; ++i) {
-        LLMC_REQUIRE(X_list_host[i] && ((uintptr_t)X_list_host[i] & 15) == 0 && T_list_host[i] > 0, "hessian_diag: bad sample");
-        a.smp[i].base = (uint64_t)(uintptr_t)X_list_host[i];
-        a.smp[i].T = (uint32_t)T_list_host[i];
-        a.smp[i].g0 = 0;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)ceil_div64(K, 512), DIAG_SLICES);
-    if (dt == LLMC_BF16) hipLaunchKernelGGL((k_diag_sumsq<LLMC_BF16>), grid, dim3(256), 0, st, a, (double*)ws);
-    else hipLaunchKernelGGL((k_diag_sumsq<LLMC_F16>), grid, dim3(256), 0, st, a, (double*)ws);
-    LLMC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_diag_apply, dim3((unsigned)ceil_div64(K, 256)), dim3(256), 0, st, (const double*)ws, DIAG_SLICES, (int)K,
-                       n_before / n_after, 2.0 / n_after, dstate, H);
-    LLMC_LAUNCH_CHECK();
-    return LLMC_OK;
+extern "C" size_t llmc_hessian_accum_ptrs_ws_bytes(const int64_t* T_list_host, int n, int64_t K, int64_t ldx) {
+    const llmc_hessian_problem_t h = one_problem(nullptr, nullptr, T_list_host, n, K, ldx, 0.0, 1.0);
+    return llmc_hessian_accum_multi_ws_bytes(&h, 1);
+}
+
+extern "C" size_t llmc_hessian_accum_ws_bytes(int64_t T, int64_t K, int64_t ldx) {
+    return llmc_hessian_accum_ptrs_ws_bytes(&T, 1, K, ldx);
+}
+
+extern "C" int llmc_hessian_accum_ptrs_partials(const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,
+                                                int64_t K, int64_t ldx, void* ws, llmc_stream_t stream) {
+    const llmc_hessian_problem_t h = one_problem(nullptr, X_list_host, T_list_host, n, K, ldx, 0.0, 1.0);
+    return llmc_hessian_accum_multi_partials(&h, 1, dt, ws, stream);
+}
+
+extern "C" int llmc_hessian_accum_barrier_timeouts(const void* ws, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
+                                                   unsigned* out_host, llmc_stream_t stream) {
+    const llmc_hessian_problem_t h = one_problem(nullptr, nullptr, T_list_host, n, K, ldx, 0.0, 1.0);
+    return llmc_hessian_accum_multi_barrier_timeouts(&h, 1, ws, out_host, stream);
 }
 
 extern "C" int llmc_hessian_accum_ptrs_reduce(float* H, const int64_t* T_list_host, int n, int64_t K, int64_t ldx,
                                               double n_before, double n_after, const void* ws, llmc_stream_t stream) {
-    LLMC_REQUIRE(H && ws && n_after > 0, "hessian_accum_reduce: bad argument");
-    SyrkArgs a;
-    int rc = syrk_plan(T_list_host, n, K, ldx, &a);
-    if (rc) return rc;
-    float alpha = (float)(n_before / n_after);
-    float beta = (float)(2.0 / n_after);
-    hipLaunchKernelGGL(k_syrk_fixup, dim3(TILE_FLOATS / 4 / 256, a.ntiles_p), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)ws, H, (int)K, a.nb, a.ntiles_p, a.S, alpha, beta);
-    LLMC_LAUNCH_CHECK();
-    return LLMC_OK;
+    const llmc_hessian_problem_t h = one_problem(H, nullptr, T_list_host, n, K, ldx, n_before, n_after);
+    return llmc_hessian_accum_multi_reduce(&h, 1, ws, stream);
 }
 
 extern "C" int llmc_hessian_accum_ptrs(float* H, const void* const* X_list_host, const int64_t* T_list_host, int n, int dt,

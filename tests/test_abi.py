@@ -41,7 +41,7 @@ def test_workspace_queries_are_pure_host_calls():
     lib = _ffi.lib()
     assert lib.llmc_minmax_qparams_ws_bytes(4096, 128) == 0
     assert lib.llmc_minmax_qparams_ws_bytes(1, 1 << 22) > 0
-    assert (lib.llmc_hessian_accum_ws_bytes(262144, 4096, 4096) - 256) % (256 * 256 * 4) == 0
+    assert lib.llmc_hessian_accum_ws_bytes(262144, 4096, 4096) > 136 * 256 * 256 * 4          # partial tiles of 136 tiles x S chunks, fp64 diagonal partials, barrier words
     assert lib.llmc_chol_inv_upper_ws_bytes(4096) >= 4096 * 4096 * 4
     assert lib.llmc_gptq_quantize_ws_bytes(4096, 4096) == 3 * 4096 * 512 * 4      # err columns of three groups in flight
 

@@ -1,5 +1,5 @@
-"""bench.py's multi-rank plumbing without a GPU: `--gpus N --dry` self-spawns N ranks (Gloo; N = 2, 4, 8), runs the independent,
-hand-off and cooperative steps with CPU stand-ins, and prints the contract's JSON line with n_gpus = N."""
+"""bench.py's multi-rank plumbing without a GPU: `--gpus N --dry` self-spawns N ranks (Gloo; N = 2, 4, 8), runs the hand-off
+(timed by default), independent and cooperative steps with CPU stand-ins, and prints the contract's JSON line with n_gpus = N."""
 import json
 import os
 import subprocess
@@ -28,7 +28,7 @@ def check_contract(j, gpus):
     assert 'dry-run' in j['data']
     for k in ('metric', 'ms_per_step', 'vs_baseline', 'dtype', 'config', 'roofline'):
         assert k in j
-    assert 'unmeasured on hardware' in j['config']['multi_gpu_status']
+    assert j['value_mode'] in ('independent_no_comm', 'handoff_gloo_dry', 'cooperative') and 'interrank_bytes_per_step_per_rank' in j
 
 
 @pytest.mark.parametrize('mode', ['independent', 'cooperative', 'handoff'])
@@ -43,20 +43,24 @@ def test_self_spawn_two_ranks_dry(mode):
         assert 'handed owner-to-owner' in j['config']['parallelism']
     if mode == 'independent':
         assert 'no data-path traffic' in j['config']['parallelism']
-    assert 'handoff_value' not in j and 'cooperative_value' not in j        # an explicit mode measures that mode only
+    assert 'independent_value' not in j and 'cooperative_value' not in j        # an explicit mode measures that mode only
+    assert j['value_mode'] == {'independent': 'independent_no_comm', 'handoff': 'handoff_gloo_dry', 'cooperative': 'cooperative'}[mode]
 
 
 @pytest.mark.parametrize('gpus', [2, 4, 8])
-def test_default_mode_carries_the_contract_value_and_both_partitions(gpus):
-    """No --mode with N > 1 (what the driver's scaling run launches): `value` comes from block-sharded ownership without
-    data-path traffic (it cannot wedge), and ONE line also carries handoff_value (block outputs handed owner-to-owner) and
-    cooperative_value (north_star's partition: one block shared by all ranks) measured outside the timed region. World sizes
-    4 and 8 run the same collectives the 8-GPU node will (Gloo here): broadcast, all_reduce, batched send/recv, ring."""
+def test_default_mode_times_the_handoff_partition_and_carries_the_others(gpus):
+    """No --mode with N > 1 (what the driver's scaling run launches): one hand-off step is tried first on every rank; it works
+    here, so the TIMED region runs north_star's partition (every rank owns its blocks, a block's calibration activations arrive
+    from the previous owner over send/recv: `value_mode: handoff...`), and ONE line also carries independent_value (the same
+    ownership without traffic) and cooperative_value (one block shared by all ranks) measured outside the timed region. World
+    sizes 4 and 8 run the same collectives the 8-GPU node will (Gloo here): broadcast, all_reduce, batched send/recv, ring."""
     j = run([], gpus=gpus)
     check_contract(j, gpus)
-    assert j['scaling'] == 'weak' and 'no data-path traffic' in j['config']['parallelism']
-    assert j['handoff_value'] > 0 and j['cooperative_value'] > 0
+    assert j['value_mode'].startswith('handoff') and j['scaling'] == 'weak'
+    assert 'handed owner-to-owner' in j['config']['parallelism']
+    assert j['independent_value'] > 0 and j['cooperative_value'] > 0
     assert 'handoff_error' not in j and 'cooperative_error' not in j
+    assert j['interrank_bytes_per_step_per_rank']['handoff'] > 0 and j['interrank_bytes_per_step_per_rank']['independent'] == 0
 
 
 @pytest.mark.parametrize('gpus', [4, 8])
@@ -67,15 +71,17 @@ def test_cooperative_mode_at_node_world_sizes(gpus):
 
 
 def test_failing_handoff_is_recorded_and_does_not_take_the_line_down():
-    """The safety net of the first multi-GPU run. Default mode: the hand-off raising (on every rank, like an unavailable
-    peer-to-peer path) costs only `handoff_value`: the contract value and cooperative_value are still there, the reason is
-    in handoff_error. Explicit --mode handoff: the ranks agree (over the Gloo control group) to continue with the same
-    ownership without the hand-off."""
+    """The safety net of the first multi-GPU run. Default mode: the pre-flight hand-off step raising (on every rank, like an
+    unavailable peer-to-peer path) makes all ranks agree — over the Gloo control group — to time the same ownership WITHOUT
+    data-path traffic: the contract value and cooperative_value are still there, the reason is in handoff_error. Explicit --mode
+    handoff: the same agreement."""
     j = run([], {'LLMC_BENCH_DRY_FAIL_HANDOFF': '1'})
     assert j['n_gpus'] == 2 and j['value'] > 0 and j['scaling'] == 'weak'
-    assert 'handoff_error' in j and 'handoff_value' not in j and j['cooperative_value'] > 0
+    assert j['value_mode'] == 'independent_no_comm' and 'no data-path traffic' in j['config']['parallelism']
+    assert 'handoff_error' in j and 'independent_value' not in j and j['cooperative_value'] > 0
     j = run(['--mode', 'handoff'], {'LLMC_BENCH_DRY_FAIL_HANDOFF': '1'})
     assert j['value'] > 0 and 'handoff_error' in j and 'no data-path traffic' in j['config']['parallelism']
+    assert j['value_mode'] == 'independent_no_comm'
 
 
 def test_single_rank_needs_a_gpu_or_dry():

@@ -163,7 +163,7 @@ def test_sample_table_ragged_lengths_and_many_samples():
     from llmc_amd.compression.quantization.hessian import HessianAccumulator
     K = 776
     gen = torch.Generator().manual_seed(11)
-    lens = [300, 1000, 257, 4096, 129, 640, 2047, 511] + [260 + 3 * i for i in range(200)] + [5, 17, 200, 64]
+    lens = [300, 1000, 257, 4096, 129, 640, 2047, 511] + [260 + (3 * i) % 200 for i in range(540)] + [5, 17, 200, 64]
     samples = [(torch.randn(1, t, K, generator=gen) * 3).to(torch.bfloat16).cuda() for t in lens]
     acc = HessianAccumulator(K, 'cuda')
     acc.timing = []
@@ -270,17 +270,17 @@ def test_pending_references_are_bounded_in_bytes(monkeypatch):
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
 def test_exact_diag_option_gives_the_fp64_diagonal_and_leaves_the_rest_alone(dt):
-    """HessianAccumulator(exact_diag=True) (GPTQ special.hessian_exact_diag): diag(H) = (2 / n) sum x^2 formed in fp64 and rounded
-    once — at the fp32 rounding level of the exact value, where the MFMA kernel's fp32 accumulation over thousands of tokens is
-    10x further away; every off-diagonal bit is the default path's; per-sample feeds, several flushes (running mean) and ragged
-    sample lengths included."""
+    """The default (round 6): diag(H) = (2 / n) sum x^2 folded into fp64 every 256 tokens by the MFMA kernel's diagonal-tile wave
+    and rounded once — at the fp32 rounding level of the exact value, where an fp32 chain over thousands of tokens
+    (exact_diag=False, rounds 1-5's default) is 10x further away; every off-diagonal bit is the same either way; per-sample
+    feeds, several flushes (running mean) and ragged sample lengths included."""
     from llmc_amd.compression.quantization.hessian import HessianAccumulator
     K = 1024
     gen = torch.Generator(device='cuda').manual_seed(11)
     xs = [(torch.randn(1, t, K, generator=gen, device='cuda') * torch.exp(0.7 * torch.randn(K, generator=gen, device='cuda'))).to(dt)
           for t in (2048, 2048, 777, 2048, 300, 2048, 4096, 2048)]
-    a0 = HessianAccumulator(K, 'cuda')
-    a1 = HessianAccumulator(K, 'cuda', exact_diag=True)
+    a0 = HessianAccumulator(K, 'cuda', exact_diag=False)
+    a1 = HessianAccumulator(K, 'cuda')
     for i, x in enumerate(xs):
         a0.add(x)
         a1.add(x)
@@ -292,10 +292,62 @@ def test_exact_diag_option_gives_the_fp64_diagonal_and_leaves_the_rest_alone(dt)
     ref = sum((x.double() ** 2).sum(dim=(0, 1)) for x in xs) * (2.0 / len(xs))
     e1 = ((torch.diagonal(H1).double() - ref).abs() / ref).max().item()
     e0 = ((torch.diagonal(H0).double() - ref).abs() / ref).max().item()
-    assert e1 <= 1.2e-7, e1             # half an fp32 ulp (6e-8) + the fp32 partial sums of 8 squares
+    assert e1 <= 1.2e-7, e1             # half an fp32 ulp (6e-8) + the fp32 chains of 16 MFMAs between the fp64 folds
     assert e0 > e1                      # (informative: the default diagonal is the noisier one)
     # reset() starts over
     a1.reset()
     a1.add(xs[0])
     r0 = (xs[0].double() ** 2).sum(dim=(0, 1)) * 2.0
-    assert ((torch.diagonal(a1.H).double() - r0).abs() / r0).max().item() <= 1.2e-7
+    # one 2048-token sample = eight fp64 folds of 16 chained MFMAs each: their fp32 rounding (1e-7) is not averaged down yet
+    assert ((torch.diagonal(a1.H).double() - r0).abs() / r0).max().item() <= 2.5e-7
+
+
+@pytest.mark.parametrize('K,lens', [(4096, [2048] * 6), (1024, [777, 2048, 300, 1536]), (640, [2048, 2048])])
+def test_several_hessians_in_one_launch(K, lens):
+    """HessianAccumulator.flush_many -> llmc_hessian_accum_multi_*: up to four Hessians of one width share ONE unit queue (the
+    three K = 4096 inputs of a Llama block). The token-chunk count of a launch is chosen for the problems that share it, so
+    against one-by-one launches the fp32 sums are formed in another order: equal to summation-order noise, diagonal at the
+    fp32 rounding of the exact value either way; the one-launch-per-problem form of the SAME call (k1_batch_off) is bit-identical."""
+    from llmc_amd import _ffi
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    gen = torch.Generator(device='cuda').manual_seed(K)
+    sets = [[(torch.randn(1, t, K, generator=gen, device='cuda') * (1 + p)).to(torch.bfloat16) for t in lens] for p in range(3)]
+    singles = []
+    for xs in sets:
+        a = HessianAccumulator(K, 'cuda')
+        for x in xs:
+            a.add(x)
+        singles.append(a.H.clone())
+    merged = {}
+    for batch_off in (0, 1):
+        accs = [HessianAccumulator(K, 'cuda') for _ in sets]
+        for a, xs in zip(accs, sets):
+            for x in xs:
+                a.add(x)
+        accs[0].timing = []
+        with _ffi.option(k1_batch_off=batch_off):
+            HessianAccumulator.flush_many(accs)
+        assert len(accs[0].timing) == 1 and accs[0].timing[0][4] == 3          # one call carried all three
+        merged[batch_off] = [a.H.clone() for a in accs]
+        for a, h, xs in zip(accs, singles, sets):
+            assert not a._pending
+            d = torch.sqrt(torch.outer(torch.diagonal(h), torch.diagonal(h)))
+            assert float(((a.H - h).abs() / d).max()) < 2e-6, (K, batch_off)
+            assert torch.equal(a.H, a.H.T)
+            ref = sum((x.double() ** 2).sum(dim=(0, 1)) for x in xs) * (2.0 / len(xs))
+            assert float(((torch.diagonal(a.H).double() - ref).abs() / ref).max()) <= 2.5e-7
+        assert accs[0].barrier_timeouts() == 0
+    for h0, h1 in zip(merged[0], merged[1]):
+        assert torch.equal(h0, h1)
+    # a second round on the same accumulators: the running mean continues through the merged launch
+    for a, xs in zip(accs, sets):
+        a.add(xs[0])
+    HessianAccumulator.flush_many(accs)
+    for a, xs in zip(accs, sets):
+        ref = HessianAccumulator(K, 'cuda')
+        for x in xs:
+            ref.add(x)
+        _ = ref.H
+        ref.add(xs[0])
+        d = torch.sqrt(torch.outer(torch.diagonal(ref.H), torch.diagonal(ref.H)))
+        assert float(((a.H - ref.H).abs() / d).max()) < 2e-6

@@ -87,7 +87,7 @@ def test_gptq_hessian_sharing_needs_the_same_input_tensor(monkeypatch):
     import llmc_amd.compression.quantization.gptq as gq
 
     class FakeAcc:
-        def __init__(self, K, dev, defer=True, exact_diag=False):
+        def __init__(self, K, dev, defer=True, exact_diag=True):
             self.K, self.nsamples, self.fed = K, 0, []
             self.H = torch.zeros(K, K)
 
@@ -142,7 +142,7 @@ def test_gptq_hessian_sharing_with_skipped_experts_and_pass_ids(monkeypatch):
     import llmc_amd.compression.quantization.gptq as gq
 
     class FakeAcc:
-        def __init__(self, K, dev, defer=True, exact_diag=False):
+        def __init__(self, K, dev, defer=True, exact_diag=True):
             self.K, self.nsamples, self.fed = K, 0, []
             self.H = torch.zeros(K, K)
 
@@ -203,7 +203,7 @@ def test_true_sequential_first_pass_feeds_only_the_first_subset(monkeypatch):
     import llmc_amd.compression.quantization.gptq as gq
 
     class FakeAcc:
-        def __init__(self, K, dev, defer=True, exact_diag=False):
+        def __init__(self, K, dev, defer=True, exact_diag=True):
             self.K, self.nsamples, self.fed = K, 0, []
             self.H = torch.zeros(K, K)
 

@@ -96,7 +96,7 @@ def run_ours(a, data):
     W, X = data['W'].to(dev), data['X'].to(dev)
     R, K = W.shape
     out = {}
-    acc = HessianAccumulator(K, dev, exact_diag=(a.arm == 'ours_exactdiag'))
+    acc = HessianAccumulator(K, dev, exact_diag=(a.arm != 'ours_fp32diag'))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(X.shape[0]):
@@ -131,7 +131,7 @@ def run_ours(a, data):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--arm', required=True, choices=['ref_cpu', 'ref_rocm', 'ours', 'ours_exactdiag'])
+    ap.add_argument('--arm', required=True, choices=['ref_cpu', 'ref_rocm', 'ours', 'ours_fp32diag'])
     ap.add_argument('--data', required=True)
     ap.add_argument('--out', required=True)
     ap.add_argument('--threads', type=int, default=0)
@@ -149,7 +149,7 @@ def main():
         torch.set_num_threads(a.threads)
     data = torch.load(a.data)
     t0 = time.perf_counter()
-    if a.arm in ('ours', 'ours_exactdiag'):
+    if a.arm in ('ours', 'ours_fp32diag'):
         out = run_ours(a, data)
     else:
         out = run_reference(a, data, torch.device('cpu') if a.arm == 'ref_cpu' else torch.device('cuda', 0))

@@ -85,7 +85,7 @@ def main():
         ]
     if a.full_down:
         shapes = [('down_proj 4096x14336, 128x2048 tokens (the bench configuration)', 4096, 14336, 128, 2048,
-                   [('ref_cpu', 32), ('ref_rocm', 0), ('ours', 0), ('ours_exactdiag', 0)])]
+                   [('ref_cpu', 32), ('ref_rocm', 0), ('ours', 0), ('ours_fp32diag', 0)])]
     report = {'cores': cores, 'torch': torch.__version__, 'shapes': []}
     lines = []
     for si, (title, R, K, n_seq, seq, arms) in enumerate(shapes):
