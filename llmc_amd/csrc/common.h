@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/llmc_hip.h"
 
@@ -67,6 +68,10 @@ enum Opt : int {
     OPT_COUNT
 };
 int opt(int id);
+#ifdef LLMC_LAB
+// lab builds only (tools/probes; never in the shipped library): ablation / debug switches read from the environment
+static inline const char* lab_env(const char* k) { return getenv(k); }
+#endif
 
 static inline int dtype_size(int dt) { return dt == LLMC_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == LLMC_F16 || dt == LLMC_BF16 || dt == LLMC_F32; }

@@ -870,7 +870,7 @@ extern "C" int llmc_fp8_block_gemm(const void* A8, const float* a_s, const void*
         a.ntm = (int)ceil_div64(M, G2_T); a.ntn = (int)ceil_div64(N, G2_T);
         g2_tile_order(a, cus);
 #ifdef LLMC_LAB
-        a.abl = getenv("LLMC_FP8_ABL") ? atoi(getenv("LLMC_FP8_ABL")) : 0;
+        a.abl = lab_env("LLMC_FP8_ABL") ? atoi(lab_env("LLMC_FP8_ABL")) : 0;
 #endif
         const void* fn = out_dt == LLMC_F16 ? (const void*)k_fp8_block_gemm256<LLMC_F16>
                        : out_dt == LLMC_BF16 ? (const void*)k_fp8_block_gemm256<LLMC_BF16> : (const void*)k_fp8_block_gemm256<LLMC_F32>;

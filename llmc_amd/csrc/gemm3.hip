@@ -617,7 +617,7 @@ int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
     if (TA && gemm3s_eligible(a)) {
         dim3 sgrid((a.N + S_BN - 1) / S_BN, (a.M + S_BM - 1) / S_BM, a.batch);
 #ifdef LLMC_LAB
-        const char* dbg = getenv("LLMC_GEMM3S_DBG");
+        const char* dbg = lab_env("LLMC_GEMM3S_DBG");
         const int d = dbg ? atoi(dbg) : 0;
 #else
         const int d = 0;

@@ -693,7 +693,7 @@ static int syrk_plan(const int64_t* T_list, int n, int64_t K, int64_t ldx, int c
     const int real = p->nb * (p->nb + 1) / 2;
     int S = choose_chunks(real, G, G * GROUP_TOK * ldx * 2, 256, copies);
 #ifdef LLMC_LAB
-    if (const char* e = getenv("LLMC_SYRK_S")) S = atoi(e);   // lab: force the token-chunk count
+    if (const char* e = lab_env("LLMC_SYRK_S")) S = atoi(e);   // lab: force the token-chunk count
 #endif
     if (S > G / 2) S = (int)(G / 2);     // every chunk at least one group pair
     if (S < 1) S = 1;
@@ -766,8 +766,8 @@ static int syrk_launch(const SyrkArgs& a, int dt, hipStream_t st) {
     int abl = 0;
     SyrkArgs b = a;
 #ifdef LLMC_LAB
-    if (getenv("LLMC_SYRK_NOSYNC")) b.sync = nullptr;
-    if (const char* e = getenv("LLMC_SYRK_ABL")) abl = atoi(e);   // wrong results by design
+    if (lab_env("LLMC_SYRK_NOSYNC")) b.sync = nullptr;
+    if (const char* e = lab_env("LLMC_SYRK_ABL")) abl = atoi(e);   // wrong results by design
 #endif
     // persistent: one workgroup per CU (a multiple of 8 keeps XCDs contiguous), minus the CUs the caller keeps free for
     // kernels of other streams (llmc_hip_set_cu_reserve): a k_syrk4 workgroup owns its CU, nothing co-resides with it

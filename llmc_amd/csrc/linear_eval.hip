@@ -807,7 +807,7 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     a.y0_lds = mode == 1 && !yblk && R % 8 == 0 && ((uintptr_t)Y0 & 15) == 0 && N * R * 2 < (1ll << 32);
     int stage = mode == 1 ? (yblk ? 2 : a.y0_lds ? 1 : 0) : 0;
 #ifdef LLMC_LAB   // lab builds only (tools/probes): wrong losses by design, never compiled into the shipped library
-    if (const char* e = getenv("LLMC_LIN_ABL")) {
+    if (const char* e = lab_env("LLMC_LIN_ABL")) {
         const int v = atoi(e);
         if (v == 1) { a.mode = 2; a.y0_lds = 0; stage = 0; }      // main loop only
         if (v == 2 && stage == 1) { a.y0_lds = 0; stage = 0; }    // row-major Y0 straight from global

@@ -125,6 +125,23 @@ def test_hessian_down_proj_k14336():
     assert torch.equal(H, H.T)
 
 
+def test_hessian_down_proj_k14336_full_calibration_set():
+    """Exactly the bench launch for down_proj: 128 x 2048 tokens, K = 14336, bf16 — 7 GiB of activations, S = 4
+    token chunks of 65 536 tokens each, 1596 tiles; sampled tiles (diagonal ones included: their upper-right quadrant is the
+    mirrored one) vs fp64, and the whole diagonal at the fp32 rounding of the exact sum of squares."""
+    T, K, n_seq = 262144, 14336, 128
+    x = synth_x(T, K, torch.bfloat16, 7)
+    H = run_hessian(x, n_seq)
+    tiles = [(0, 0), (55, 55), (55, 0), (55, 54), (28, 27), (31, 4), (40, 40), (17, 16), (44, 9), (27, 27)]
+    check_tiles(H, x, n_seq, tiles)
+    assert torch.equal(H, H.T) and torch.isfinite(H).all()
+    d = torch.zeros(K, dtype=torch.float64, device='cuda')
+    for t in range(0, T, 16384):
+        d += (x[t:t + 16384].double() ** 2).sum(0)
+    d *= 2.0 / n_seq
+    assert float(((torch.diagonal(H).double() - d).abs() / d).max()) <= 1.2e-7
+
+
 def test_hessian_ragged_k_and_f16():
     T, K, n_seq = 65536, 5000, 32       # 5000 = 19 * 256 + 136: ragged last tile row / column
     x = synth_x(T, K, torch.float16, 3)

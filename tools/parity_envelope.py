@@ -69,6 +69,10 @@ def main():
     ap.add_argument('--tmp', default='/tmp/llmc_envelope')
     ap.add_argument('--full-down', action='store_true',
                     help='only down_proj 4096 x 14336 with the FULL 128 x 2048 calibration set (the configuration the metric is quoted on)')
+    ap.add_argument('--down-70b', action='store_true',
+                    help='only the Llama-3-70B down_proj 8192 x 28672 with the full 128 x 2048 calibration set (BASELINE configs[3]): the '
+                         'reference on this GPU (ROCm), llmc_amd, and its fp32-diagonal A/B arm (the host arm of the reference needs '
+                         '> 15 minutes here and is left out)')
     a = ap.parse_args()
     os.makedirs(a.tmp, exist_ok=True)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
@@ -86,6 +90,9 @@ def main():
     if a.full_down:
         shapes = [('down_proj 4096x14336, 128x2048 tokens (the bench configuration)', 4096, 14336, 128, 2048,
                    [('ref_cpu', 32), ('ref_rocm', 0), ('ours', 0), ('ours_fp32diag', 0)])]
+    if a.down_70b:
+        shapes = [('down_proj 8192x28672, 128x2048 tokens (Llama-3-70B, BASELINE configs[3])', 8192, 28672, 128, 2048,
+                   [('ref_rocm', 0), ('ours', 0), ('ours_fp32diag', 0)])]
     report = {'cores': cores, 'torch': torch.__version__, 'shapes': []}
     lines = []
     for si, (title, R, K, n_seq, seq, arms) in enumerate(shapes):
@@ -104,7 +111,7 @@ def main():
                 cmd += ['--threads', str(thr)]
             t0 = time.time()
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900 if a.full_down else 420)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500 if (a.full_down or a.down_70b) else 420)
             except subprocess.TimeoutExpired:
                 lines.append(f'[{title}] arm {key} TIMED OUT')
                 continue
