@@ -64,7 +64,8 @@ enum Opt : int {
     OPT_FP8_EXACT_DIV,      // FP8 cast through the IEEE division + general encoder
     OPT_SIDE_CU_MASK,       // helper streams created with a CU mask (read when a caller stream's helper set is first created)
     OPT_K1_BATCH_OFF,       // llmc_hessian_accum_multi as one launch per problem instead of one tile queue
-    OPT_K1_FP32_DIAG,       // keep the MFMA kernel's fp32 diagonal instead of the fp64-folded one
+    OPT_K1_FP32_DIAG,
+    OPT_GEMM3S_NO_DMA,      // k_gemm3s planes form: producers copy through registers + ds_write (round 5) instead of LDS-DMA       // keep the MFMA kernel's fp32 diagonal instead of the fp64-folded one
     OPT_COUNT
 };
 int opt(int id);

@@ -322,6 +322,118 @@ __global__ __launch_bounds__(512, 1) void k_gemm3s(SgemmArgs a) {
     G3S_STAMP(0);
     LDS_AS float* tile = (LDS_AS float*)lds;     // the epilogue's 256 x 128 fp32 image of the accumulators
 
+    if constexpr (PRE && DBG == 0) {
+      if (wv >= 4 && a.planes_dma) {
+        // ---------------- producer waves, planes form (round 6): the planes of step j go into buffer j & 1 by LDS-DMA
+        // (buffer_load_dwordx4 ... lds: 64 lanes x 16 B per instruction straight into LDS, no staging registers, no ds_write):
+        // 18 instructions per wave and K-step instead of 18 loads + 18 LDS writes per THREAD. The round-5 stamps
+        // (profiles/r05_gemm3s.txt) showed 7800 cycles before the first MFMA, a 5800-cycle stall at the third-last step (32 old-C
+        // loads per thread issued there) and 3750-4050 cycles per 3072-cycle K-step; here the first planes land after one
+        // DMA round trip, the old C values are requested four per K-step from the third step on (the staging registers that
+        // held plane data are free for them), and a K-step's copy work is 18 issue slots.
+        // A 1-KiB piece = two 512-B k-rows of an A plane (lanes 0-31 / 32-63) or four 256-B k-rows of a B plane (16 lanes each);
+        // the LDS image is lane-linear, the rows' 64-B-unit XOR swizzle (unit ^ (k & 3), what the fragment reads undo) is
+        // applied to the per-lane SOURCE column instead. Same planes, same LDS image, same MFMA order: the same bits.
+        const int pw = wv - 4;
+        auto mk = [](const void* p, uint32_t bytes) {     // from provably wave-uniform inputs
+            const uint64_t u = (uint64_t)p;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0,
+                                                     __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+        };
+        const uint16_t* pA = (const uint16_t*)a.planesA + (int64_t)z * a.sA;
+        const uint16_t* pB = (const uint16_t*)a.planesB + (int64_t)z * a.sB;
+        const auto dA = mk(pA + i0, (uint32_t)((2 * a.plane_stride + ((int64_t)(Kd - 1)) * a.ldp + min(S_BM, M - i0)) * 2));
+        const auto dB = mk(pB + j0, (uint32_t)((2 * a.plane_stride + ((int64_t)(Kd - 1)) * a.ldp + min(S_BN, N - j0)) * 2));
+        // A pieces of this wave are p = pw, pw + 4, ..: k = 2 p, so (k + r) & 3 = 2 (pw & 1) + r for the lane's row r
+        uint32_t voA, voB;
+        {
+            const int r = lane >> 5, c = lane & 31, k3 = 2 * (pw & 1) + r;
+            const int ca = (((c >> 2) ^ k3) << 2) | (c & 3);
+            voA = (uint32_t)(((int64_t)r * a.ldp + 8 * ca) * 2) | (i0 + 8 * ca < M ? 0u : 0x80000000u);
+        }
+        {
+            const int r = lane >> 4, c = lane & 15;
+            const int cb = (((c >> 2) ^ r) << 2) | (c & 3);
+            voB = (uint32_t)(((int64_t)r * a.ldp + 8 * cb) * 2) | (j0 + 8 * cb < N ? 0u : 0x80000000u);
+        }
+        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+        const uint32_t row2 = (uint32_t)(a.ldp * 2), ps2 = (uint32_t)(a.plane_stride * 2);
+        auto dma = [&](const decltype(dA)& d, uint32_t vo, uint32_t so, uint32_t dst) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                         :: "v"(vo), "s"(d), "s"(dst), "s"(so) : "memory");
+        };
+        auto issue = [&](int j) {
+            const uint32_t buf = lds0 + (uint32_t)(j & 1) * S_BUF;
+            const uint32_t k0 = (uint32_t)j * G3K;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {                 // A: piece index 4 t + pw = 16 plane + p
+                const int idx = 4 * t + pw, pl = idx >> 4, pp = idx & 15;
+                dma(dA, voA, (uint32_t)pl * ps2 + (k0 + 2u * pp) * row2, buf + (uint32_t)pl * S_APLANE + (uint32_t)pp * 1024u);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {                  // B: piece index 4 t + pw = 8 plane + q
+                const int idx = 4 * t + pw, pl = idx >> 3, q = idx & 7;
+                dma(dB, voB, (uint32_t)pl * ps2 + (k0 + 4u * q) * row2, buf + 3u * S_APLANE + (uint32_t)pl * S_BPLANE + (uint32_t)q * 1024u);
+            }
+        };
+        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        // the old C values: this thread's 32 quadruples (row (t >> 5) + 8 q, columns 4 (t & 31)), four per K-step from step 2 on
+        const int t = tid - 256;
+        const int c4 = 4 * (t & 31), r0 = t >> 5;
+        const int col = j0 + c4;
+        const auto dC = mk(C + (int64_t)i0 * a.ldc + j0, (uint32_t)((((int64_t)(min(S_BM, M - i0) - 1)) * a.ldc + min(S_BN, N - j0)) * 4));
+        const int row_lim = col >= N ? 0 : (a.c_upper_only ? min(M, (col & ~31) + 32) : M) - i0 - r0;
+        const uint32_t c_base = (uint32_t)(((int64_t)r0 * a.ldc + c4) * 4), c_step = (uint32_t)(a.ldc * 32);
+        auto c_off = [&](int q) { return (c_base + (uint32_t)q * c_step) | (8 * q < row_lim ? 0u : 0x80000000u); };
+        f32x4 old[32];
+        issue(0);
+        landed();
+        __syncthreads();                 // step 0 is in buffer 0
+        // nsteps is even and >= 4 (gemm3s_eligible). Straight-line loads (behind per-lane or per-step branches hipcc's vmcnt
+        // bookkeeping cannot count them): with ten or more steps (the far updates have 16) four per step behind steps 1 .. 8,
+        // otherwise all of them behind step 1.
+        int j = 1;
+        if (nsteps >= 10) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                issue(j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    old[4 * u + e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dC, c_off(4 * u + e), 0, 0));
+                landed();
+                __syncthreads();         // step j is in buffer j & 1; buffer (j - 1) & 1 is being read
+                ++j;
+            }
+        } else {
+            issue(j);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) old[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dC, c_off(q), 0, 0));
+            landed();
+            __syncthreads();
+            ++j;
+        }
+        for (; j < nsteps; ++j) {
+            issue(j);
+            landed();
+            __syncthreads();
+        }
+        __syncthreads();                 // (E1) the MFMA waves are done with the planes
+        __syncthreads();                 // (E2) the accumulators are in LDS
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const f32x4 v = *(LDS_AS f32x4*)(tile + (r0 + 8 * q) * S_BN + c4);
+            f32x4 w;
+            if (a.epilogue == SG_SUB) w = old[q] - v;
+            else if (a.epilogue == SG_SET) w = v;
+            else w = -v;
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w), dC, c_off(q), 0, 0);
+        }
+        return;
+      }
+    }
     if (wv >= 4) {
         // ---------------- producer waves: bring the planes of step j into buffer j & 1
         const int t = tid - 256;
@@ -615,6 +727,8 @@ int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
                  "gemm3: operands must be 16-B aligned with ld and sizes multiples of 4");
     LLMC_REQUIRE((const void*)a.C != (const void*)a.B && (const void*)a.C != (const void*)a.A, "gemm3: no in-place product");
     if (TA && gemm3s_eligible(a)) {
+        SgemmArgs b = a;
+        b.planes_dma = opt(OPT_GEMM3S_NO_DMA) ? 0 : 1;
         dim3 sgrid((a.N + S_BN - 1) / S_BN, (a.M + S_BM - 1) / S_BM, a.batch);
 #ifdef LLMC_LAB
         const char* dbg = lab_env("LLMC_GEMM3S_DBG");
@@ -623,7 +737,7 @@ int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
         const int d = 0;
 #endif
 #define LLMC_G3S(D, PRE) do { if (int rc = ensure_dynamic_lds((const void*)k_gemm3s<D, PRE>, S_LDS)) return rc; \
-                              hipLaunchKernelGGL((k_gemm3s<D, PRE>), sgrid, dim3(512), S_LDS, st, a); } while (0)
+                              hipLaunchKernelGGL((k_gemm3s<D, PRE>), sgrid, dim3(512), S_LDS, st, b); } while (0)
 #ifdef LLMC_LAB
         if (a.planesA) { if (d == 2) LLMC_G3S(2, true); else if (d == 4) LLMC_G3S(4, true); else LLMC_G3S(0, true); }
         else { if (d == 2) LLMC_G3S(2, false); else if (d == 4) LLMC_G3S(4, false); else LLMC_G3S(0, false); }

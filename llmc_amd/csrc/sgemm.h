@@ -37,6 +37,7 @@ struct SgemmArgs {
     const void* planesA;
     const void* planesB;
     int64_t ldp, plane_stride;
+    int planes_dma;   // set by gemm3_launch: the planes form's producers copy by LDS-DMA (0: through registers, option gemm3s_no_dma)
 };
 
 // launches on `st`; returns LLMC_* status
