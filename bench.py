@@ -364,7 +364,7 @@ def run_extras(args):
                 out[key] = {'error': (r.stderr or r.stdout)[-300:]}
                 continue
             j = json.loads(line[-1])
-            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline') if k in j}
+            out[key] = {k: j[k] for k in ('metric', 'value', 'value_with_auto_clip', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline') if k in j}
         except Exception as e:
             out[key] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
     return out

@@ -233,10 +233,10 @@ int llmc_hessian_accum_ptrs_reduce(float* H, const int64_t* T_list_host, int n, 
  *
  * Exact diagonal (always on; no extra pass over the samples): in a DIAGONAL 256 x 256 tile of the kernel the upper-right
  * quadrant is the transpose of the lower-left one, so the reduction mirrors that one and the quadrant's wave spends its
- * MFMAs on the eight 32 x 32 blocks ON the diagonal, restarting its accumulators every 128 tokens and folding each block's
- * diagonal into fp64. diag(H) — what actorder sorts (gptq.py:58-83) and the damping averages (gptq.py:169) — then carries
- * ~1e-8 of relative error before its one rounding to fp32, instead of the 2-3e-6 an fp32 chain over a whole token chunk
- * leaves (twice the reference's sgemm; rounds 1-5 offered a second fp64 pass over the samples for this). dstate [K] fp64 (may
+ * MFMAs on the eight 32 x 32 blocks ON the diagonal, restarting its accumulators every 2048 tokens (every 256 in short units)
+ * and folding each block's diagonal into fp64. diag(H) — what actorder sorts (gptq.py:58-83) and the damping averages
+ * (gptq.py:169) — then sits within 2e-7 of the exact value (an fp32 rounding is 6e-8), instead of the 2-3e-6 an fp32 chain over a
+ * whole token chunk leaves (twice the reference's sgemm; rounds 1-5 offered a second fp64 pass over the samples for this). dstate [K] fp64 (may
  * be NULL) carries the unrounded running diagonal across calls (overwritten when n_before == 0); without it H's own fp32
  * diagonal is the carried value. llmc_hip_set_option("k1_fp32_diag", 1) keeps the MFMA kernel's fp32 diagonal (A/B). */
 typedef struct {

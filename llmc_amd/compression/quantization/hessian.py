@@ -269,16 +269,16 @@ class HessianAccumulator:
         st = _ffi.stream()
         dtc = _ffi.dt(xs_list[0][0])
         wsp = ws.data_ptr() + ((-ws.data_ptr()) % 256)
-        if timing is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _ffi.check(L.llmc_hessian_accum_multi_partials(probs, P, dtc, wsp, st), 'llmc_hessian_accum_multi_partials')
-        if timing is not None:
-            e1.record()
         fp32_diag = [a for a in accs if not a.exact_diag]
         if fp32_diag and len(fp32_diag) != len(accs):
             raise ValueError('hessian: accumulators with and without exact_diag cannot share a launch')
-        with _ffi.option(k1_fp32_diag=1 if fp32_diag else 0):
+        with _ffi.option(k1_fp32_diag=1 if fp32_diag else 0):       # both calls of the pair see the same switch
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _ffi.check(L.llmc_hessian_accum_multi_partials(probs, P, dtc, wsp, st), 'llmc_hessian_accum_multi_partials')
+            if timing is not None:
+                e1.record()
             _ffi.check(L.llmc_hessian_accum_multi_reduce(probs, P, wsp, st), 'llmc_hessian_accum_multi_reduce')
         if timing is not None:
             e2 = torch.cuda.Event(enable_timing=True)

@@ -44,6 +44,7 @@ static constexpr int GROUP_TOK = 128;            // tokens per group = one turn 
 static constexpr int SYRK_MAX_SAMPLES = 512;     // table entries per launch, all problems together (8 KiB of kernel arguments)
 static constexpr int SYRK_MAX_CHUNKS = 32;
 static constexpr int SYRK_UNIT_SAMPLES = 64;     // samples one unit may cross (one per lane; the kernel clamps at 63)
+static constexpr int FOLD_GROUPS = 16;           // exact diagonal: the diagonal wave folds its accumulators into fp64 every 16 groups (2048 tokens)
 static constexpr int SYRK_MAX_PROBS = 4;         // Hessians (problems) one launch may carry in its unit queue
 
 struct TileIdx {
@@ -115,6 +116,8 @@ struct SyrkProb {
 struct SyrkArgs {
     int P;             // problems
     int nunits;        // units of all problems
+    int no_dwave;      // k1_fp32_diag: diagonal tiles are computed in full (rounds 1-5), no fp64 diagonal
+    int pad_;
     unsigned* sync;    // round barrier counter (zeroed before the launch), or null
     SyrkProb pr[SYRK_MAX_PROBS];
     SyrkSample smp[SYRK_MAX_SAMPLES];
@@ -259,11 +262,11 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
         const int i0 = (int)pr.ci[s];
         // Exact diagonal. In a DIAGONAL tile the upper-right 128 x 128 quadrant (wave wm = 0, wn = 1) is the transpose of the
         // lower-left one: k_syrk_fixup mirrors that one instead, and this wave spends its MFMAs on the eight 32 x 32 blocks ON
-        // the diagonal (A fragment x the same A fragment, B x the same B), restarting the accumulators every 256 tokens (a pair
-        // of groups) and folding each block's diagonal into fp64: diag(H) then carries the rounding of 16 chained MFMAs and an
-        // fp64 sum over the pairs (~1e-8 relative) instead of an fp32 chain over the whole chunk (2-3e-6, twice the
+        // the diagonal (A fragment x the same A fragment, B x the same B), restarting the accumulators every 2048 tokens (FOLD_GROUPS)
+        // and folding each block's diagonal into fp64: diag(H) then carries the rounding of 128 chained MFMAs and an
+        // fp64 sum over the folds (~2e-8 relative) instead of an fp32 chain over the whole chunk (2-3e-6, twice the
         // reference's sgemm) — diag(H) is what GPTQ's actorder sorts and what the damping averages (gptq.py:63, 169).
-        const bool dwave = t.bi == t.bj && wv == 1;
+        const bool dwave = !a.no_dwave && t.bi == t.bj && wv == 1;
 
         // lane table: descriptor words of sample i0 + lane as this unit sees it (file header, "sample table")
         int v0, v1, v2, vend;
@@ -379,8 +382,8 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             // of slot RSL into (na, nb) (all eight are back six MFMAs before the burst ends); i in {3,7,11,15} ->
             // LDS-DMA piece D0 + i/4 of slot DSL (one KiB per wave every four MFMAs = 32 B/clk per CU, evenly spread);
             // i in {10,12,13,14} -> `extra(i)`: scalar bookkeeping that must not cost an issue slot of its own
-            // DW (the diagonal wave of a diagonal tile): 0 = the 4x4 block walk, 1 = the eight blocks on the diagonal, 2 = the same
-            // with fresh accumulators (first burst of a 128-token group). The diagonal blocks take slots whose operand is already
+            // DW (the diagonal wave of a diagonal tile): 0 = the 4x4 block walk, 1 = the eight blocks on the diagonal. The diagonal
+            // blocks take slots whose operand is already
             // in registers in the walk's fragment order: 0..3 -> fb[i] x fb[i], 4 -> fa[1], 5 -> fa[0], 8 -> fa[2], 12 -> fa[3];
             // every slot keeps its fragment read / DMA piece (the wave still stages its share of the tile).
             auto burst = [&](auto dwc, const s16x8 (&fa)[4], const s16x8 (&fb)[4], s16x8 (&na)[4], s16x8 (&nb)[4], auto rslc, int rd_kk,
@@ -394,12 +397,11 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                     if constexpr (DW == 0) {
                         acc[mi][ni] = Mfma<DT>::run(fa[mi], fb[ni], acc[mi][ni]);
                     } else {
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        if constexpr (i < 4) acc[0][i] = Mfma<DT>::run(fb[i], fb[i], DW == 2 ? zero : acc[0][i]);
-                        else if constexpr (i == 4) acc[1][0] = Mfma<DT>::run(fa[1], fa[1], DW == 2 ? zero : acc[1][0]);
-                        else if constexpr (i == 5) acc[1][1] = Mfma<DT>::run(fa[0], fa[0], DW == 2 ? zero : acc[1][1]);
-                        else if constexpr (i == 8) acc[2][0] = Mfma<DT>::run(fa[2], fa[2], DW == 2 ? zero : acc[2][0]);
-                        else if constexpr (i == 12) acc[3][0] = Mfma<DT>::run(fa[3], fa[3], DW == 2 ? zero : acc[3][0]);
+                        if constexpr (i < 4) acc[0][i] = Mfma<DT>::run(fb[i], fb[i], acc[0][i]);
+                        else if constexpr (i == 4) acc[1][0] = Mfma<DT>::run(fa[1], fa[1], acc[1][0]);
+                        else if constexpr (i == 5) acc[1][1] = Mfma<DT>::run(fa[0], fa[0], acc[1][1]);
+                        else if constexpr (i == 8) acc[2][0] = Mfma<DT>::run(fa[2], fa[2], acc[2][0]);
+                        else if constexpr (i == 12) acc[3][0] = Mfma<DT>::run(fa[3], fa[3], acc[3][0]);
                     }
                     if constexpr ((i & 3) == 3) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{}, rs);
                     else if constexpr (i < 10) frag(rslc, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
@@ -411,14 +413,13 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             // one group (ring turn) g: `cur` = descriptor of group g, `nxt` = of group g + 1; `cur` is rebuilt for group
             // g + 2 behind the second burst of the group's first stage
             auto group = [&](auto dwg, i32x4& cur, const i32x4& nxt, int g) {
-                constexpr int DWG = decltype(dwg)::value;               // 0: the block walk; diagonal wave: 1 = first group of a pair
-                //                                                         (fresh accumulators), 2 = second (folded into fp64 at its end)
+                constexpr int DWG = decltype(dwg)::value;               // 0: the block walk, 1: the diagonal wave (see burst)
                 static_for<0, NSLOT>([&](auto jc) {
                     constexpr int J = decltype(jc)::value;              // stage st = g*NSLOT + J sits in slot J
                     constexpr int JN = (J + 1) % NSLOT;                 // slot of stage st+1
                     constexpr int JP = (J + NSLOT - 1) % NSLOT;         // slot of stage st+NSLOT-1 (= st-1)
-                    constexpr auto dw1 = std::integral_constant<int, DWG ? 1 : 0>{};
-                    constexpr auto dw0 = std::integral_constant<int, (DWG == 1 && J == 0) ? 2 : (DWG ? 1 : 0)>{};   // a pair starts from zero
+                    constexpr auto dw1 = std::integral_constant<int, DWG>{};
+                    constexpr auto dw0 = dw1;
                     // slice 0 of stage st; fetches slice 1; requests the B half of stage st+NSLOT-1 (J = 0: the last
                     // stage of this group, otherwise a stage of the next group)
                     burst(dw0, fa0, fb0, fa1, fb1, jc, 1, std::integral_constant<int, JP>{}, std::integral_constant<int, 4>{},
@@ -453,49 +454,60 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                               nothing);
                     }
                 });
-                if constexpr (DWG == 2) {
-                    // the pair's eight block diagonals into fp64 (the accumulators restart from zero with the next pair's first
-                    // burst). Lane l of a 32x32 accumulator holds column j = l & 31 and rows 8 q + 4 (l >> 5) + r in register
-                    // 4 q + r: element (j, j) sits in register k = (j & 3) + 4 (j >> 3) of lane j + 32 ((j >> 2) & 1) — every
-                    // register carries the diagonal in exactly two lanes, so sixteen accumulator reads under a two-lane EXEC
-                    // mask each collect the block's diagonal into one VGPR (no per-lane select chain, no mask registers).
-                    // s_nop: an MFMA result must be 11+ wait states old before a VALU reads it (invisible to the compiler in asm).
-                    auto dg = [&](const f32x16& c) -> float {
-                        float t = 0.0f;
-                        uint64_t save;
-                        asm volatile(
-                            "s_nop 15\n\ts_mov_b64 %[sv], exec\n\t"
-                            "s_mov_b32 exec_lo, 0x00000001\n\ts_mov_b32 exec_hi, 0x00000010\n\tv_accvgpr_read_b32 %[t], %[c0]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000002\n\ts_mov_b32 exec_hi, 0x00000020\n\tv_accvgpr_read_b32 %[t], %[c1]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000004\n\ts_mov_b32 exec_hi, 0x00000040\n\tv_accvgpr_read_b32 %[t], %[c2]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000008\n\ts_mov_b32 exec_hi, 0x00000080\n\tv_accvgpr_read_b32 %[t], %[c3]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000100\n\ts_mov_b32 exec_hi, 0x00001000\n\tv_accvgpr_read_b32 %[t], %[c4]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000200\n\ts_mov_b32 exec_hi, 0x00002000\n\tv_accvgpr_read_b32 %[t], %[c5]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000400\n\ts_mov_b32 exec_hi, 0x00004000\n\tv_accvgpr_read_b32 %[t], %[c6]\n\t"
-                            "s_mov_b32 exec_lo, 0x00000800\n\ts_mov_b32 exec_hi, 0x00008000\n\tv_accvgpr_read_b32 %[t], %[c7]\n\t"
-                            "s_mov_b32 exec_lo, 0x00010000\n\ts_mov_b32 exec_hi, 0x00100000\n\tv_accvgpr_read_b32 %[t], %[c8]\n\t"
-                            "s_mov_b32 exec_lo, 0x00020000\n\ts_mov_b32 exec_hi, 0x00200000\n\tv_accvgpr_read_b32 %[t], %[c9]\n\t"
-                            "s_mov_b32 exec_lo, 0x00040000\n\ts_mov_b32 exec_hi, 0x00400000\n\tv_accvgpr_read_b32 %[t], %[c10]\n\t"
-                            "s_mov_b32 exec_lo, 0x00080000\n\ts_mov_b32 exec_hi, 0x00800000\n\tv_accvgpr_read_b32 %[t], %[c11]\n\t"
-                            "s_mov_b32 exec_lo, 0x01000000\n\ts_mov_b32 exec_hi, 0x10000000\n\tv_accvgpr_read_b32 %[t], %[c12]\n\t"
-                            "s_mov_b32 exec_lo, 0x02000000\n\ts_mov_b32 exec_hi, 0x20000000\n\tv_accvgpr_read_b32 %[t], %[c13]\n\t"
-                            "s_mov_b32 exec_lo, 0x04000000\n\ts_mov_b32 exec_hi, 0x40000000\n\tv_accvgpr_read_b32 %[t], %[c14]\n\t"
-                            "s_mov_b32 exec_lo, 0x08000000\n\ts_mov_b32 exec_hi, 0x80000000\n\tv_accvgpr_read_b32 %[t], %[c15]\n\t"
-                            "s_mov_b64 exec, %[sv]"
-                            : [t] "+v"(t), [sv] "=&s"(save)
-                            : [c0] "a"(c[0]), [c1] "a"(c[1]), [c2] "a"(c[2]), [c3] "a"(c[3]), [c4] "a"(c[4]), [c5] "a"(c[5]),
-                              [c6] "a"(c[6]), [c7] "a"(c[7]), [c8] "a"(c[8]), [c9] "a"(c[9]), [c10] "a"(c[10]), [c11] "a"(c[11]),
-                              [c12] "a"(c[12]), [c13] "a"(c[13]), [c14] "a"(c[14]), [c15] "a"(c[15]));
-                        return t;
-                    };
-                    dsum[0] += (double)dg(acc[0][0]);
-                    dsum[1] += (double)dg(acc[0][1]);
-                    dsum[2] += (double)dg(acc[0][2]);
-                    dsum[3] += (double)dg(acc[0][3]);
-                    dsum[4] += (double)dg(acc[1][0]);
-                    dsum[5] += (double)dg(acc[1][1]);
-                    dsum[6] += (double)dg(acc[2][0]);
-                    dsum[7] += (double)dg(acc[3][0]);
+            };
+            // The diagonal wave's eight block diagonals into fp64, every FOLD_GROUPS groups (2048 tokens: 128 chained MFMAs per
+            // block between folds — their fp32 rounding, ~2e-7, averages down over the folds of a chunk and the chunks of a
+            // launch; the final fp32 rounding of diag(H) dominates). Then the eight accumulators restart from zero. A fold is
+            // ~2000 cycles of this wave's time: per group it must stay well inside the slack its halved MFMA load leaves, or
+            // every round (whose barrier waits for its slowest unit) pays for it — folding every pair of groups cost 3 ms per
+            // bench step (profiles/r06_k1_ab.txt).
+            auto fold = [&]() {
+                    // Lane l of a 32x32 accumulator holds column j = l & 31 and rows 8 q + 4 (l >> 5) + r in register
+                // 4 q + r: element (j, j) sits in register k = (j & 3) + 4 (j >> 3) of lane j + 32 ((j >> 2) & 1) — every
+                // register carries the diagonal in exactly two lanes, so sixteen accumulator reads under a two-lane EXEC
+                // mask each collect the block's diagonal into one VGPR (no per-lane select chain, no mask registers).
+                // s_nop: an MFMA result must be 11+ wait states old before a VALU reads it (invisible to the compiler in asm).
+                auto dg = [&](const f32x16& c) -> float {
+                    float t = 0.0f;
+                    uint64_t save;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "s_mov_b32 exec_lo, 0x00000001\n\ts_mov_b32 exec_hi, 0x00000010\n\tv_accvgpr_read_b32 %[t], %[c0]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000002\n\ts_mov_b32 exec_hi, 0x00000020\n\tv_accvgpr_read_b32 %[t], %[c1]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000004\n\ts_mov_b32 exec_hi, 0x00000040\n\tv_accvgpr_read_b32 %[t], %[c2]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000008\n\ts_mov_b32 exec_hi, 0x00000080\n\tv_accvgpr_read_b32 %[t], %[c3]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000100\n\ts_mov_b32 exec_hi, 0x00001000\n\tv_accvgpr_read_b32 %[t], %[c4]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000200\n\ts_mov_b32 exec_hi, 0x00002000\n\tv_accvgpr_read_b32 %[t], %[c5]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000400\n\ts_mov_b32 exec_hi, 0x00004000\n\tv_accvgpr_read_b32 %[t], %[c6]\n\t"
+                        "s_mov_b32 exec_lo, 0x00000800\n\ts_mov_b32 exec_hi, 0x00008000\n\tv_accvgpr_read_b32 %[t], %[c7]\n\t"
+                        "s_mov_b32 exec_lo, 0x00010000\n\ts_mov_b32 exec_hi, 0x00100000\n\tv_accvgpr_read_b32 %[t], %[c8]\n\t"
+                        "s_mov_b32 exec_lo, 0x00020000\n\ts_mov_b32 exec_hi, 0x00200000\n\tv_accvgpr_read_b32 %[t], %[c9]\n\t"
+                        "s_mov_b32 exec_lo, 0x00040000\n\ts_mov_b32 exec_hi, 0x00400000\n\tv_accvgpr_read_b32 %[t], %[c10]\n\t"
+                        "s_mov_b32 exec_lo, 0x00080000\n\ts_mov_b32 exec_hi, 0x00800000\n\tv_accvgpr_read_b32 %[t], %[c11]\n\t"
+                        "s_mov_b32 exec_lo, 0x01000000\n\ts_mov_b32 exec_hi, 0x10000000\n\tv_accvgpr_read_b32 %[t], %[c12]\n\t"
+                        "s_mov_b32 exec_lo, 0x02000000\n\ts_mov_b32 exec_hi, 0x20000000\n\tv_accvgpr_read_b32 %[t], %[c13]\n\t"
+                        "s_mov_b32 exec_lo, 0x04000000\n\ts_mov_b32 exec_hi, 0x40000000\n\tv_accvgpr_read_b32 %[t], %[c14]\n\t"
+                        "s_mov_b32 exec_lo, 0x08000000\n\ts_mov_b32 exec_hi, 0x80000000\n\tv_accvgpr_read_b32 %[t], %[c15]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [t] "+v"(t), [sv] "=&s"(save)
+                        : [c0] "a"(c[0]), [c1] "a"(c[1]), [c2] "a"(c[2]), [c3] "a"(c[3]), [c4] "a"(c[4]), [c5] "a"(c[5]),
+                          [c6] "a"(c[6]), [c7] "a"(c[7]), [c8] "a"(c[8]), [c9] "a"(c[9]), [c10] "a"(c[10]), [c11] "a"(c[11]),
+                          [c12] "a"(c[12]), [c13] "a"(c[13]), [c14] "a"(c[14]), [c15] "a"(c[15]));
+                    return t;
+                };
+                asm volatile("s_nop 15" ::: "memory");      // the last MFMA of the burst is at most a few instructions old
+                dsum[0] += (double)dg(acc[0][0]);
+                dsum[1] += (double)dg(acc[0][1]);
+                dsum[2] += (double)dg(acc[0][2]);
+                dsum[3] += (double)dg(acc[0][3]);
+                dsum[4] += (double)dg(acc[1][0]);
+                dsum[5] += (double)dg(acc[1][1]);
+                dsum[6] += (double)dg(acc[2][0]);
+                dsum[7] += (double)dg(acc[3][0]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[0][0][r] = 0.0f; acc[0][1][r] = 0.0f; acc[0][2][r] = 0.0f; acc[0][3][r] = 0.0f;
+                    acc[1][0][r] = 0.0f; acc[1][1][r] = 0.0f; acc[2][0][r] = 0.0f; acc[3][0][r] = 0.0f;
                 }
             };
             // prologue: stages 0 .. NSLOT-2 and the A half of stage NSLOT-1 (all of group 0) requested, stage 0 published
@@ -506,9 +518,12 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
             static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, 0, fc, fa0, fb0); });
             // groups in pairs (the descriptor sets swap roles); an odd chunk gets one padding group of zeros
             if (dwave) {
+                // long units fold every FOLD_GROUPS groups; short ones (small calibration sets: few folds to average over) every pair
+                const int fmask = ngroups >= 8 * FOLD_GROUPS ? FOLD_GROUPS - 1 : 1;
                 for (int g = 0; g < ngroups; g += 2) {
                     group(std::integral_constant<int, 1>{}, dA, dB, g);
-                    group(std::integral_constant<int, 2>{}, dB, dA, g + 1);
+                    group(std::integral_constant<int, 1>{}, dB, dA, g + 1);
+                    if (((g + 2) & fmask) == 0 || g + 2 >= ngroups) fold();
                 }
             } else {
                 for (int g = 0; g < ngroups; g += 2) {
@@ -569,7 +584,7 @@ struct FixupProb {
 };
 struct FixupArgs {
     FixupProb pr[SYRK_MAX_PROBS];
-    int skip_diag;
+    int exact;         // 1: diagonal tiles carry no upper-right quadrant (mirrored here) and diag(H) is left to k_diag_apply
 };
 
 __global__ __launch_bounds__(256) void k_syrk_fixup(const FixupArgs fa) {
@@ -585,7 +600,7 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const FixupArgs fa) {
     const int m = (idx >> 9) & 3;
     const int wv = idx >> 11;
     const int wm = wv >> 2, wn = wv & 3;
-    const bool dtile = t.bi == t.bj;
+    const bool dtile = fa.exact && t.bi == t.bj;
     if (dtile && wm == 0 && wn >= 2) return;         // mirrored from the lower-left quadrant below
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < a.S; ++s) {
@@ -606,10 +621,10 @@ __global__ __launch_bounds__(256) void k_syrk_fixup(const FixupArgs fa) {
             float h = a.beta * sum[r];
             if (a.alpha != 0.0f) h += a.alpha * H[(int64_t)i * K + j];
             o[r] = h;
-            if (!(fa.skip_diag && i == j)) H[(int64_t)i * K + j] = h;
+            if (!(fa.exact && i == j)) H[(int64_t)i * K + j] = h;
         }
     }
-    if (!dtile || (wm == 1 && wn < 2)) {
+    if (t.bi != t.bj || (dtile && wm == 1 && wn < 2)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (i0 + r < K) H[(int64_t)j * K + i0 + r] = o[r];
@@ -746,6 +761,8 @@ static int syrk_plan_multi(const llmc_hessian_problem_t* probs, int P, void* ws,
     }
     a->P = P;
     a->nunits = unit0;
+    a->no_dwave = opt(OPT_K1_FP32_DIAG) ? 1 : 0;
+    a->pad_ = 0;
     a->sync = ws ? (unsigned*)((char*)ws + off) : nullptr;
     off += 256;
     if (total) *total = off;
@@ -832,7 +849,8 @@ extern "C" int llmc_hessian_accum_multi_partials(const llmc_hessian_problem_t* p
 }
 
 // The ordered reduction of every problem's partial tiles into its H (running mean weights from n_before / n_after) and the
-// exact diagonal (k_diag_apply). k1_fp32_diag (llmc_hip_set_option): keep the MFMA kernel's own fp32 diagonal instead.
+// exact diagonal (k_diag_apply). k1_fp32_diag (llmc_hip_set_option, set for BOTH calls of a pair): the kernel of rounds 1-5 —
+// diagonal tiles computed in full, the fp32 chain's own diagonal — for A/B.
 extern "C" int llmc_hessian_accum_multi_reduce(const llmc_hessian_problem_t* probs_host, int P, const void* ws, llmc_stream_t stream) {
     LLMC_REQUIRE(ws, "hessian_accum_reduce: null workspace");
     SyrkArgs a;
@@ -856,7 +874,7 @@ extern "C" int llmc_hessian_accum_multi_reduce(const llmc_hessian_problem_t* pro
         if (p.ntiles_p > max_tiles) max_tiles = p.ntiles_p;
         if (p.K > max_k) max_k = p.K;
     }
-    f.skip_diag = exact ? 1 : 0;
+    f.exact = exact ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_syrk_fixup, dim3(TILE_FLOATS / 4 / 256, max_tiles, P), dim3(256), 0, st, f);
     LLMC_LAUNCH_CHECK();

@@ -139,7 +139,9 @@ def test_hessian_down_proj_k14336_full_calibration_set():
     for t in range(0, T, 16384):
         d += (x[t:t + 16384].double() ** 2).sum(0)
     d *= 2.0 / n_seq
-    assert float(((torch.diagonal(H).double() - d).abs() / d).max()) <= 1.2e-7
+    # an fp32 rounding of the exact value is 6e-8; the fp32 chains of 128 MFMAs between the fp64 folds add ~1e-7 (the fp32 chain over a
+    # whole chunk left 3.2e-6 here, the reference's own sgemm 1.2-1.7e-6)
+    assert float(((torch.diagonal(H).double() - d).abs() / d).max()) <= 3e-7
 
 
 def test_hessian_ragged_k_and_f16():

@@ -145,6 +145,8 @@ def run_awq(args):
             'metric': 'layers/sec (AWQ W4A16 g128 scale search + fake-quant eval, %s Linear shapes, 128x512 calib)' % args.model,
             'value': n_layers * args.steps * world / dt, 'unit': 'layers/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            # the shipped awq_w_only.yml also enables weight_clip: the same block with AutoClipper's search after the scale search
+            'value_with_auto_clip': (n_layers * world / (dt / args.steps + clip_ms * 1e-3)) if clip_ms else None,
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'AWQ W4A16 g128 sym, trans v2, 20-point scale search with inspect = the Linear layers, '
