@@ -258,6 +258,13 @@ static constexpr int S_AROW = S_BM * 2, S_BROW = S_BN * 2;                 // by
 static constexpr int S_APLANE = G3K * S_AROW, S_BPLANE = G3K * S_BROW;     // 16 KiB, 8 KiB
 static constexpr int S_BUF = 3 * S_APLANE + 3 * S_BPLANE;                  // 72 KiB
 static constexpr int S_LDS = 2 * S_BUF;
+// LDS-DMA form of the planes kernel (round 6): a ring of FOUR 16-k slots instead of two 32-k buffers, so that a slot's copies are
+// requested three steps before its MFMAs (a DMA round trip is longer than one step's MFMAs)
+static constexpr int R_K = 16;
+static constexpr int R_APLANE = R_K * S_AROW, R_BPLANE = R_K * S_BROW;       // 8 KiB, 4 KiB
+static constexpr int R_SLOT = 3 * R_APLANE + 3 * R_BPLANE;                    // 36 KiB
+static constexpr int R_SLOTS = 4;
+static_assert(R_SLOTS * R_SLOT == S_LDS, "the ring takes the two buffers' LDS");
 
 template <int ROW>
 __device__ __forceinline__ s16x8 tr_frag_row(LDS_AS char* p, int imm0) {
@@ -364,22 +371,22 @@ __global__ __launch_bounds__(512, 1) void k_gemm3s(SgemmArgs a) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
                          :: "v"(vo), "s"(d), "s"(dst), "s"(so) : "memory");
         };
+        const int rsteps = Kd / R_K;                      // 16-k ring steps (Kd % 64 == 0, >= 128: an even number >= 8)
         auto issue = [&](int j) {
-            const uint32_t buf = lds0 + (uint32_t)(j & 1) * S_BUF;
-            const uint32_t k0 = (uint32_t)j * G3K;
+            const uint32_t slot = lds0 + (uint32_t)(j & (R_SLOTS - 1)) * R_SLOT;
+            const uint32_t k0 = (uint32_t)j * R_K;
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {                 // A: piece index 4 t + pw = 16 plane + p
-                const int idx = 4 * t + pw, pl = idx >> 4, pp = idx & 15;
-                dma(dA, voA, (uint32_t)pl * ps2 + (k0 + 2u * pp) * row2, buf + (uint32_t)pl * S_APLANE + (uint32_t)pp * 1024u);
+            for (int t = 0; t < 6; ++t) {                  // A: piece index 4 t + pw = 8 plane + p (two k-rows each)
+                const int idx = 4 * t + pw, pl = idx >> 3, pp = idx & 7;
+                dma(dA, voA, (uint32_t)pl * ps2 + (k0 + 2u * pp) * row2, slot + (uint32_t)pl * R_APLANE + (uint32_t)pp * 1024u);
             }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {                  // B: piece index 4 t + pw = 8 plane + q
-                const int idx = 4 * t + pw, pl = idx >> 3, q = idx & 7;
-                dma(dB, voB, (uint32_t)pl * ps2 + (k0 + 4u * q) * row2, buf + 3u * S_APLANE + (uint32_t)pl * S_BPLANE + (uint32_t)q * 1024u);
+            for (int t = 0; t < 3; ++t) {                  // B: piece index 4 t + pw = 4 plane + q (four k-rows each)
+                const int idx = 4 * t + pw, pl = idx >> 2, q = idx & 3;
+                dma(dB, voB, (uint32_t)pl * ps2 + (k0 + 4u * q) * row2, slot + 3u * R_APLANE + (uint32_t)pl * R_BPLANE + (uint32_t)q * 1024u);
             }
         };
-        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-        // the old C values: this thread's 32 quadruples (row (t >> 5) + 8 q, columns 4 (t & 31)), four per K-step from step 2 on
+        // the old C values: this thread's 32 quadruples (row (t >> 5) + 8 q, columns 4 (t & 31)), four per step behind steps 0 .. 7
         const int t = tid - 256;
         const int c4 = 4 * (t & 31), r0 = t >> 5;
         const int col = j0 + c4;
@@ -389,34 +396,37 @@ __global__ __launch_bounds__(512, 1) void k_gemm3s(SgemmArgs a) {
         auto c_off = [&](int q) { return (c_base + (uint32_t)q * c_step) | (8 * q < row_lim ? 0u : 0x80000000u); };
         f32x4 old[32];
         issue(0);
-        landed();
-        __syncthreads();                 // step 0 is in buffer 0
-        // nsteps is even and >= 4 (gemm3s_eligible). Straight-line loads (behind per-lane or per-step branches hipcc's vmcnt
-        // bookkeeping cannot count them): with ten or more steps (the far updates have 16) four per step behind steps 1 .. 8,
-        // otherwise all of them behind step 1.
-        int j = 1;
-        if (nsteps >= 10) {
+        issue(1);
+        issue(2);
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // step 0's nine pieces of this wave have landed (18 younger ones may fly)
+        __syncthreads();                 // step 0 is in its slot
+        // Loop body j: the MFMA waves work on step j; slot (j + 3) & 3 = (j - 1) & 3 was read in step j - 1, which every MFMA wave
+        // had finished at the barrier before: request step j + 3 into it, wait for step j + 1, publish it. The counted waits
+        // ignore the C loads mixed in (they only make a wait stricter). Straight-line C loads (behind per-lane or per-step
+        // branches hipcc's vmcnt bookkeeping cannot count them): the first eight bodies are peeled (rsteps >= 8).
+        int j = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                issue(j);
+        for (int u = 0; u < 8; ++u) {
+            if (j + 3 < rsteps) issue(j + 3);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    old[4 * u + e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dC, c_off(4 * u + e), 0, 0));
-                landed();
-                __syncthreads();         // step j is in buffer j & 1; buffer (j - 1) & 1 is being read
-                ++j;
+            for (int e = 0; e < 4; ++e)
+                old[4 * u + e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dC, c_off(4 * u + e), 0, 0));
+            if (j + 1 < rsteps) {
+                if (j + 3 < rsteps) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");        // younger than step j + 1: steps j + 2, j + 3 (18) and the C loads of three bodies (12)
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-        } else {
-            issue(j);
-#pragma unroll
-            for (int q = 0; q < 32; ++q) old[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dC, c_off(q), 0, 0));
-            landed();
-            __syncthreads();
             ++j;
         }
-        for (; j < nsteps; ++j) {
-            issue(j);
-            landed();
+        for (; j + 1 < rsteps; ++j) {
+            if (j + 3 < rsteps) {
+                issue(j + 3);
+                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            } else if (j + 2 < rsteps) {
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();
         }
         __syncthreads();                 // (E1) the MFMA waves are done with the planes
@@ -628,6 +638,80 @@ __global__ __launch_bounds__(512, 1) void k_gemm3s(SgemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
     __syncthreads();                 // step 0 is in buffer 0
+    if constexpr (DBG == 0) {
+        // Round 6: the fragment reads of an accumulator row are issued one row AHEAD of its MFMAs (A fragments double-buffered per
+        // row, B fragments per 16-k slice: 72 fragment registers as before plus 36), every phase pinned by a scheduling barrier.
+        // The compiler's own schedule read a row's fragments and then waited for them in front of its MFMAs — 3750-4050 cycles
+        // per 3072-cycle K-step in the round-5 stamps. Per accumulator the six products keep k_gemm3's order: the same bits.
+        // TWO accumulator rows at a time: the six products of an accumulator are a dependent chain (k_gemm3's order is kept, so
+        // the bits are), and with only the row's two accumulators alternating every MFMA waited ~12 cycles for the one two
+        // places before it (3750-4050 cycles per 3072-cycle K-step in the round-5 stamps); four accumulators in rotation hide it.
+        auto ldP = [&](s16x8 (&f)[2][3], LDS_AS char* bA, int aplane, int m0, int imm) {     // A fragments of rows m0, m0 + 1
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) f[r][t] = tr_frag_row<S_AROW>(bA + t * aplane + offA[m0 + r], imm);
+        };
+        auto ldB = [&](s16x8 (&f)[2][3], LDS_AS char* bB, int bplane, int imm) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) f[n][t] = tr_frag_row<S_BROW>(bB + t * bplane + offB[n], imm);
+        };
+        auto pair = [&](auto mc, const s16x8 (&fa)[2][3], const s16x8 (&fb)[2][3]) {
+            constexpr int m = decltype(mc)::value;
+            f32x16 c00 = acc[m][0], c01 = acc[m][1], c10 = acc[m + 1][0], c11 = acc[m + 1][1];
+#define LLMC_G3_PROD(TA, TB)                                      \
+            c00 = Mfma<LLMC_BF16>::run(fa[0][TA], fb[0][TB], c00);    \
+            c01 = Mfma<LLMC_BF16>::run(fa[0][TA], fb[1][TB], c01);    \
+            c10 = Mfma<LLMC_BF16>::run(fa[1][TA], fb[0][TB], c10);    \
+            c11 = Mfma<LLMC_BF16>::run(fa[1][TA], fb[1][TB], c11);
+            LLMC_G3_PROD(2, 0)   // lo  * hi   (k_gemm3's order per accumulator)
+            LLMC_G3_PROD(0, 2)   // hi  * lo
+            LLMC_G3_PROD(1, 1)   // mid * mid
+            LLMC_G3_PROD(1, 0)   // mid * hi
+            LLMC_G3_PROD(0, 1)   // hi  * mid
+            LLMC_G3_PROD(0, 0)   // hi  * hi
+#undef LLMC_G3_PROD
+            acc[m][0] = c00; acc[m][1] = c01; acc[m + 1][0] = c10; acc[m + 1][1] = c11;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 2> P2{};
+        s16x8 fb[2][3], faP[2][3], faQ[2][3];
+        if (PRE && a.planes_dma) {
+            // the LDS-DMA producers' ring: 16-k steps in four slots (see R_K)
+            const int rsteps = Kd / R_K;
+            for (int s = 0; s < rsteps; ++s) {
+                LDS_AS char* bufA = lds + (s & (R_SLOTS - 1)) * R_SLOT;
+                LDS_AS char* bufB = bufA + 3 * R_APLANE;
+                ldB(fb, bufB, R_BPLANE, 0);
+                ldP(faP, bufA, R_APLANE, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldP(faQ, bufA, R_APLANE, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                pair(P0, faP, fb);
+                pair(P2, faQ, fb);
+                if (s + 1 < rsteps) __syncthreads();   // step s + 1 is in its slot; slot s & 3 may be refilled
+            }
+        } else {
+            for (int s = 0; s < nsteps; ++s) {
+                LDS_AS char* bufA = lds + (s & 1) * S_BUF;
+                LDS_AS char* bufB = bufA + 3 * S_APLANE;
+#pragma unroll
+                for (int kk = 0; kk < G3K / 16; ++kk) {
+                    ldB(fb, bufB, S_BPLANE, kk * 16 * S_BROW);
+                    ldP(faP, bufA, S_APLANE, 0, kk * 16 * S_AROW);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldP(faQ, bufA, S_APLANE, 2, kk * 16 * S_AROW);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pair(P0, faP, fb);
+                    pair(P2, faQ, fb);
+                }
+                if (s + 1 < nsteps) __syncthreads();   // buffer (s + 1) & 1 is written, buffer s & 1 is free again
+            }
+        }
+    } else
     for (int s = 0; s < nsteps; ++s) {
         G3S_STAMP(1 + 4 * s);
         LDS_AS char* bufA = lds + (s & 1) * S_BUF;
