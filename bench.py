@@ -52,23 +52,24 @@ def block_groups(model):
 
 def parity_envelope_summary(args):
     """End-to-end agreement with the reference on the configuration the metric is quoted on, from the committed measurement
-    (tools/parity_envelope.py --full-down on an MI355X: the reference's own GPTQ class on the host cores / on ROCm / llmc_amd on
-    identical weights and the full 128 x 2048 calibration set, down_proj 4096 x 14336). `parity_live` of the same line is what THIS
-    run measured itself."""
-    if args.model != 'llama3-8b':
-        return None
+    (tools/parity_envelope.py --full-down / --down-70b on an MI355X: the reference's own GPTQ class on the host cores [8B only] /
+    on ROCm / llmc_amd on identical weights and the full 128 x 2048 calibration set, the model's down_proj). `parity_live` of
+    the same line is what THIS run measured itself."""
+    src = {'llama3-8b': PARITY_FILE, 'llama3-70b': PARITY_FILE.replace('full_down', 'down_70b')}.get(args.model)
     try:
-        j = json.load(open(os.path.join(ROOT, PARITY_FILE)))
+        j = json.load(open(os.path.join(ROOT, src)))
         pr = j['shapes'][0]['pairs']['w_only' if args.variant == 'w_only' else 'vllm']
         pick = lambda m: {k: m[k] for k in ('codes_equal', 'scales_within_1e-4', 'scales_within_1e-2', 'zeros_equal', 'perm_equal',
                                             'perm_diff_within_4x_noise', 'H_diag_rel_max') if k in m}
         ours = 'ours' if args.exact_diag else 'ours_fp32diag'
-        return {'layer': j['shapes'][0]['title'], 'source': PARITY_FILE,
-                'precomputed': 'read from the committed file (tools/parity_envelope.py --full-down on an MI355X, round 6)',
-                'arm': ours + (' (the default: diag(H) folded into fp64 inside the Hessian kernel)' if args.exact_diag else
-                               ' (--exact-diag 0: the fp32 chain\'s own diagonal, rounds 1-5\'s default)'),
-                'ours_vs_reference_cpu': pick(pr['ref_cpu_32t vs ' + ours]),
-                'reference_cpu_vs_reference_rocm': pick(pr['ref_cpu_32t vs ref_rocm'])}
+        out = {'layer': j['shapes'][0]['title'], 'source': src, 'precomputed': 'read from the committed file (round 6)',
+               'arm': ours + (' (default: diag(H) folded into fp64 inside the Hessian kernel)' if args.exact_diag else ' (--exact-diag 0)')}
+        for ref in ('ref_cpu_32t', 'ref_rocm'):
+            if f'{ref} vs {ours}' in pr:
+                out[f'ours_vs_{ref}'] = pick(pr[f'{ref} vs {ours}'])
+        if 'ref_cpu_32t vs ref_rocm' in pr:
+            out['reference_cpu_vs_reference_rocm'] = pick(pr['ref_cpu_32t vs ref_rocm'])
+        return out
     except Exception:       # noqa: BLE001
         return None
 
