@@ -87,6 +87,7 @@ int llmc_hip_set_cu_reserve(int n_cus);
  *   side_cu_mask      helper streams created with a CU mask (read when a caller stream's helper set is first created)
  *   k1_batch_off      llmc_hessian_accum_multi as one launch per problem instead of one tile queue; same bits
  *   k1_fp32_diag      diag(H) as the MFMA kernel's fp32 chain leaves it instead of the fp64-folded one (other diagonal)
+ *   fp8_no_packed16   FP8 e4m3 cast of bf16 tensors (qtorch rounding, codes out): the float form of the division-free path; same bits
  *   gemm3s_no_dma     k_gemm3s (planes form): producer waves copy through registers instead of LDS-DMA; same bits
  * set: returns the previous value, or LLMC_EINVAL for an unknown key / negative value. get: the value, or LLMC_EINVAL.
  * option_name: the key of index 0, 1, ... (copied into buf), LLMC_EINVAL past the last one. No reference counterpart. */
