@@ -260,7 +260,9 @@ class GPTQ(BaseBlockwiseQuantization):
         if not getattr(self, 'true_sequential', False) and _world() == 1:
             # one block forward has fed every subset's accumulator: the Hessians of one width (q|k|v, o and gate|up of a Llama
             # block) are formed by ONE launch (HessianAccumulator.flush_many) instead of one launch per subset
-            HessianAccumulator.flush_many([g['acc'] for g in self._groups.values()])
+            flush_many = getattr(HessianAccumulator, 'flush_many', None)
+            if flush_many is not None:
+                flush_many([g['acc'] for g in self._groups.values()])
         super().block_transform(block, input_feat, block_kwargs)
 
     def _transform_owq(self, gid, layers, names):

@@ -40,7 +40,7 @@ for job in "$@"; do
       timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras $arg > $O/ks.log 2>&1
       F=$(ls $O/ks/*/*kernel_trace.csv $O/ks/*kernel_trace.csv 2>/dev/null | head -1)
       if [ "$kind" = stats ]; then python tools/kernel_stats_csv.py $F > $O/kernel_stats_$n.txt 2>&1; head -14 $O/kernel_stats_$n.txt
-      else python tools/step_timeline.py $F > $O/step_timeline_$n.txt 2>&1; head -30 $O/step_timeline_$n.txt; fi
+      else python tools/step_timeline.py $F --step -2 > $O/step_timeline_$n.txt 2>&1; head -30 $O/step_timeline_$n.txt; fi
       rm -rf $O/ks ;;
     pmc) bash tools/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1; cp $O/pmc/pmc_traffic.json $O/ 2>/dev/null; tail -30 $O/pmc.log; rm -rf $O/pmc/f $O/pmc/w ;;
     py) timeout 1500 python $arg > $O/py_$n.txt 2>&1; echo "py rc=$? [$arg]"; tail -25 $O/py_$n.txt ;;
