@@ -455,7 +455,12 @@ int llmc_fp8_block_dequant(const void* W8, const float* scales, int64_t M, int64
 int llmc_fp8_act_quant(const void* X, int dt, int64_t n_elem, int block, void* out8, float* scales, llmc_stream_t stream);
 /* fp8_gemm + block_wise_fp8_forward_func (kernel.py:146-242; module_utils.py:40-45): A8 [M, K] e4m3 with a_s [M, K/128],
  * B8 [N, K] e4m3 (a weight) with b_s [N/128, K/128]; C [M, N] out_dt = sum over 128-deep K blocks of
- * (A_kb . B_kb^T) * a_s * b_s, fp32 accumulation on the fp8 MFMA; bias [N] (out_dt) is added after the rounding. */
+ * (A_kb . B_kb^T) * a_s * b_s, fp32 accumulation on the fp8 MFMA; bias [N] (out_dt) is added after the rounding.
+ * The K-block update is the reference Triton kernel's, acc = fma(part * a_s, b_s, acc): bit-identical outputs, two VALU ops per
+ * element and K block, which bound the kernel at 0.31-0.37 of the fp8 MFMA peak. out_dt | LLMC_FP8_GEMM_FUSED_SCALE (opt-in, for
+ * callers that do not need bit-identity with the Triton kernel): acc = fma(part, fl(a_s * b_s), acc), one op — the same value up
+ * to one fp32 rounding of the scale product per row and K block (the 256 x 256-tile kernel only; the small-shape kernel ignores it). */
+#define LLMC_FP8_GEMM_FUSED_SCALE 0x100
 int llmc_fp8_block_gemm(const void* A8, const float* a_s, const void* B8, const float* b_s, int64_t M, int64_t N,
                         int64_t K, int out_dt, const void* bias, void* C, llmc_stream_t stream);
 

@@ -46,8 +46,10 @@ def weight_cast_to_bf16(x, s, block_size=128, dtype=torch.bfloat16):
     return y
 
 
-def fp8_gemm(a, a_s, b, b_s, dtype=torch.bfloat16, bias=None):
-    """kernel.py:213-242: c[..., N] = sum over 128-deep K blocks (a_blk . b_blk^T) * a_s * b_s."""
+def fp8_gemm(a, a_s, b, b_s, dtype=torch.bfloat16, bias=None, fused_scale=False):
+    """kernel.py:213-242: c[..., N] = sum over 128-deep K blocks (a_blk . b_blk^T) * a_s * b_s.
+    fused_scale (not a reference argument; default False = bit-identical to the reference's Triton kernel): the K-block update as
+    ONE fma with the scale product rounded once (LLMC_FP8_GEMM_FUSED_SCALE) — faster, within an fp32 rounding per K block."""
     _ffi.require_gpu(a, a_s, b, b_s, bias)
     assert a.is_contiguous() and b.is_contiguous(), 'Input tensors must be contiguous'
     assert a_s.is_contiguous() and b_s.is_contiguous(), 'Scaling factor tensors must be contiguous'
@@ -59,7 +61,7 @@ def fp8_gemm(a, a_s, b, b_s, dtype=torch.bfloat16, bias=None):
     if bias is not None:
         bias = bias.to(dtype).contiguous()
     _ffi.check(L.llmc_fp8_block_gemm(_ffi.ptr(a.view(torch.uint8)), _ffi.ptr(a_s), _ffi.ptr(b.view(torch.uint8)),
-                                     _ffi.ptr(b_s), M, N, K, _ffi.dt(dtype), _ffi.ptr(bias), _ffi.ptr(c), _ffi.stream()),
+                                     _ffi.ptr(b_s), M, N, K, _ffi.dt(dtype) | (0x100 if fused_scale else 0), _ffi.ptr(bias), _ffi.ptr(c), _ffi.stream()),
                'llmc_fp8_block_gemm')
     return c
 

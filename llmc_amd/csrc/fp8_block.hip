@@ -406,6 +406,8 @@ struct Fp8GemmArgs {
     int64_t M, N, K;
     const void* bias; void* C;
     int ntm, ntn, sbm, sbn, nsn, nrounds;
+    int fused;    // LLMC_FP8_GEMM_FUSED_SCALE: acc = fma(part, a_s * b_s, acc) — one VALU op per element and K block instead of the
+                  // reference kernel's two (other rounding of the scale product: not bit-identical to the Triton kernel)
 #ifdef LLMC_LAB
     int abl;      // tools/probes/fp8_gemm_lab.hip: 1 no accumulator update, 2 no DMA after a tile's first stage, 4 no MFMA, 16 / 32 update
                   // variants, 64 no barrier in the K loop, 128 no fragment reads after a tile's first
@@ -429,7 +431,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void g2_for(F&& f
     }
 }
 
-template <int DT>
+template <int DT, bool FUSED = false>     // FUSED: LLMC_FP8_GEMM_FUSED_SCALE (a template parameter: as a run-time branch it spilled 102 registers)
 __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char g2_smem[];
     LDS_AS char* lds = (LDS_AS char*)g2_smem;
@@ -576,7 +578,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                 // and the sum contract into one fma); scalar fp32 ops: packed ones cost twice the issue time
 #ifdef LLMC_LAB
                 if (a.abl & 1) return;
-                if (a.abl & 16) {        // one op per element (not the reference's rounding)
+#endif
+                if constexpr (FUSED) {   // opt-in: one op per element (the scale product rounded once per row and K block)
                     const float sc = as_cur[j] * bs;
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
@@ -585,6 +588,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_fp8_block_gemm256(Fp8GemmArgs a)
                                  "+v"(acc[i][j][4]), "+v"(acc[i][j][5]), "+v"(acc[i][j][6]), "+v"(acc[i][j][7]));
                     return;
                 }
+#ifdef LLMC_LAB
                 if (a.abl & 32) {        // the same op count, not reading the MFMA results
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
@@ -858,6 +862,8 @@ extern "C" int llmc_fp8_act_quant(const void* X, int dt, int64_t n_elem, int blo
 extern "C" int llmc_fp8_block_gemm(const void* A8, const float* a_s, const void* B8, const float* b_s, int64_t M,
                                    int64_t N, int64_t K, int out_dt, const void* bias, void* C, llmc_stream_t stream) {
     LLMC_REQUIRE(A8 && a_s && B8 && b_s && C && M > 0 && N > 0 && K > 0, "fp8_block_gemm: null/empty argument");
+    const int fused = (out_dt & LLMC_FP8_GEMM_FUSED_SCALE) ? 1 : 0;
+    out_dt &= ~LLMC_FP8_GEMM_FUSED_SCALE;
     LLMC_REQUIRE(out_dt == LLMC_F16 || out_dt == LLMC_BF16 || out_dt == LLMC_F32, "fp8_block_gemm: bad output dtype");
     hipStream_t st = (hipStream_t)stream;
     const int cus = device_cu_count() & ~7;
@@ -869,11 +875,13 @@ extern "C" int llmc_fp8_block_gemm(const void* A8, const float* a_s, const void*
         a.M = M; a.N = N; a.K = K; a.bias = bias; a.C = C;
         a.ntm = (int)ceil_div64(M, G2_T); a.ntn = (int)ceil_div64(N, G2_T);
         g2_tile_order(a, cus);
+        a.fused = fused;
 #ifdef LLMC_LAB
         a.abl = lab_env("LLMC_FP8_ABL") ? atoi(lab_env("LLMC_FP8_ABL")) : 0;
 #endif
-        const void* fn = out_dt == LLMC_F16 ? (const void*)k_fp8_block_gemm256<LLMC_F16>
-                       : out_dt == LLMC_BF16 ? (const void*)k_fp8_block_gemm256<LLMC_BF16> : (const void*)k_fp8_block_gemm256<LLMC_F32>;
+        const void* fn = out_dt == LLMC_F16 ? (fused ? (const void*)k_fp8_block_gemm256<LLMC_F16, true> : (const void*)k_fp8_block_gemm256<LLMC_F16>)
+                       : out_dt == LLMC_BF16 ? (fused ? (const void*)k_fp8_block_gemm256<LLMC_BF16, true> : (const void*)k_fp8_block_gemm256<LLMC_BF16>)
+                                             : (fused ? (const void*)k_fp8_block_gemm256<LLMC_F32, true> : (const void*)k_fp8_block_gemm256<LLMC_F32>);
         if (int rc = ensure_dynamic_lds(fn, G2_LDS)) return rc;
         void* kargs[] = {(void*)&a};
         LLMC_HIP_CHECK(hipLaunchKernel(fn, dim3(cus), dim3(G2_THREADS), kargs, (size_t)G2_LDS, st));

@@ -130,6 +130,13 @@ def test_fp8_block_gemm_k64_kernel(shape, dtype, with_bias):
     if with_bias:
         tol = tol + eps * np.abs(ref)          # the product is rounded to the output dtype before the bias is added
     assert (err <= tol).all(), (float((err - tol).max()), np.unravel_index(np.argmax(err - tol), err.shape))
+    # the opt-in one-fma update (fused_scale: the scale product rounded once per row and K block) stays inside the same envelope and
+    # within a few fp32 roundings per K block of the bit-identical form
+    f = KN.fp8_gemm(a8, a_s, w8, w_s, dtype=dtype, bias=bias, fused_scale=True)
+    errf = (f.cpu().double() - want.double()).abs().numpy()
+    assert (errf <= tol).all(), float((errf - tol).max())
+    if dtype == torch.float32 and not with_bias:
+        assert float((f - c).abs().max()) <= 4e-7 * (K // 128) * float(c.abs().max())
 
 
 def test_llmc_fp8_linear_forward():

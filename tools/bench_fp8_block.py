@@ -33,10 +33,14 @@ def main():
         w8, w_s = KN.weight_cast_to_fp8(w, 128)
         t_d = timed(lambda: KN.weight_cast_to_bf16(w8, w_s, 128))
         t_g = timed(lambda: KN.fp8_gemm(a8, a_s, w8, w_s))
+        t_f = timed(lambda: KN.fp8_gemm(a8, a_s, w8, w_s, fused_scale=True))
+        ref, fus = KN.fp8_gemm(a8, a_s, w8, w_s, dtype=torch.float32), KN.fp8_gemm(a8, a_s, w8, w_s, dtype=torch.float32, fused_scale=True)
+        dev = float((ref - fus).abs().max() / ref.abs().max())
         fl = 2.0 * M * N * K
         print(f'M={M} N={N} K={K}: act_quant {t_a*1e6:.0f} us = {3.0*M*K/t_a/1e12:.2f} TB/s (2MK read + MK write) | '
               f'weight_cast_to_fp8 {t_w*1e6:.0f} us = {3.0*N*K/t_w/1e12:.2f} TB/s | weight_cast_to_bf16 {t_d*1e6:.0f} us = {3.0*N*K/t_d/1e12:.2f} TB/s | fp8_gemm {t_g*1e3:.2f} ms = '
-              f'{fl/t_g/1e12:.0f} TFLOP/s = {fl/t_g/5e15:.3f} of the 5 PF fp8 MFMA peak', flush=True)
+              f'{fl/t_g/1e12:.0f} TFLOP/s = {fl/t_g/5e15:.3f} of the 5 PF fp8 MFMA peak | fused_scale=True {t_f*1e3:.2f} ms = {fl/t_f/1e12:.0f} TFLOP/s = '
+              f'{fl/t_f/5e15:.3f} (max |difference| to the bit-identical form / max |output|, fp32 output: {dev:.1e})', flush=True)
 
 
 if __name__ == '__main__':
