@@ -83,9 +83,8 @@ def parse_args(argv=None):
     ap.add_argument('--n-seq', type=int, default=128)
     ap.add_argument('--seq-len', type=int, default=2048)
     ap.add_argument('--calib-bs', type=int, default=1,
-                    help='sequences per add_batch call (reference calib.bs). 1 (default) = the reference config\'s calling pattern '
-                         '(gptq_w_only.yml:12): 128 hook calls of [1, seq, K] per input, each its own allocation, walked by ONE kernel '
-                         'launch through the sample table; n_seq = one call on one tensor')
+                    help='sequences per add_batch call (reference calib.bs; 1 = gptq_w_only.yml:12: 128 hook calls of [1, seq, K] per input, '
+                         'each its own allocation, walked by ONE launch through the sample table; n_seq = one call on one tensor)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
     ap.add_argument('--variant', default='w_only', choices=['w_only', 'vllm'],
                     help='w_only: asym g128 actorder dynamic groups (configs/quantization/methods/GPTQ/gptq_w_only.yml); '
@@ -93,15 +92,12 @@ def parse_args(argv=None):
     ap.add_argument('--workload', default='gptq', choices=['gptq', 'awq', 'fp8'])
     ap.add_argument('--mode', default=None, choices=['independent', 'handoff', 'cooperative'])
     ap.add_argument('--exact-diag', type=int, default=1, help='0: keep the MFMA kernel\'s fp32 diagonal of H (A/B; rounds 1-5\'s default)')
-    ap.add_argument('--merge-k1', type=int, default=1,
-                    help='1 (default): the Hessians of one width (three K = 4096 inputs) in ONE launch (one unit queue); 0: one launch each')
+    ap.add_argument('--merge-k1', type=int, default=1, help='0: one Hessian launch per input instead of one per width')
     ap.add_argument('--overlap', type=int, default=4,
                     help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); 0 = serial')
     ap.add_argument('--dry', action='store_true', help='GPU-less plumbing check (gloo + CPU stand-ins)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true',
-                    help='skip the secondary workloads reported under "extra" (N = 1 only): AWQ (configs[2]), the INT4-packing GPTQ '
-                         'variant, Llama-3-70B shapes (configs[3]), FP8 on Mixtral shapes (configs[4])')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary workloads reported under "extra" (N = 1 only)')
     return ap.parse_args(argv)
 
 
@@ -575,21 +571,30 @@ def main():
             torch.cuda.empty_cache()
 
     def try_steps(mode, n_warm, n_timed):
-        """A few steps of `mode` behind a try / except and an agreement over the control group: (layers/s | None, error | None).
-        An RCCL failure on one rank cannot hang the others' line."""
-        ok, val, err, ctx2 = 1, None, None, None
+        """A few steps of `mode` behind try / except: (layers/s | None, error | None). The ranks meet ONLY in control-group
+        reductions that every rank reaches whether or not its phase raised (no barrier inside a try: a rank that failed never
+        leaves its peers waiting in one — ADVICE r03), and skip the timed phase together if the warm-up failed anywhere."""
+        ok, val, err, ctx2 = 1, 0.0, None, None
+
+        def phase(n):
+            nonlocal ok, err
+            try:
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    step2(False)
+                ops.sync()
+                return time.perf_counter() - t1
+            except Exception as e:      # noqa: BLE001
+                ok, err = 0, err or f'{type(e).__name__}: {str(e)[:200]}'
+                return 0.0
         try:
             step2, ctx2 = prepare(mode)
-            for _ in range(n_warm):
-                step2(False)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(n_timed):
-                step2(False)
-            barrier()
-            val = time.perf_counter() - t1
-        except Exception as e:      # noqa: BLE001
+        except Exception as e:          # noqa: BLE001
             ok, err = 0, f'{type(e).__name__}: {str(e)[:200]}'
+        if ctl_reduce(ok, torch.distributed.ReduceOp.MIN):
+            phase(n_warm)
+        if ctl_reduce(ok, torch.distributed.ReduceOp.MIN):
+            val = phase(n_timed)
         ok = ctl_reduce(ok, torch.distributed.ReduceOp.MIN)
         try:
             if ctx2 is not None:
