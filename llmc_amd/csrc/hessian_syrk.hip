@@ -266,7 +266,19 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
         // and folding each block's diagonal into fp64: diag(H) then carries the rounding of 128 chained MFMAs and an
         // fp64 sum over the folds (~2e-8 relative) instead of an fp32 chain over the whole chunk (2-3e-6, twice the
         // reference's sgemm) — diag(H) is what GPTQ's actorder sorts and what the damping averages (gptq.py:63, 169).
-        const bool dwave = !a.no_dwave && t.bi == t.bj && wv == 1;
+        const bool dex = !a.no_dwave && t.bi == t.bj;
+        const bool dwave = dex && wv == 1;
+        // In such a tile the B panel would be a copy of the A panel: EVERY wave reads its B fragments from the A panel instead
+        // (offBu), the B pieces of the three walking waves carry an out-of-range offset (no memory access, zeros into a panel
+        // nobody reads) and the diagonal wave does not issue its B pieces at all — half of its LDS-DMA issue slots, which is
+        // what pays for its folds: with all of a wave's pieces and fragment reads its instruction stream takes as long as the
+        // other waves' MFMA stream, and a round's barrier waits for its slowest unit (profiles/r06_k1_ab.txt). (Moving the
+        // diagonal wave's A pieces to a walking wave as well bought nothing more: measured, gpurun_out/r06v.)
+        int offBu[NPAIR][4];
+#pragma unroll
+        for (int pr_ = 0; pr_ < NPAIR; ++pr_)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) offBu[pr_][m] = offB[pr_][m] - (dex ? S4_PANEL : 0);
 
         // lane table: descriptor words of sample i0 + lane as this unit sees it (file header, "sample table")
         int v0, v1, v2, vend;
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
         asm volatile("s_nop 4" : "+s"(dA[0]), "+s"(dA[1]), "+s"(dA[2]), "+s"(dB[0]), "+s"(dB[1]), "+s"(dB[2]));
         // a diagonal tile loads its panel into both LDS panels (vB == vA): the loop below never branches
         const uint32_t vA = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bi * TM + ch_off) * 2);
-        const uint32_t vB = (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
+        const uint32_t vB = dex ? 0x80000000u : (uint32_t)((int64_t)row_lo * row_bytes + ((int64_t)t.bj * TM + ch_off) * 2);
 
         double dsum[8];
 #pragma unroll
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                 if constexpr (RD) {
                     constexpr int IMM = (SL & 1) * S4_STAGE;
                     if constexpr (f == 0) fa[0] = tr_frag(lds + offA[SL >> 1][0], IMM + kk * 16 * TM * 2);
-                    else if constexpr (f <= 4) fb[f - 1] = tr_frag(lds + offB[SL >> 1][f - 1], IMM + kk * 16 * TM * 2);
+                    else if constexpr (f <= 4) fb[f - 1] = tr_frag(lds + offBu[SL >> 1][f - 1], IMM + kk * 16 * TM * 2);
                     else fa[f - 4] = tr_frag(lds + offA[SL >> 1][f - 4], IMM + kk * 16 * TM * 2);
                 }
             };
@@ -403,7 +415,9 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                         else if constexpr (i == 8) acc[2][0] = Mfma<DT>::run(fa[2], fa[2], acc[2][0]);
                         else if constexpr (i == 12) acc[3][0] = Mfma<DT>::run(fa[3], fa[3], acc[3][0]);
                     }
-                    if constexpr ((i & 3) == 3) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{}, rs);
+                    if constexpr ((i & 3) == 3) {
+                        if constexpr (!(DW != 0 && D0 == 4)) piece(dslc, std::integral_constant<int, D0 + (i >> 2)>{}, rs);   // the diagonal wave: no B pieces
+                    }
                     else if constexpr (i < 10) frag(rslc, rd_kk, std::integral_constant<int, i - (i >> 2)>{}, na, nb);
                     else extra(ic);
                     __builtin_amdgcn_sched_barrier(0);
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                           J == 0 ? cur : nxt, nothing);
                     // this wave's pieces of stage st+1 have landed (NSLOT-2 later stages may still be in flight);
                     // every wave has read the whole of stage st once its lgkmcnt(0) is behind the barrier
-                    dma_wait_upto<(NSLOT - 2) * PER>();
+                    dma_wait_upto<(NSLOT - 2) * (DWG ? PER / 2 : PER)>();
                     lds_wait_all();
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -511,9 +525,14 @@ __global__ __launch_bounds__(S4_THREADS) void k_syrk4(const SyrkArgs a) {
                 }
             };
             // prologue: stages 0 .. NSLOT-2 and the A half of stage NSLOT-1 (all of group 0) requested, stage 0 published
-            static_for<0, NSLOT - 1>([&](auto slc) { static_for<0, 8>([&](auto dc) { piece(slc, dc, dA); }); });
-            static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, NSLOT - 1>{}, dc, dA); });
-            dma_wait_upto<(NSLOT - 2) * PER + PER / 2>();
+            if (dwave) {      // A halves only (see offBu)
+                static_for<0, NSLOT>([&](auto slc) { static_for<0, 4>([&](auto dc) { piece(slc, dc, dA); }); });
+                dma_wait_upto<(NSLOT - 2) * (PER / 2) + PER / 2>();
+            } else {
+                static_for<0, NSLOT - 1>([&](auto slc) { static_for<0, 8>([&](auto dc) { piece(slc, dc, dA); }); });
+                static_for<0, 4>([&](auto dc) { piece(std::integral_constant<int, NSLOT - 1>{}, dc, dA); });
+                dma_wait_upto<(NSLOT - 2) * PER + PER / 2>();
+            }
             __builtin_amdgcn_s_barrier();
             static_for<0, 8>([&](auto fc) { frag(std::integral_constant<int, 0>{}, 0, fc, fa0, fb0); });
             // groups in pairs (the descriptor sets swap roles); an odd chunk gets one padding group of zeros
