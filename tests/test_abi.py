@@ -82,3 +82,61 @@ def test_a_stale_library_is_refused(monkeypatch):
         _ffi.lib()
     monkeypatch.setenv('LLMC_SKIP_BUILD_ID_CHECK', '1')
     assert _ffi.lib() is not None
+
+
+def test_options_are_explicit_per_thread_switches_not_environment_variables():
+    """llmc_hip_set_option / get_option / option_name (round 6): every A/B switch of the library is a named per-thread option, 0 by
+    default; unknown keys are refused; the sources read no environment variable outside -DLLMC_LAB builds."""
+    import glob
+    import threading
+
+    import pytest
+
+    from llmc_amd import _ffi
+    keys = _ffi.library_options()
+    assert len(keys) >= 14 and len(set(keys)) == len(keys) and 'k3_no_planes' in keys and 'k1_fp32_diag' in keys
+    assert all(_ffi.get_option(k) == 0 for k in keys)
+    with _ffi.option(k3_no_planes=1, gemm3s_min_tiles=7, awq_kt=0):
+        assert _ffi.get_option('k3_no_planes') == 1 and _ffi.get_option('gemm3s_min_tiles') == 7 and _ffi.HOST_OPTIONS['awq_kt'] == 0
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(_ffi.get_option('k3_no_planes')))      # another thread: its own defaults
+        t.start()
+        t.join()
+        assert seen == [0]
+    assert _ffi.get_option('k3_no_planes') == 0 and _ffi.HOST_OPTIONS['awq_kt'] == 1
+    with pytest.raises(ValueError):
+        _ffi.set_option('no_such_switch', 1)
+    assert _ffi.lib().llmc_hip_set_option(b'k3_fp32', -1) == -22
+    n = 0
+    for f in glob.glob(os.path.join(ROOT, 'llmc_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'llmc_amd', 'csrc', '*.h')):
+        n += open(f).read().count('getenv(')
+    assert n == 1          # the lab_env() helper of -DLLMC_LAB builds (common.h)
+
+
+def test_hessian_multi_problem_plan_is_a_pure_host_call():
+    """llmc_hessian_accum_multi_ws_bytes: up to llmc_hessian_max_problems() Hessians and llmc_hessian_max_samples() samples per call;
+    the workspace holds every problem's partial tiles + fp64 diagonal partials; bad calls return 0 without touching a GPU."""
+    import ctypes as C
+
+    from llmc_amd import _ffi
+    L = _ffi.lib()
+    assert L.llmc_hessian_max_problems() == 4 and L.llmc_hessian_max_samples() == 512
+
+    def problems(P, n, T, K):
+        arr = (_ffi.HessianProblem * P)()
+        keep = []
+        for i in range(P):
+            Ts = (C.c_int64 * n)(*([T] * n))
+            keep.append(Ts)
+            arr[i].T_list_host, arr[i].n, arr[i].K, arr[i].ldx = C.cast(Ts, C.c_void_p), n, K, K
+            arr[i].n_before, arr[i].n_after = 0.0, float(n)
+        return arr, keep
+    one, k1 = problems(1, 128, 2048, 4096)
+    three, k3 = problems(3, 128, 2048, 4096)
+    b1, b3 = L.llmc_hessian_accum_multi_ws_bytes(one, 1), L.llmc_hessian_accum_multi_ws_bytes(three, 3)
+    tile = 256 * 256 * 4
+    assert b1 > 9 * 136 * tile and b3 > 3 * 9 * 136 * tile          # >= 9 token chunks of 136 (padded: 144) tiles per problem
+    assert L.llmc_hessian_accum_multi_ws_bytes(three, 5) == 0       # more problems than a launch takes
+    many, km = problems(4, 129, 2048, 4096)                          # 516 samples > 512
+    assert L.llmc_hessian_accum_multi_ws_bytes(many, 4) == 0
+    assert L.llmc_hessian_accum_ptrs_ws_bytes(k1[0], 128, 4096, 4096) == b1
