@@ -261,7 +261,7 @@ class HipOps:
         """items: [(name, K, x)] -> {name: H}. merge: inputs of one width share ONE launch (HessianAccumulator.flush_many)."""
         accs = [self.feed(n, K, x, calib_bs) for n, K, x in items]
         if merge:
-            self.Acc.flush_many(accs)
+            self.Acc.flush_many(accs, mix_widths=merge > 1)
         return {n: a.H for (n, _, _), a in zip(items, accs)}
 
     def static_qparams(self, weights):
@@ -467,7 +467,7 @@ def main():
             the four subsets' factorisations and column loops, independent latency-bound chains, on one stream each, widest
             first, the library's internal helper streams off (measured schedules: profiles/NOTES.md, r05_schedule_experiments.txt)."""
             ops.timing = timing if record else None
-            Hs = ops.hessians([(name, K, acts[name]) for name, K, _ in groups], args.calib_bs, merge=bool(args.merge_k1))
+            Hs = ops.hessians([(name, K, acts[name]) for name, K, _ in groups], args.calib_bs, merge=args.merge_k1)
             if args.overlap <= 1 or args.dry:
                 return [ops.quantize(name, weights[name], Hs[name]) for name, _, _ in groups]
             cur = torch.cuda.current_stream()

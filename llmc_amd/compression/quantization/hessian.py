@@ -163,12 +163,13 @@ class HessianAccumulator:
             first = False
 
     @staticmethod
-    def flush_many(accs):
+    def flush_many(accs, mix_widths=False):
         """Flush several accumulators together: those whose pending samples form ONE launch each (one dtype, one row stride —
         the hook calls of a block forward) share launches of up to llmc_hessian_max_problems() Hessians of the same width
         (llmc_hessian_accum_multi_*: one unit queue, the triangular tails fill rounds together — the three K = 4096 inputs
         of a Llama block); everything else is flushed on its own. The token-chunk count of a launch is chosen for the problems that
-        share it, so against one-by-one launches the fp32 sums are formed in another order (summation-order noise, <= 1e-6)."""
+        share it, so against one-by-one launches the fp32 sums are formed in another order (summation-order noise, <= 1e-6).
+        mix_widths: Hessians of different widths share a launch too (measured: profiles/r06_k1_ab.txt)."""
         L = _ffi.lib()
         pmax, nmax = L.llmc_hessian_max_problems(), L.llmc_hessian_max_samples()
         singles, seen = {}, set()
@@ -179,7 +180,7 @@ class HessianAccumulator:
             groups, b_total = a._take_pending()
             if len(groups) == 1 and len(groups[0]) <= nmax // 2:
                 xs = groups[0]
-                singles.setdefault((a.K, xs[0].dtype, xs[0].device), []).append((a, xs, b_total))
+                singles.setdefault((None if mix_widths else a.K, xs[0].dtype, xs[0].device), []).append((a, xs, b_total))
                 continue
             # not one launch: put it back the simple way
             if not groups:
@@ -191,6 +192,7 @@ class HessianAccumulator:
                 a._launch(xs, b_total if first else 0)
                 first = False
         for items in singles.values():
+            items.sort(key=lambda it: -it[0].K)      # mix_widths: the widest first, so that the last round holds the shortest units
             batch, nsmp = [], 0
             for it in items + [None]:
                 if it is None or len(batch) == pmax or nsmp + len(it[1]) > nmax:

@@ -351,3 +351,27 @@ def test_several_hessians_in_one_launch(K, lens):
         ref.add(xs[0])
         d = torch.sqrt(torch.outer(torch.diagonal(ref.H), torch.diagonal(ref.H)))
         assert float(((a.H - ref.H).abs() / d).max()) < 2e-6
+
+
+def test_hessians_of_different_widths_in_one_launch():
+    """flush_many(..., mix_widths=True): problems of different K share one unit queue (the widest first); each H equals its
+    one-by-one result up to the chunking's summation order, the diagonal at the fp32 rounding of the exact value."""
+    from llmc_amd.compression.quantization.hessian import HessianAccumulator
+    gen = torch.Generator(device='cuda').manual_seed(77)
+    shapes = [(768, [2048, 2048, 1000]), (1280, [2048] * 4), (768, [512, 2048]), (256, [4096])]
+    sets = [[(torch.randn(1, t, K, generator=gen, device='cuda') * (1 + i)).to(torch.bfloat16) for t in lens] for i, (K, lens) in enumerate(shapes)]
+    accs = [HessianAccumulator(K, 'cuda') for K, _ in shapes]
+    for a, xs in zip(accs, sets):
+        for x in xs:
+            a.add(x)
+    accs[0].timing = accs[1].timing = []
+    HessianAccumulator.flush_many(accs, mix_widths=True)
+    assert len(accs[1].timing) == 1 and accs[1].timing[0][4] == 4          # one launch pair, four problems, the widest is its owner
+    for a, xs in zip(accs, sets):
+        ref = HessianAccumulator(a.K, 'cuda')
+        for x in xs:
+            ref.add(x)
+        d = torch.sqrt(torch.outer(torch.diagonal(ref.H), torch.diagonal(ref.H)))
+        assert float(((a.H - ref.H).abs() / d).max()) < 2e-6 and torch.equal(a.H, a.H.T)
+        ex = sum((x.double() ** 2).sum(dim=(0, 1)) for x in xs) * (2.0 / len(xs))
+        assert float(((torch.diagonal(a.H).double() - ex).abs() / ex).max()) <= 2.5e-7
