@@ -694,7 +694,7 @@ static int chol_inv_upper_impl(float* A, float* Uout, int64_t K64, void* ws, int
     SideStream* side = (!helper_streams_enabled()) ? nullptr : side_stream_for(st);
     bool pending_side = false;
     // The large products of K3 (far updates, triangular-inverse levels >= 512) run as split-bf16 products on the 16-bit
-    // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). LLMC_K3_FP32=1 keeps everything on
+    // MFMA pipe (gemm3.hip: fp32-level accuracy, 1.3-1.5x the fp32-MFMA kernel). option k3_fp32 keeps everything on
     // the fp32 MFMA path.
     const bool k3_x3 = !opt(OPT_K3_FP32);
     const bool use_x3u = k3_x3, use_x3 = k3_x3, use_x3t = k3_x3;

@@ -474,7 +474,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     const int ELD = BS * GRP;
     // Round 5: the error columns are kept K-MAJOR, [GRP * 128][Rp] — the fp32 GEMMs stage a k-major A panel with 16-B LDS writes,
     // a row-major one ([R][512]) through four scalar transposing writes per float4 (square 4096: 130 vs 122 TFLOP/s). The in-block
-    // kernel's stores become 16-B segments (four rows of one column); the volume is 2 MB per block. LLMC_K4_ERR_ROWMAJOR=1: the old
+    // kernel's stores become 16-B segments (four rows of one column); the volume is 2 MB per block. option k4_err_rowmajor: the old
     // layout (same bits).
     const bool ekm = !opt(OPT_K4_ERR_ROWMAJOR);
     const int64_t Rp = (R + 3) & ~(int64_t)3;
@@ -486,7 +486,7 @@ extern "C" int llmc_gptq_quantize_cols(float* W, const float* Hinv, int64_t R, i
     // (event C1: all the next group's own update waits for), then the rest. Round 3 joined the whole side update before
     // every group's far update, so the chain stood still while ~430 us of fp32 far update drained. Per element the updates
     // still arrive in the reference's order (block 0, 1, 2, ...: bulk stream order, then the chain behind C1), from the
-    // same kernels on the same tile grid: bit-identical to one stream (LLMC_NO_SIDE_STREAM=1), which tests compare.
+    // same kernels on the same tile grid: bit-identical to one stream (llmc_hip_set_helper_streams(0)), which tests compare.
     PipeStreams* ps = (!helper_streams_enabled()) ? nullptr : pipe_streams_for(caller);
     const bool merge_far = !opt(OPT_K4_SPLIT_FAR);
     hipStream_t st = ps ? pipe_chain_stream(ps, caller) : caller;

@@ -797,7 +797,7 @@ extern "C" int llmc_linear_eval_kt(const void* Xt, const void* Wt, int dt, int64
     a.yblk = yblk;
     a.C = nullptr; a.ldc = 0; a.csign = 1.0f; a.krange = 0; a.kunit = 1; a.queue = nullptr; a.ksplit = 1; a.ntm_real = a.ntm;
     // split-K for products that leave CUs idle (mode 0, row-major output, workspace given): fp32 slices into ws, then one
-    // reduction + rounding pass. LLMC_LINEAR_NOSPLIT=1 keeps the single-pass form (tests compare the two).
+    // reduction + rounding pass. option linear_nosplit keeps the single-pass form (tests compare the two).
     const int sk = (mode == 0 && !yblk && ws && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)Yout & 15) == 0 && !opt(OPT_LINEAR_NOSPLIT))
                        ? lin_ksplit(N, K, R, grid) : 1;
     if (sk > 1) {

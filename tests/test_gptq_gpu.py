@@ -103,7 +103,7 @@ def test_gemm3_split_bf16_matches_fp32_accuracy(shape, TA):
                                    (768, 768, 128)])
 def test_gemm3_specialised_kernel_is_bit_identical(shape, monkeypatch):
     """k_gemm3s (producer waves split the panels, MFMA waves multiply; range-checked buffer loads two K-steps ahead) against
-    k_gemm3 (LLMC_GEMM3_NOSPEC=1): same bits for every epilogue and for the upper-only form, on panels that sit inside a
+    k_gemm3 (option gemm3_nospec): same bits for every epilogue and for the upper-only form, on panels that sit inside a
     larger poisoned matrix (anything read beyond a panel's rows or columns would show), and nothing written outside C's
     upper part when only that is asked for."""
     M, N, Kd = shape
@@ -386,7 +386,7 @@ def test_factor_and_column_loop_are_run_to_run_deterministic():
 
 def test_split_bf16_factor_is_as_accurate_as_fp32_on_outlier_channels(monkeypatch):
     """K3's large products run as split-bf16 by default; on a Hessian with 100x outlier channels (condition number
-    ~1e6 after damping) its factor must be as close to the fp64 factor as the all-fp32-MFMA path's (LLMC_K3_FP32=1)."""
+    ~1e6 after damping) its factor must be as close to the fp64 factor as the all-fp32-MFMA path's (option k3_fp32)."""
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
     K = 2048
     gen = torch.Generator().manual_seed(5)
@@ -436,7 +436,7 @@ def test_chol_inv_upper_vs_fp64(K):
 @pytest.mark.parametrize('K', [4096, 5000])
 def test_chol_inv_upper_far_updates_on_planes_keep_every_bit(K, monkeypatch):
     """K3 with the large far updates on pre-split planes (the default) against the same factorisation with k_gemm3 splitting
-    inside every tile (LLMC_K3_NO_PLANES=1): the factor is the same to the last bit. K = 5000: far widths that are multiples
+    inside every tile (option k3_no_planes): the factor is the same to the last bit. K = 5000: far widths that are multiples
     of 8 but not of 128 (ragged last tiles)."""
     from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
     gen = torch.Generator().manual_seed(K + 1)

@@ -1,4 +1,5 @@
-"""Time one far update (C -= P^T P, upper only, Kd = 512) on k_gemm3 and on k_gemm3s with parts switched off (LLMC_GEMM3S_DBG).
+"""(Round 5 probe; LLMC_GEMM3S_DBG needs a -DLLMC_LAB build of the library, gemm3_nospec is an option since round 6.)
+Time one far update (C -= P^T P, upper only, Kd = 512) on k_gemm3 and on k_gemm3s with parts switched off (LLMC_GEMM3S_DBG).
 usage: python tools/probes/gemm3s_probe.py [n]"""
 import os
 import sys

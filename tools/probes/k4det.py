@@ -26,7 +26,7 @@ else:
     import torch
     env = dict(os.environ)
     subprocess.run([sys.executable, __file__, 'child', '/tmp/k4_side.pt'], env=env, check=True)
-    env['LLMC_NO_SIDE_STREAM'] = '1'
+    env['LLMC_OPTIONS'] = ''      # (helper streams are switched with llmc_hip_set_helper_streams since round 6)
     subprocess.run([sys.executable, __file__, 'child', '/tmp/k4_noside.pt'], env=env, check=True)
     a, b = torch.load('/tmp/k4_side.pt'), torch.load('/tmp/k4_noside.pt')
     for k in a:
