@@ -16,6 +16,10 @@ extern "C" {
 int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M,
                     int N, int Kd, int TA, int TB, int epilogue, int a_upper, int a_lower, int b_upper,
                     int c_upper_only, llmc_stream_t stream);
+/* The phased form K4's far update uses: C -= op(A)[:, p] B[p, :] for p = consecutive ranges of `phase_len` k (a multiple of 16),
+ * one launch, bit-identical to Kd / phase_len separate llmc_test_sgemm calls. op(B) = N. */
+int llmc_test_sgemm_phased(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
+                           int Kd, int TA, int phase_len, llmc_stream_t stream);
 int llmc_test_gemm3(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc, int M, int N,
                     int Kd, int TA, int epilogue, int a_upper, int b_upper, int c_upper_only, llmc_stream_t stream);
 /* The k-major product (TA) of llmc_test_gemm3 in the form K3's large far updates use: both operands are first split into

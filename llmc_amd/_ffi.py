@@ -100,6 +100,7 @@ SIGNATURES = {
     'llmc_pack_awq_gemm': (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     'llmc_test_sgemm': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i32, _vp]),
+    'llmc_test_sgemm_phased': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     'llmc_test_gemm3': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'llmc_test_gemm3_planes': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'llmc_test_gemm3s_stamps': (_i32, [_vp]),

@@ -66,7 +66,8 @@ enum Opt : int {
     OPT_K1_BATCH_OFF,       // llmc_hessian_accum_multi as one launch per problem instead of one tile queue
     OPT_K1_FP32_DIAG,
     OPT_FP8_NO_PACKED16,    // FP8 cast: the float form of the division-free path instead of the packed 16-bit one
-    OPT_GEMM3S_NO_DMA,      // k_gemm3s planes form: producers copy through registers + ds_write (round 5) instead of LDS-DMA       // keep the MFMA kernel's fp32 diagonal instead of the fp64-folded one
+    OPT_GEMM3S_NO_DMA,      // k_gemm3s planes form: producers copy through registers + ds_write (round 5) instead of LDS-DMA
+    OPT_SGEMM_NO_WIDE,      // K4's phased far update on k_sgemm (128 x 128 tiles, two workgroups per CU) instead of k_sgemm_wide
     OPT_COUNT
 };
 int opt(int id);

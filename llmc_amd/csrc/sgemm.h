@@ -43,6 +43,11 @@ struct SgemmArgs {
 // launches on `st`; returns LLMC_* status
 int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st);
 
+// K4's phased far update (TA, op(B) = N, SG_SUB, phase_len = 128, whole 256 x 128 tiles) on the one-wave-per-SIMD kernel of
+// sgemm_wide.hip: same chain, same bits as sgemm_launch's other kernels
+bool sgemm_wide_eligible(const SgemmArgs& a, bool TA, bool TB);
+int sgemm_wide_launch(const SgemmArgs& a, hipStream_t st);
+
 // C -= A^T B (A [Kd x M], B [Kd x N], both k-major) on the 16-bit MFMA pipe with three bf16 terms per fp32 operand
 // (gemm3.hip): fp32-level accuracy, NOT the bitwise fma chain above — K3 only.
 int gemm3_tn_launch(const SgemmArgs& a, hipStream_t st);

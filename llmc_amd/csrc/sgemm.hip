@@ -517,6 +517,7 @@ int sgemm_launch(const SgemmArgs& a, bool TA, bool TB, hipStream_t st) {
         LLMC_LAUNCH_CHECK();
         return LLMC_OK;
     }
+    if (sgemm_wide_eligible(a, TA, TB)) return sgemm_wide_launch(a, st);
     LLMC_REQUIRE((const void*)a.C != (const void*)a.B || (a.M <= GB && a.batch == 1),
                  "sgemm: in-place C = op(A) B needs a single row tile (M <= 128)");
     dim3 grid((a.N + GB - 1) / GB, (a.M + GB - 1) / GB, a.batch);
@@ -563,4 +564,16 @@ extern "C" int llmc_test_sgemm(const float* A, const float* B, float* C, int64_t
     a.a_upper = a_upper; a.a_lower = a_lower; a.b_upper = b_upper; a.c_upper_only = c_upper_only;
     a.batch = 1;
     return llmc::sgemm_launch(a, TA != 0, TB != 0, (hipStream_t)stream);
+}
+// the phased form (K4's far update): C -= op(A)[:, p] B[p, :] for p = phases of `phase_len` k, one launch
+extern "C" int llmc_test_sgemm_phased(const float* A, const float* B, float* C, int64_t lda, int64_t ldb, int64_t ldc,
+                                      int M, int N, int Kd, int TA, int phase_len, llmc_stream_t stream) {
+    llmc::SgemmArgs a{};
+    a.A = A; a.B = B; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.M = a.M_last = M; a.N = a.N_last = N; a.Kd = a.Kd_last = Kd;
+    a.epilogue = llmc::SG_SUB;
+    a.batch = 1;
+    a.phase_len = phase_len;
+    return llmc::sgemm_launch(a, TA != 0, false, (hipStream_t)stream);
 }

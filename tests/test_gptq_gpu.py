@@ -61,6 +61,60 @@ def test_sgemm_bitwise_chain(shape):
     np.testing.assert_array_equal(bits(C3.cpu().numpy()[:, :N]), bits(-ref))
 
 
+def sgemm_phased(A, B, C, M, N, Kd, TA, phase):
+    L = _ffi.lib()
+    _ffi.check(L.llmc_test_sgemm_phased(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
+                                        M, N, Kd, int(TA), phase, _ffi.stream()), 'sgemm_phased')
+    return C
+
+
+@pytest.mark.parametrize('shape', [(256, 128, 128), (512, 384, 512), (1024, 1152, 256), (4096, 2176, 512), (768, 4224, 384)])
+def test_sgemm_wide_phased_far_update_bitwise(shape):
+    """K4's lazy far update (gptq.py:240-244 for a group of 128-column blocks in one launch) on k_sgemm_wide (256 x 128 tiles,
+    LDS-DMA ring, one wave per SIMD): bit-identical to the oracle's chain applied block by block, and to k_sgemm."""
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M + N + Kd)
+    at = (torch.randn(Kd, M, generator=gen) * 0.01)          # the error columns, k-major
+    b = torch.randn(Kd, N, generator=gen)
+    c0 = torch.randn(M, N, generator=gen)
+    exp = c0.numpy().copy()
+    if M * N * Kd <= 512 * 384 * 512:                        # the oracle's scalar chain is slow: small cases only
+        for p0 in range(0, Kd, 128):
+            exp = exp - G.mm_chain(np.ascontiguousarray(at[p0:p0 + 128].t().numpy()), b[p0:p0 + 128].numpy())
+    else:
+        exp = None
+    res = {}
+    for name, opts in (('wide', dict(no_shortk=1)), ('k_sgemm', dict(no_shortk=1, sgemm_no_wide=1)), ('default', {})):
+        with _ffi.option(**opts):
+            C = c0.cuda()
+            sgemm_phased(at.cuda(), b.cuda(), C, M, N, Kd, True, 128)
+            res[name] = C.cpu().numpy()
+    if exp is not None:
+        np.testing.assert_array_equal(bits(res['wide']), bits(exp))
+    np.testing.assert_array_equal(bits(res['wide']), bits(res['k_sgemm']))
+    np.testing.assert_array_equal(bits(res['default']), bits(res['k_sgemm']))
+
+
+def test_sgemm_wide_strided_operands_and_zero_products():
+    """Operands that are column ranges of wider matrices (ld > width, as in the column loop), and exact zeros in the error panel
+    (a phase whose products are all zero must leave -0.0 entries of C as they are: C - (+0))."""
+    M, N, Kd = 512, 640, 256
+    gen = torch.Generator().manual_seed(5)
+    Abig = (torch.randn(Kd, M + 64, generator=gen) * 0.01).cuda()
+    Abig[:128] = 0.0
+    Bbig = torch.randn(Kd, N + 256, generator=gen).cuda()
+    Cbig = torch.randn(M, N + 256, generator=gen)
+    Cbig[::7, ::5] = -0.0
+    out = {}
+    for name, opts in (('wide', dict(no_shortk=1)), ('k_sgemm', dict(no_shortk=1, sgemm_no_wide=1))):
+        with _ffi.option(**opts):
+            C = Cbig.cuda()
+            sgemm_phased(Abig[:, 64:], Bbig[:, 128:], C[:, 128:], M, N, Kd, True, 128)
+            out[name] = C.cpu().numpy()
+    np.testing.assert_array_equal(bits(out['wide']), bits(out['k_sgemm']))
+    np.testing.assert_array_equal(bits(out['wide'][:, :128]), bits(Cbig.numpy()[:, :128]))      # columns outside the product untouched
+
+
 def gemm3(A, B, C, M, N, Kd, TA, epi, hints=(0, 0, 0)):
     L = _ffi.lib()
     _ffi.check(L.llmc_test_gemm3(A.data_ptr(), B.data_ptr(), C.data_ptr(), A.stride(0), B.stride(0), C.stride(0),
