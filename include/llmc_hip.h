@@ -89,7 +89,8 @@ int llmc_hip_set_cu_reserve(int n_cus);
  *   k1_fp32_diag      diag(H) as the MFMA kernel's fp32 chain leaves it instead of the fp64-folded one (other diagonal)
  *   fp8_no_packed16   FP8 e4m3 cast of bf16 tensors (qtorch rounding, codes out): the float form of the division-free path; same bits
  *   gemm3s_no_dma     k_gemm3s (planes form): producer waves copy through registers instead of LDS-DMA; same bits
- *   sgemm_no_wide     K4's far update on k_sgemm (128 x 128 tiles) instead of k_sgemm_wide (256 x 128, LDS-DMA); same bits
+ *   sgemm_no_wide     K4's far update: 1 = on k_sgemm (the kernel of rounds 2-5), 4 = k_sgemm_wide's 256 x 128 form (one workgroup
+ *                     per CU) instead of its 128 x 128 form (two per CU, the default); same bits
  * set: returns the previous value, or LLMC_EINVAL for an unknown key / negative value. get: the value, or LLMC_EINVAL.
  * option_name: the key of index 0, 1, ... (copied into buf), LLMC_EINVAL past the last one. No reference counterpart. */
 int llmc_hip_set_option(const char* key, int value);

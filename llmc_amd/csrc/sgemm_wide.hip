@@ -1,4 +1,4 @@
-// sgemm_wide.hip — K4's phased far update on a 256 x 128 workgroup tile with ONE wave per SIMD (round 6).
+// sgemm_wide.hip — K4's phased far update with LDS-DMA operands and XCD-dealt tiles (round 6).
 //
 // The product:  C -= A^T B  phase by phase (phase = 128 k), A = a column group's error columns [Kd x M] k-major, B = the same
 // rows of the inverse factor [Kd x N] k-major, C = the weight columns still to come (gptq.py:240-244 applied lazily: per element
@@ -6,16 +6,21 @@
 // accumulator per element and phase, products added in ascending k from +0 by v_mfma_f32_32x32x2_f32, then one rounding C - acc.
 //
 // Why another kernel: tools/probes/mfma_f32_peak.hip measures 0.99 of the 157.3-TFLOP/s fp32 MFMA peak with nothing else in the
-// loop (one to four waves per SIMD, operands from LDS or not), k_sgemm reaches 0.61-0.66 on these shapes whatever its occupancy
-// or K-step (profiles/r04_chain_pmc.txt, r05_sgemm_far_experiment.txt): its 128 x 128 tile asks the memory system for 1 B per
-// 32 flop (4.9 TB/s of operand fetch at peak), through registers, with 83 VALU instructions per K-step. Here:
-//   - 256 x 128 per workgroup (128 x 64 per wave: 8 accumulator blocks + the C tile itself = 256 registers of a 512-register wave):
-//     1 B per 43 flop;
+// loop (one to four waves per SIMD, operands from LDS or not); k_sgemm reaches 0.58-0.72 on these shapes whatever its occupancy
+// or K-step (profiles/r04_chain_pmc.txt, r05_sgemm_far_experiment.txt): its operands go through registers (83 VALU instructions
+// per K-step: addresses, transposing writes, the phase end) and its tiles are dealt row by row over the XCDs. Here:
 //   - operands by LDS-DMA (buffer_load_dwordx4 .. lds) into a four-slot ring of 16-k stages, two stages ahead: no staging
-//     registers, no address arithmetic, no ds_write; six DMA instructions per wave and stage;
-//   - a 1-D grid dealt so that the 32 workgroups an XCD runs at a time are a 4 x 8 block of tiles (8 + 4 panels for 32 tiles in that
-//     XCD's L2 instead of one pair per tile) and the eight XCDs' blocks share their B panels;
+//     registers, no address arithmetic, no ds_write; MB + 2 DMA instructions per wave and stage. The loop is one MFMA and one
+//     ds_read_b32 per slot;
+//   - the C tile stays in registers; a phase's accumulators start from the inline constant +0 and are subtracted from C block by
+//     block under the next phase's first MFMAs;
+//   - a 1-D grid dealt so that the workgroups an XCD runs at a time are one 1024 x 1024 block of tiles (12-16 panels in that XCD's
+//     L2 instead of one pair per tile), blocks of one B panel on neighbouring XCDs;
 //   - the k-rows an MFMA operand read touches (lanes 0-31: k, lanes 32-63: k + 1) lie 1152 B apart in LDS: the other half of the banks.
+// Two forms (template MB): 256 x 128 tiles with one workgroup per CU (128 x 64 per wave: accumulators + C = 256 of a wave's 512
+// registers), and 128 x 128 tiles with two workgroups per CU, whose partner covers a workgroup's first DMA round trip, C loads,
+// last subtraction and stores. Measured (profiles/r06_sgemm_wide_ab.txt): 0.74-0.87 of peak for the second form, 0.65-0.81 for the
+// first, 0.59-0.72 for k_sgemm; inside the column loop -17 % / -11 % of k_sgemm's time. The second form is the default.
 #include <type_traits>
 
 #include "mfma_common.h"
@@ -24,14 +29,22 @@
 namespace llmc {
 namespace {
 
-constexpr int W_BM = 256, W_BN = 128, W_K = 16, W_SLOTS = 4;
-constexpr int W_ROW = 1152;                    // bytes between the LDS images of consecutive A k-rows (1 KiB of data) / of the two B pieces of a k-quad
-constexpr int W_AB = W_K * W_ROW;              // A part of a stage: 16 k-rows of 256 floats
-constexpr int W_BB = (W_K / 2) * W_ROW;        // B part: 8 pieces of 1 KiB = rows (4q + e, 4q + e + 2), q = 0..3, e = 0..1
-constexpr int W_SLOT = W_AB + W_BB;            // 27648
-constexpr int W_LDS = W_SLOTS * W_SLOT;        // 110592
-constexpr int W_SM = 4, W_SN = 8;              // an XCD's block of tiles
+constexpr int W_BN = 128, W_K = 16, W_SLOTS = 4;
+constexpr int W_ROW = 1152;                    // LDS pitch of a 1-KiB piece: 1024 + 128, so that the piece holding k + 1 starts in the other half of the banks
+constexpr int W_BB = (W_K / 2) * W_ROW;        // a 128-wide operand's part of a stage: 8 pieces = rows (4q + e, 4q + e + 2), q = 0..3, e = 0..1
 constexpr int W_PHASE = 128 / W_K;             // stages per phase
+// MB = 32-row blocks per wave along M: 4 -> 256 x 128 workgroup tile, 407 registers, one workgroup per CU, an XCD's 32 tiles = 4 x 8;
+//                                      2 -> 128 x 128, two workgroups per CU (one covers the other's first and last microseconds), 64 tiles = 8 x 8
+template <int MB> struct Wide {
+    static constexpr int BM = 64 * MB;
+    static constexpr int AB = MB == 4 ? W_K * W_ROW : W_BB;      // 256 wide: one k-row per piece; 128 wide: as B
+    static constexpr int SLOT = AB + W_BB;
+    static constexpr int LDS = W_SLOTS * SLOT;                   // 110592 / 73728
+    static constexpr int SM = MB == 4 ? 4 : 8, SN = 8;           // an XCD's block of tiles
+    static constexpr int PER_XCD = SM * SN;
+    static constexpr int D = MB + 2;                             // DMA instructions per wave and stage
+    static constexpr int NBLK = 2 * MB;                          // accumulator blocks per wave
+};
 
 struct WideArgs {
     const float* A;
@@ -50,15 +63,18 @@ template <int I, int N, typename F> __device__ __forceinline__ void wfor(F&& f) 
         wfor<I + 1, N>(f);
     }
 }
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-__global__ __launch_bounds__(256) void k_sgemm_wide(const WideArgs a) {
+template <int MB>
+__global__ __launch_bounds__(256, MB == 4 ? 1 : 2) void k_sgemm_wide(const WideArgs a) {
+    using W = Wide<MB>;
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    // workgroup w runs on XCD w % 8 (round-robin dispatch); the 32 consecutive workgroups of an XCD are one 4 x 8 block of tiles
+    // workgroup w runs on XCD w % 8 (round-robin dispatch); the PER_XCD consecutive workgroups of an XCD are one block of tiles
     const int w = blockIdx.x;
-    const int g = (w >> 8) * 8 + (w & 7);
+    const int g = (w / (8 * W::PER_XCD)) * 8 + (w & 7);
     if (g >= a.nsb) return;
-    const int within = (w >> 3) & 31;
-    const int ti = (g % a.sbm) * W_SM + (within >> 3), tj = (g / a.sbm) * W_SN + (within & 7);
+    const int within = (w >> 3) % W::PER_XCD;
+    const int ti = (g % a.sbm) * W::SM + within / W::SN, tj = (g / a.sbm) * W::SN + within % W::SN;
     if (ti >= a.tm || tj >= a.tn) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,66 +87,78 @@ __global__ __launch_bounds__(256) void k_sgemm_wide(const WideArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0,
                                                  __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     };
-    const auto dA = mk(a.A + (int64_t)ti * W_BM, a.bytesA);
+    const auto dA = mk(a.A + (int64_t)ti * W::BM, a.bytesA);
     const auto dB = mk(a.B + (int64_t)tj * W_BN, a.bytesB);
-    const auto dC = mk(a.C + (int64_t)ti * W_BM * a.ldc + (int64_t)tj * W_BN, a.bytesC);
+    const auto dC = mk(a.C + (int64_t)ti * W::BM * a.ldc + (int64_t)tj * W_BN, a.bytesC);
     LDS_AS char* lds = (LDS_AS char*)smem_w;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
     const int nst = a.nst;
 
-    // ---- LDS-DMA: wave wv brings A k-rows 4 wv .. 4 wv + 3 (1 KiB each) and the two B pieces of k-quad wv of every stage
-    const uint32_t voA = (uint32_t)lane * 16u;
+    // ---- LDS-DMA. A 128-wide operand: piece (q, e) = k-rows 4q + e (lanes 0-31) and 4q + e + 2 (lanes 32-63), 512 B each, at
+    // (2q + e) * W_ROW; wave wv brings k-quad q = wv. The 256-wide A: one k-row (1 KiB) per piece at k * W_ROW, wave wv brings rows 4 wv ..
+    const uint32_t voA = MB == 4 ? (uint32_t)lane * 16u : (uint32_t)(lane >> 5) * 2u * a.rowA + (uint32_t)(lane & 31) * 16u;
     const uint32_t voB = (uint32_t)(lane >> 5) * 2u * a.rowB + (uint32_t)(lane & 31) * 16u;
     auto dma = [&](const decltype(dA)& d, uint32_t vo, uint32_t so, uint32_t dst) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
                      :: "v"(vo), "s"(d), "s"(dst), "s"(so) : "memory");
     };
     auto issue = [&](int j) {
-        const uint32_t slot = lds0 + (uint32_t)(j & (W_SLOTS - 1)) * W_SLOT;
+        const uint32_t slot = lds0 + (uint32_t)(j & (W_SLOTS - 1)) * W::SLOT;
         const uint32_t k = (uint32_t)(j * W_K + 4 * wv);
+        if constexpr (MB == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma(dA, voA, (k + i) * a.rowA, slot + (uint32_t)(4 * wv + i) * W_ROW);
+            for (int i = 0; i < 4; ++i) dma(dA, voA, (k + i) * a.rowA, slot + (uint32_t)(4 * wv + i) * W_ROW);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) dma(dB, voB, (k + e) * a.rowB, slot + W_AB + (uint32_t)(2 * wv + e) * W_ROW);
+            for (int e = 0; e < 2; ++e) dma(dA, voA, (k + e) * a.rowA, slot + (uint32_t)(2 * wv + e) * W_ROW);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dma(dB, voB, (k + e) * a.rowB, slot + W::AB + (uint32_t)(2 * wv + e) * W_ROW);
     };
 
-    // ---- operand reads: pair kp of a stage = k-rows 2 kp (lanes 0-31) and 2 kp + 1 (lanes 32-63)
+    // ---- operand reads: pair kp of a stage = k-rows 2 kp (lanes 0-31) and 2 kp + 1 (lanes 32-63); two base registers per operand
+    // (slots 0-1 / 2-3: the ds_read offset field has 16 bits)
     LDS_AS char* pA[2];
     LDS_AS char* pB[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        pA[h] = lds + h * 2 * W_SLOT + (lane >> 5) * W_ROW + (wm * 128 + (lane & 31)) * 4;
-        pB[h] = lds + h * 2 * W_SLOT + W_AB + (lane >> 5) * W_ROW + (wn * 64 + (lane & 31)) * 4;
+        pA[h] = lds + h * 2 * W::SLOT + (lane >> 5) * W_ROW + (wm * 32 * MB + (lane & 31)) * 4;
+        pB[h] = lds + h * 2 * W::SLOT + W::AB + (lane >> 5) * W_ROW + (wn * 64 + (lane & 31)) * 4;
     }
-    float fa[2][4], fb[2][2];
+    float fa[2][MB], fb[2][2];
     auto rd = [&](auto cc, auto slc, auto kpc, auto ic) {
         constexpr int c = decltype(cc)::value, SL = decltype(slc)::value, kp = decltype(kpc)::value, i = decltype(ic)::value;
-        if constexpr (i < 4) fa[c][i] = *(LDS_AS const float*)(pA[SL >> 1] + (SL & 1) * W_SLOT + kp * 2 * W_ROW + i * 128);
-        else fb[c][i - 4] = *(LDS_AS const float*)(pB[SL >> 1] + (SL & 1) * W_SLOT + (kp >> 1) * 2 * W_ROW + (kp & 1) * 512 + (i - 4) * 128);
+        constexpr int narrow = (SL & 1) * W::SLOT + (kp >> 1) * 2 * W_ROW + (kp & 1) * 512;
+        if constexpr (i < MB) {
+            if constexpr (MB == 4) fa[c][i] = *(LDS_AS const float*)(pA[SL >> 1] + (SL & 1) * W::SLOT + kp * 2 * W_ROW + i * 128);
+            else fa[c][i] = *(LDS_AS const float*)(pA[SL >> 1] + narrow + i * 128);
+        } else {
+            fb[c][i - MB] = *(LDS_AS const float*)(pB[SL >> 1] + narrow + (i - MB) * 128);
+        }
     };
 
-    // ---- the C tile of this wave: block (m, n) element r of lane l = row wm*128 + m*32 + (r & 3) + 8 (r >> 2) + 4 (l >> 5),
+    // ---- the C tile of this wave: block (m, n) element r of lane l = row wm*32*MB + m*32 + (r & 3) + 8 (r >> 2) + 4 (l >> 5),
     // column wn*64 + n*32 + (l & 31)
-    const uint32_t voC = (uint32_t)(wm * 128 + 4 * (lane >> 5)) * a.rowC + (uint32_t)(wn * 64 + (lane & 31)) * 4u;
+    const uint32_t voC = (uint32_t)(wm * 32 * MB + 4 * (lane >> 5)) * a.rowC + (uint32_t)(wn * 64 + (lane & 31)) * 4u;
     auto soC = [&](uint32_t rowC, int m, int n, int r) { return (uint32_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * rowC + (uint32_t)n * 128u; };
-    f32x16 cv[4][2], acc[4][2];
+    f32x16 cv[MB][2], acc[MB][2];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // prologue: three stages requested, the first one published
+    // prologue: three stages requested (nst >= 8), the first one published
     issue(0);
-    if (1 < nst) issue(1);
-    if (2 < nst) issue(2);
-    if (2 < nst) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(1);
+    issue(2);
+    vm_wait<2 * W::D>();
     __builtin_amdgcn_s_barrier();
-    wfor<0, 6>([&](auto ic) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ic); });
+    wfor<0, MB + 2>([&](auto ic) { rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ic); });
     __builtin_amdgcn_sched_barrier(0);
 
-    // One phase = 8 stages = 64 pairs of 8 MFMAs. Behind MFMA i of pair p: i < 6 -> operand i of the next pair (pair 7: the next
-    // stage's first pair; the barrier in pair 5 has published that stage). Pair 5, last MFMA: this wave's pieces of stage j + 1 have
-    // landed, barrier (every wave is past its last read of stage j - 1). Pair 6: stage j + 3 requested into the slot of stage j - 1.
-    // First phase, pair 7: the C values of block s requested (two per MFMA), i.e. issue order D0 D1 D2 | D3 C0 | D4 C1 | ..: when
-    // stage j waits for D(j+1) the younger requests are C(j-2) D(j+2) C(j-1) = 38 (j = 0: D2 = 6; j = 1: D3 C0 = 22); later phases: 6.
+    // One phase = 8 stages of 8 pairs of 2 MB MFMAs. Behind MFMA i of pair p: i < MB + 2 -> operand i of the next pair (pair 7: the
+    // next stage's first pair; the barrier in pair 5 has published that stage). Pair 5, last MFMA: this wave's pieces of stage j + 1
+    // have landed, barrier (every wave is past its last read of stage j - 1). Pair 6, last MFMA: stage j + 3 requested into the slot
+    // of stage j - 1. First phase, pair 7 of stages s < 2 MB: the C values of block s requested, i.e. issue order
+    // D0 D1 D2 | D3 C0 | D4 C1 | ..: when stage j waits for D(j+1) the younger requests are C(j-2) D(j+2) C(j-1).
+    constexpr int LASTI = 2 * MB - 1, CPER = 16 / (2 * MB);
     auto phase = [&](auto firstc, int j0) {
         constexpr bool FIRST = decltype(firstc)::value;
         wfor<0, W_PHASE>([&](auto sc) {
@@ -138,7 +166,7 @@ __global__ __launch_bounds__(256) void k_sgemm_wide(const WideArgs a) {
             const int j = j0 + s;
             wfor<0, 8>([&](auto pc) {
                 constexpr int p = decltype(pc)::value, c = p & 1;
-                wfor<0, 8>([&](auto ic) {
+                wfor<0, 2 * MB>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, m = i >> 1, n = (m & 1) ? 1 - (i & 1) : (i & 1);
                     if constexpr (s == 0 && p == 0) {
                         // a phase's first product starts from +0 (inline constant: no zeroing); the previous phase's block is
@@ -148,49 +176,47 @@ __global__ __launch_bounds__(256) void k_sgemm_wide(const WideArgs a) {
                     } else {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][m], fb[c][n], acc[m][n], 0, 0, 0);
                     }
-                    if constexpr (i < 6) {
+                    if constexpr (i < MB + 2) {
                         if constexpr (p < 7) rd(std::integral_constant<int, c ^ 1>{}, std::integral_constant<int, SL>{}, std::integral_constant<int, (p + 1) & 7>{}, ic);
                         else rd(std::integral_constant<int, c ^ 1>{}, std::integral_constant<int, SN>{}, std::integral_constant<int, 0>{}, ic);
                     }
-                    if constexpr (p == 5 && i == 7) {
+                    if constexpr (p == 5 && i == LASTI) {
                         if (j + 2 < nst) {
-                            if constexpr (FIRST && s == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                            else if constexpr (FIRST && s == 1) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-                            else if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                            constexpr int younger_c = FIRST ? 16 * ((s >= 2 && s - 2 < W::NBLK) + (s >= 1 && s - 1 < W::NBLK)) : 0;
+                            vm_wait<W::D + younger_c>();
                         } else {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            vm_wait<0>();
                         }
                         __builtin_amdgcn_s_barrier();
                     }
-                    if constexpr (p == 6 && i == 6) {
+                    if constexpr (p == 6 && i == LASTI) {
                         if (j + 3 < nst) issue(j + 3);
                     }
-                    if constexpr (FIRST && p == 7) {
+                    if constexpr (FIRST && p == 7 && s < W::NBLK) {
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
+                        for (int e = 0; e < CPER; ++e) {
                             constexpr int bm = s >> 1, bn = s & 1;
-                            cv[bm][bn][2 * i + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dC, voC, soC(a.rowC, bm, bn, 2 * i + e), 0));
+                            cv[bm][bn][CPER * i + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dC, voC, soC(a.rowC, bm, bn, CPER * i + e), 0));
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
         });
-        if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the C values are here (and every request older than them)
+        if constexpr (FIRST) vm_wait<0>();      // the C values are here (and every request older than them)
         __builtin_amdgcn_sched_barrier(0);
     };
     phase(std::true_type{}, 0);
     for (int j0 = W_PHASE; j0 < nst; j0 += W_PHASE) phase(std::false_type{}, j0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) cv[m][n] = cv[m][n] - acc[m][n];
 
-    uint32_t rowC2 = a.rowC;      // opaque copy: the 128 row offsets are recomputed here, not kept in SGPRs from the first phase on
+    uint32_t rowC2 = a.rowC;      // opaque copy: the row offsets are recomputed here, not kept in SGPRs from the first phase on
     asm volatile("" : "+s"(rowC2));
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -202,33 +228,42 @@ __global__ __launch_bounds__(256) void k_sgemm_wide(const WideArgs a) {
 
 }  // namespace
 
-bool sgemm_wide_eligible(const SgemmArgs& a, bool TA, bool TB) {
-    if (!TA || TB || a.batch != 1 || a.epilogue != SG_SUB || a.phase_len != 128) return false;
-    if (a.a_upper || a.a_lower || a.b_upper || a.c_upper_only) return false;
-    if (a.M <= 0 || a.N <= 0 || a.M % W_BM || a.N % W_BN || a.Kd % 128 || a.Kd < 128) return false;
-    if ((a.lda % 4) || (a.ldb % 4) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 3)) return false;
+// form: 0 = none, 4 = 256 x 128 tiles (one workgroup per CU), 2 = 128 x 128 tiles (two per CU)
+static int wide_form(const SgemmArgs& a, bool TA, bool TB) {
+    if (!TA || TB || a.batch != 1 || a.epilogue != SG_SUB || a.phase_len != 128) return 0;
+    if (a.a_upper || a.a_lower || a.b_upper || a.c_upper_only) return 0;
+    if (a.M <= 0 || a.N <= 0 || a.M % 128 || a.N % W_BN || a.Kd % 128 || a.Kd < 128) return 0;
+    if ((a.lda % 4) || (a.ldb % 4) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 3)) return 0;
     const int64_t lim = (int64_t)1 << 31;
-    if ((int64_t)a.Kd * a.lda * 4 >= lim || (int64_t)a.Kd * a.ldb * 4 >= lim || (int64_t)W_BM * a.ldc * 4 >= lim) return false;
-    if ((const void*)a.C == (const void*)a.A || (const void*)a.C == (const void*)a.B) return false;
-    return !opt(OPT_SGEMM_NO_WIDE);
+    if ((int64_t)a.Kd * a.lda * 4 >= lim || (int64_t)a.Kd * a.ldb * 4 >= lim || (int64_t)256 * a.ldc * 4 >= lim) return 0;
+    if ((const void*)a.C == (const void*)a.A || (const void*)a.C == (const void*)a.B) return 0;
+    const int v = opt(OPT_SGEMM_NO_WIDE);      // 0: the default form, 1: never, 2 / 4: that form where the shape allows it
+    if (v == 1) return 0;
+    if (v == 4) return a.M % 256 ? 2 : 4;
+    return 2;      // measured (profiles/r06_sgemm_wide_ab.txt): two 128 x 128 workgroups per CU beat one 256 x 128 on every shape of the column loop
 }
+bool sgemm_wide_eligible(const SgemmArgs& a, bool TA, bool TB) { return wide_form(a, TA, TB) != 0; }
 
-int sgemm_wide_launch(const SgemmArgs& a, hipStream_t st) {
+template <int MB> static int wide_launch(const SgemmArgs& a, hipStream_t st) {
+    using W = Wide<MB>;
     WideArgs w{};
     w.A = a.A; w.B = a.B; w.C = a.C; w.ldc = a.ldc;
     w.rowA = (uint32_t)(a.lda * 4); w.rowB = (uint32_t)(a.ldb * 4); w.rowC = (uint32_t)(a.ldc * 4);
-    w.bytesA = (uint32_t)(((int64_t)(a.Kd - 1) * a.lda + W_BM) * 4);
+    w.bytesA = (uint32_t)(((int64_t)(a.Kd - 1) * a.lda + W::BM) * 4);
     w.bytesB = (uint32_t)(((int64_t)(a.Kd - 1) * a.ldb + W_BN) * 4);
-    w.bytesC = (uint32_t)(((int64_t)(W_BM - 1) * a.ldc + W_BN) * 4);
+    w.bytesC = (uint32_t)(((int64_t)(W::BM - 1) * a.ldc + W_BN) * 4);
     w.nst = a.Kd / W_K;
-    w.tm = a.M / W_BM; w.tn = a.N / W_BN;
-    w.sbm = (w.tm + W_SM - 1) / W_SM;
-    w.nsb = w.sbm * ((w.tn + W_SN - 1) / W_SN);
+    w.tm = a.M / W::BM; w.tn = a.N / W_BN;
+    w.sbm = (w.tm + W::SM - 1) / W::SM;
+    w.nsb = w.sbm * ((w.tn + W::SN - 1) / W::SN);
     const int rounds = (w.nsb + 7) / 8;
-    if (int rc = ensure_dynamic_lds((const void*)k_sgemm_wide, W_LDS)) return rc;
-    hipLaunchKernelGGL(k_sgemm_wide, dim3(rounds * 256), dim3(256), W_LDS, st, w);
+    if (int rc = ensure_dynamic_lds((const void*)k_sgemm_wide<MB>, W::LDS)) return rc;
+    hipLaunchKernelGGL(k_sgemm_wide<MB>, dim3(rounds * 8 * W::PER_XCD), dim3(256), W::LDS, st, w);
     LLMC_LAUNCH_CHECK();
     return LLMC_OK;
+}
+int sgemm_wide_launch(const SgemmArgs& a, hipStream_t st) {
+    return wide_form(a, true, false) == 4 ? wide_launch<4>(a, st) : wide_launch<2>(a, st);
 }
 
 }  // namespace llmc

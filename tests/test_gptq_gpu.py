@@ -68,7 +68,7 @@ def sgemm_phased(A, B, C, M, N, Kd, TA, phase):
     return C
 
 
-@pytest.mark.parametrize('shape', [(256, 128, 128), (512, 384, 512), (1024, 1152, 256), (4096, 2176, 512), (768, 4224, 384)])
+@pytest.mark.parametrize('shape', [(256, 128, 128), (512, 384, 512), (1024, 1152, 256), (4096, 2176, 512), (768, 4224, 384), (384, 256, 256)])
 def test_sgemm_wide_phased_far_update_bitwise(shape):
     """K4's lazy far update (gptq.py:240-244 for a group of 128-column blocks in one launch) on k_sgemm_wide (256 x 128 tiles,
     LDS-DMA ring, one wave per SIMD): bit-identical to the oracle's chain applied block by block, and to k_sgemm."""
@@ -84,15 +84,16 @@ def test_sgemm_wide_phased_far_update_bitwise(shape):
     else:
         exp = None
     res = {}
-    for name, opts in (('wide', dict(no_shortk=1)), ('k_sgemm', dict(no_shortk=1, sgemm_no_wide=1)), ('default', {})):
+    for name, opts in (('wide4', dict(no_shortk=1, sgemm_no_wide=4)), ('wide2', dict(no_shortk=1, sgemm_no_wide=2)),
+                       ('k_sgemm', dict(no_shortk=1, sgemm_no_wide=1)), ('default', {})):
         with _ffi.option(**opts):
             C = c0.cuda()
             sgemm_phased(at.cuda(), b.cuda(), C, M, N, Kd, True, 128)
             res[name] = C.cpu().numpy()
     if exp is not None:
-        np.testing.assert_array_equal(bits(res['wide']), bits(exp))
-    np.testing.assert_array_equal(bits(res['wide']), bits(res['k_sgemm']))
-    np.testing.assert_array_equal(bits(res['default']), bits(res['k_sgemm']))
+        np.testing.assert_array_equal(bits(res['wide4']), bits(exp))
+    for name in ('wide4', 'wide2', 'default'):
+        np.testing.assert_array_equal(bits(res[name]), bits(res['k_sgemm']))
 
 
 def test_sgemm_wide_strided_operands_and_zero_products():
@@ -106,13 +107,15 @@ def test_sgemm_wide_strided_operands_and_zero_products():
     Cbig = torch.randn(M, N + 256, generator=gen)
     Cbig[::7, ::5] = -0.0
     out = {}
-    for name, opts in (('wide', dict(no_shortk=1)), ('k_sgemm', dict(no_shortk=1, sgemm_no_wide=1))):
+    for name, opts in (('wide4', dict(no_shortk=1, sgemm_no_wide=4)), ('wide2', dict(no_shortk=1, sgemm_no_wide=2)),
+                       ('k_sgemm', dict(no_shortk=1, sgemm_no_wide=1))):
         with _ffi.option(**opts):
             C = Cbig.cuda()
             sgemm_phased(Abig[:, 64:], Bbig[:, 128:], C[:, 128:], M, N, Kd, True, 128)
             out[name] = C.cpu().numpy()
-    np.testing.assert_array_equal(bits(out['wide']), bits(out['k_sgemm']))
-    np.testing.assert_array_equal(bits(out['wide'][:, :128]), bits(Cbig.numpy()[:, :128]))      # columns outside the product untouched
+    for name in ('wide4', 'wide2'):
+        np.testing.assert_array_equal(bits(out[name]), bits(out['k_sgemm']))
+        np.testing.assert_array_equal(bits(out[name][:, :128]), bits(Cbig.numpy()[:, :128]))      # columns outside the product untouched
 
 
 def gemm3(A, B, C, M, N, Kd, TA, epi, hints=(0, 0, 0)):

@@ -18,7 +18,7 @@ def run(tag, M, N, Kd, K=None, reps=7):
     C0 = torch.randn(M, K, device='cuda', generator=g)
     B = Bfull[:, K - N:]
     out, t = {}, {}
-    for arm, opts in (('wide', {}), ('k_sgemm', dict(sgemm_no_wide=1))):
+    for arm, opts in (('wide', dict(sgemm_no_wide=4)), ('wide2', dict(sgemm_no_wide=2)), ('k_sgemm', dict(sgemm_no_wide=1))):
         with _ffi.option(**opts):
             C = C0.clone()
             Cv = C[:, K - N:]
@@ -34,10 +34,11 @@ def run(tag, M, N, Kd, K=None, reps=7):
                 e0.record(); go(); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)
             t[arm] = sorted(ts)[len(ts) // 2]
-    same = torch.equal(out['wide'].view(torch.int32), out['k_sgemm'].view(torch.int32))
+    same = all(torch.equal(out[k].view(torch.int32), out['k_sgemm'].view(torch.int32)) for k in ('wide', 'wide2'))
     fl = 2.0 * M * N * Kd
-    print(f'{tag:26s} M={M:6d} N={N:6d} Kd={Kd}: wide {t["wide"]:8.1f} us ({fl/t["wide"]/1e6/157.3:.3f} of fp32 MFMA peak) | '
-          f'k_sgemm {t["k_sgemm"]:8.1f} us ({fl/t["k_sgemm"]/1e6/157.3:.3f}) | ratio {t["k_sgemm"]/t["wide"]:.3f} | same bits: {same}', flush=True)
+    print(f'{tag:22s} M={M:6d} N={N:6d} Kd={Kd}: 256x128 {t["wide"]:8.1f} us ({fl/t["wide"]/1e6/157.3:.3f} of fp32 MFMA peak) | '
+          f'128x128 x2 {t["wide2"]:8.1f} us ({fl/t["wide2"]/1e6/157.3:.3f}) | '
+          f'k_sgemm {t["k_sgemm"]:8.1f} us ({fl/t["k_sgemm"]/1e6/157.3:.3f}) | same bits: {same}', flush=True)
 
 
 if __name__ == '__main__':
