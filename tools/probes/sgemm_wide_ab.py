@@ -9,6 +9,9 @@ import torch
 from llmc_amd import _ffi
 
 
+COLD = None
+
+
 def run(tag, M, N, Kd, K=None, reps=7):
     L = _ffi.lib()
     K = K or N
@@ -30,6 +33,8 @@ def run(tag, M, N, Kd, K=None, reps=7):
             out[arm] = C.clone()
             ts = []
             for _ in range(reps):
+                if COLD is not None:
+                    COLD.add_(1.0)          # 1 GiB read + written: nothing of the operands left in L2 / MALL
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); go(); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)
@@ -42,6 +47,8 @@ def run(tag, M, N, Kd, K=None, reps=7):
 
 
 if __name__ == '__main__':
+    if '--cold' in sys.argv:
+        COLD = torch.zeros(1 << 28, device='cuda')
     if '--ld' in sys.argv:          # one round of tiles (4096 x 2048), the operands' row stride varied
         for K in (2048, 4096, 6144, 8192, 12288, 14336, 14336 + 64, 16384, 28672):
             run(f'ld sweep K={K}', 4096, 2048, 512, K)
