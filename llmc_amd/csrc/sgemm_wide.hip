@@ -40,8 +40,7 @@ template <int MB> struct Wide {
     static constexpr int AB = MB == 4 ? W_K * W_ROW : W_BB;      // 256 wide: one k-row per piece; 128 wide: as B
     static constexpr int SLOT = AB + W_BB;
     static constexpr int LDS = W_SLOTS * SLOT;                   // 110592 / 73728
-    static constexpr int SM = MB == 4 ? 4 : 8, SN = 8;           // an XCD's block of tiles
-    static constexpr int PER_XCD = SM * SN;
+    static constexpr int PER_XCD = MB == 4 ? 32 : 64;            // tiles an XCD runs at a time = one block of 2^sm x 2^sn tiles (host's choice)
     static constexpr int D = MB + 2;                             // DMA instructions per wave and stage
     static constexpr int NBLK = 2 * MB;                          // accumulator blocks per wave
 };
@@ -55,6 +54,7 @@ struct WideArgs {
     uint32_t bytesA, bytesB, bytesC;    // buffer extents from a tile's first element
     int nst;                            // Kd / 16
     int tm, tn, sbm, nsb;               // tiles along M, N; tile blocks along M; tile blocks
+    int sm_log, sn_log;                 // a tile block = 2^sm_log x 2^sn_log tiles
 };
 
 template <int I, int N, typename F> __device__ __forceinline__ void wfor(F&& f) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, MB == 4 ? 1 : 2) void k_sgemm_wide(const WideA
     const int g = (w / (8 * W::PER_XCD)) * 8 + (w & 7);
     if (g >= a.nsb) return;
     const int within = (w >> 3) % W::PER_XCD;
-    const int ti = (g % a.sbm) * W::SM + within / W::SN, tj = (g / a.sbm) * W::SN + within % W::SN;
+    const int ti = ((g % a.sbm) << a.sm_log) + (within >> a.sn_log), tj = ((g / a.sbm) << a.sn_log) + (within & ((1 << a.sn_log) - 1));
     if (ti >= a.tm || tj >= a.tn) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -254,8 +254,27 @@ template <int MB> static int wide_launch(const SgemmArgs& a, hipStream_t st) {
     w.bytesC = (uint32_t)(((int64_t)(W::BM - 1) * a.ldc + W_BN) * 4);
     w.nst = a.Kd / W_K;
     w.tm = a.M / W::BM; w.tn = a.N / W_BN;
-    w.sbm = (w.tm + W::SM - 1) / W::SM;
-    w.nsb = w.sbm * ((w.tn + W::SN - 1) / W::SN);
+    // The shape of an XCD's tile block: the one whose busiest XCD has the fewest tiles (block g goes to XCD g % 8; a ragged last
+    // block column or a block count that is not a multiple of 8 leaves XCDs idle in the last round — the column loop's far updates
+    // shrink by four tile columns per launch, most of them are a few rounds long), the squarest among equals (fewest panels in L2).
+    int best_cost = 1 << 30, best_sm = 0;
+    constexpr int LOGT = MB == 4 ? 5 : 6;
+    for (int sm = 1; sm < LOGT; ++sm) {
+        const int SM = 1 << sm, SN = 1 << (LOGT - sm);
+        const int sbm = (w.tm + SM - 1) / SM, sbn = (w.tn + SN - 1) / SN;
+        int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < sbm * sbn; ++g) {
+            const int bi = g % sbm, bj = g / sbm;
+            load[g & 7] += (w.tm - bi * SM < SM ? w.tm - bi * SM : SM) * (w.tn - bj * SN < SN ? w.tn - bj * SN : SN);
+        }
+        int mx = 0;
+        for (int x = 0; x < 8; ++x) mx = load[x] > mx ? load[x] : mx;
+        const int cost = mx * 64 + (SM + SN);
+        if (cost < best_cost) { best_cost = cost; best_sm = sm; }
+    }
+    w.sm_log = best_sm; w.sn_log = LOGT - best_sm;
+    w.sbm = (w.tm + (1 << w.sm_log) - 1) >> w.sm_log;
+    w.nsb = w.sbm * ((w.tn + (1 << w.sn_log) - 1) >> w.sn_log);
     const int rounds = (w.nsb + 7) / 8;
     if (int rc = ensure_dynamic_lds((const void*)k_sgemm_wide<MB>, W::LDS)) return rc;
     hipLaunchKernelGGL(k_sgemm_wide<MB>, dim3(rounds * 8 * W::PER_XCD), dim3(256), W::LDS, st, w);
