@@ -89,6 +89,7 @@ int llmc_hip_set_cu_reserve(int n_cus);
  *   k1_fp32_diag      diag(H) as the MFMA kernel's fp32 chain leaves it instead of the fp64-folded one (other diagonal)
  *   fp8_no_packed16   FP8 e4m3 cast of bf16 tensors (qtorch rounding, codes out): the float form of the division-free path; same bits
  *   gemm3s_no_dma     k_gemm3s (planes form): producer waves copy through registers instead of LDS-DMA; same bits
+ *   gemm3_no_wide     K3's far updates on k_gemm3s instead of k_gemm3w (128 x 128 tiles, two workgroups per CU); same bits
  *   sgemm_no_wide     K4's far update: 1 = on k_sgemm (the kernel of rounds 2-5), 4 = k_sgemm_wide's 256 x 128 form (one workgroup
  *                     per CU) instead of its 128 x 128 form (two per CU, the default); same bits
  * set: returns the previous value, or LLMC_EINVAL for an unknown key / negative value. get: the value, or LLMC_EINVAL.

@@ -14,7 +14,7 @@ static thread_local int g_opt[OPT_COUNT] = {};
 int opt(int id) { return (id >= 0 && id < OPT_COUNT) ? g_opt[id] : 0; }
 static const char* const g_opt_names[OPT_COUNT] = {
     "k3_fp32", "k3_no_gemm6", "k3_no_planes", "k3_split_far", "k4_split_far", "k4_err_rowmajor", "gptq_generic",
-    "gemm3_nospec", "gemm3s_min_tiles", "no_shortk", "linear_nosplit", "fp8_exact_div", "side_cu_mask", "k1_batch_off", "k1_fp32_diag", "fp8_no_packed16", "gemm3s_no_dma", "sgemm_no_wide"};
+    "gemm3_nospec", "gemm3s_min_tiles", "no_shortk", "linear_nosplit", "fp8_exact_div", "side_cu_mask", "k1_batch_off", "k1_fp32_diag", "fp8_no_packed16", "gemm3s_no_dma", "sgemm_no_wide", "gemm3_no_wide"};
 
 void set_last_error(const char* where, hipError_t e) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);

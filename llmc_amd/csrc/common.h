@@ -68,6 +68,7 @@ enum Opt : int {
     OPT_FP8_NO_PACKED16,    // FP8 cast: the float form of the division-free path instead of the packed 16-bit one
     OPT_GEMM3S_NO_DMA,      // k_gemm3s planes form: producers copy through registers + ds_write (round 5) instead of LDS-DMA
     OPT_SGEMM_NO_WIDE,      // K4's phased far update on k_sgemm (128 x 128 tiles, two workgroups per CU) instead of k_sgemm_wide
+    OPT_GEMM3_NO_WIDE,      // K3's far updates on k_gemm3s (one 512-thread workgroup per CU) instead of k_gemm3w (two 128 x 128 workgroups)
     OPT_COUNT
 };
 int opt(int id);

@@ -810,6 +810,7 @@ int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st) {
                      (((uintptr_t)a.B & 15) == 0) && (a.sA % 4 == 0) && (a.sB % 4 == 0),
                  "gemm3: operands must be 16-B aligned with ld and sizes multiples of 4");
     LLMC_REQUIRE((const void*)a.C != (const void*)a.B && (const void*)a.C != (const void*)a.A, "gemm3: no in-place product");
+    if (TA && gemm3s_eligible(a) && gemm3w_eligible(a)) return gemm3w_launch(a, st);
     if (TA && gemm3s_eligible(a)) {
         SgemmArgs b = a;
         b.planes_dma = opt(OPT_GEMM3S_NO_DMA) ? 0 : 1;

@@ -53,6 +53,9 @@ int sgemm_wide_launch(const SgemmArgs& a, hipStream_t st);
 int gemm3_tn_launch(const SgemmArgs& a, hipStream_t st);
 // general form: TA as in sgemm_launch, op(B) = N; hints a_upper / a_lower / b_upper / c_upper_only, all epilogues, batch
 int gemm3_launch(const SgemmArgs& a, bool TA, hipStream_t st);
+// the planes form on 128 x 128 tiles with two workgroups per CU (gemm3_wide.hip): SG_SUB, whole tiles, planes given
+bool gemm3w_eligible(const SgemmArgs& a);
+int gemm3w_launch(const SgemmArgs& a, hipStream_t st);
 // true when gemm3_launch(a, true, ..) would run the planes form for these arguments (a.planesA set): split only then
 bool gemm3_uses_planes(const SgemmArgs& a);
 // hi | mid | lo bf16 planes of a k-major fp32 panel [rows x n] (n % 8 == 0): planes + t * plane_stride + r * ldp + c

@@ -227,6 +227,41 @@ def test_gemm3_planes_form_is_bit_identical(shape, monkeypatch):
                 assert torch.equal(c_new, c_old), (epi, upper)
 
 
+@pytest.mark.parametrize('shape', [(512, 640, 512), (1024, 1024, 512), (2048, 2048, 256), (1536, 2560, 128), (128, 128, 128)])
+def test_gemm3w_two_workgroups_per_cu_is_bit_identical(shape):
+    """K3's far update on k_gemm3w (128 x 128 tiles, two workgroups per CU, LDS-DMA ring of three stages, fragments a stage ahead)
+    against k_gemm3s (option gemm3_no_wide) and k_gemm3 (gemm3_nospec): the same bits, full and upper-only."""
+    L = _ffi.lib()
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M * 3 + N + Kd)
+    A = (torch.randn(Kd, M, generator=gen) * torch.exp(torch.randn(Kd, 1, generator=gen))).cuda()
+    B = torch.randn(Kd, N, generator=gen).cuda()
+    Cbig = torch.randn(M, N + 64, generator=gen).cuda()          # C is a column range of a wider matrix
+    ldp = (max(M, N) + 7) // 8 * 8
+    ws = torch.full((6 * Kd * ldp,), -1, dtype=torch.int16).cuda()
+    _ffi.set_option('gemm3s_min_tiles', 1)
+    for upper in (0, 1) if M == N else (0,):
+        out = {}
+        for name, opts in (('w', {}), ('s', dict(gemm3_no_wide=1))):
+            with _ffi.option(**opts):
+                c = Cbig.clone()
+                _ffi.check(L.llmc_test_gemm3_planes(A.data_ptr(), B.data_ptr(), c[:, 64:].data_ptr(), A.stride(0), B.stride(0), c.stride(0),
+                                                    M, N, Kd, 0, upper, ws.data_ptr(), _ffi.stream()), 'gemm3 planes')
+                out[name] = c
+        with _ffi.option(gemm3_nospec=1):
+            ref = Cbig.clone()
+            gemm3(A, B, ref[:, 64:], M, N, Kd, True, 0, (0, 0, upper))
+        assert torch.equal(out['w'][:, :64], Cbig[:, :64])
+        if upper:
+            iu = torch.triu(torch.ones(M, N, dtype=torch.bool)).cuda()
+            for k in ('w', 's'):
+                assert torch.equal(out[k][:, 64:][iu], ref[:, 64:][iu]), (k, upper)
+            blk = (torch.arange(M)[:, None] // 128 > torch.arange(N)[None, :] // 128).cuda()
+            assert torch.equal(out['w'][:, 64:][blk], Cbig[:, 64:][blk])
+        else:
+            assert torch.equal(out['w'], ref) and torch.equal(out['s'], ref)
+
+
 def test_gemm3_triangular_hints_do_not_change_results():
     n = 384
     gen = torch.Generator().manual_seed(3)
