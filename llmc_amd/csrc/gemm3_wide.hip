@@ -85,8 +85,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm3w(const G3wArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0,
                                                  __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     };
+#if defined(G3W_DBG) && G3W_DBG == 1      // lab (tools/probes/g3w_lab.sh): every tile reads the panels of tile (0, 0) — wrong results, perfect L2 reuse
+    const auto dA = mk(a.PA, a.bytesP);
+    const auto dB = mk(a.PB, a.bytesP);
+#else
     const auto dA = mk(a.PA + (int64_t)ti * G_B, a.bytesP);
     const auto dB = mk(a.PB + (int64_t)tj * G_B, a.bytesP);
+#endif
     const auto dC = mk(a.C + (int64_t)ti * G_B * a.ldc + (int64_t)tj * G_B, a.bytesC);
     LDS_AS char* lds = (LDS_AS char*)smem_g;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
@@ -157,12 +162,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm3w(const G3wArgs a) {
     // fly); barrier: every wave has read stage j (under stage j - 1's MFMAs) and stage j + 1 is complete; stage j + 3 requested into
     // stage j's slot; then 24 MFMAs = six products x four accumulators in rotation, a fragment of stage j + 1 read behind each of the
     // first twelve (all of them back long before the next barrier: the slot they came from is refilled behind it).
+    // The old C values of block cb are requested under the MFMAs of stage cb (cb = 0..3: two loads behind each of MFMAs 12..19), so
+    // that the tile ends with a subtraction and stores only (lab builds, tools/probes/g3w_lab.sh: a load-subtract-store epilogue was
+    // 17 % of the kernel — one workgroup alone does not fill the pipe while its partner waits for C). Issue order D0 D1 D2 | D3 C0 |
+    // D4 C1 | D5 C2 | D6 C3 | D7 ..: the requests younger than D(j+1) when stage j waits for it are C(j-2) D(j+2) C(j-1).
+    const uint32_t voC = (uint32_t)(wm * 64 + 4 * (lane >> 5)) * a.rowC + (uint32_t)(wn * 64 + (lane & 31)) * 4u;
+    auto soC = [&](uint32_t rowC, int m, int n, int r) { return (uint32_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * rowC + (uint32_t)n * 128u; };
+    f32x16 oldc[2][2];
     uint32_t cur = 0;                                   // byte offset of stage j's slot
-    auto stage = [&](auto setc, int j) {
-        constexpr int S = decltype(setc)::value;
-        if (j + 2 < nst) g_vm_wait<6>(); else g_vm_wait<0>();
+    auto stage = [&](auto setc, auto cbc, auto youngc, int j) {
+        constexpr int S = decltype(setc)::value, CB = decltype(cbc)::value, YOUNG = decltype(youngc)::value;
+        if (j + 2 < nst) g_vm_wait<YOUNG>(); else g_vm_wait<0>();
         __builtin_amdgcn_s_barrier();
+#if !(defined(G3W_DBG) && G3W_DBG == 2)    // lab: no operand traffic after the prologue
         if (j + 3 < nst) issue(j + 3, cur);
+#endif
         const uint32_t nxt = cur + G_SLOT == G_LDS ? 0u : cur + G_SLOT;
         LDS_AS char* nb = lds + nxt;
         __builtin_amdgcn_sched_barrier(0);
@@ -172,33 +186,48 @@ __global__ __launch_bounds__(256, 2) void k_gemm3w(const G3wArgs a) {
             constexpr int TB = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : q == 3 ? 0 : q == 4 ? 1 : 0;
             acc[m][n] = Mfma<LLMC_BF16>::run(fa[S][m][TA], fb[S][n][TB], acc[m][n]);
             if constexpr (i < 12) rd(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, i>{}, nb);
+#if !(defined(G3W_DBG) && G3W_DBG == 3)    // lab: no C traffic
+            if constexpr (CB >= 0 && i >= 12 && i < 20) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    constexpr int r0 = 2 * (i - 12);
+                    oldc[CB >> 1][CB & 1][r0 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dC, voC, soC(a.rowC, CB >> 1, CB & 1, r0 + e), 0));
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         cur = nxt;
     };
-    for (int j = 0; j < nst; j += 2) {
-        stage(std::integral_constant<int, 0>{}, j);
-        stage(std::integral_constant<int, 1>{}, j + 1);
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    constexpr std::integral_constant<int, -1> NOC{};
+    stage(S0, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, 0);          // nst >= 8
+    stage(S1, std::integral_constant<int, 1>{}, std::integral_constant<int, 22>{}, 1);
+    stage(S0, std::integral_constant<int, 2>{}, std::integral_constant<int, 38>{}, 2);
+    stage(S1, std::integral_constant<int, 3>{}, std::integral_constant<int, 38>{}, 3);
+    stage(S0, NOC, std::integral_constant<int, 38>{}, 4);
+    stage(S1, NOC, std::integral_constant<int, 22>{}, 5);
+    for (int j = 6; j < nst; j += 2) {
+        stage(S0, NOC, std::integral_constant<int, 6>{}, j);
+        stage(S1, NOC, std::integral_constant<int, 6>{}, j + 1);
     }
 
-    // ---- C -= acc, block by block; of a diagonal tile only the blocks that reach the diagonal (k_gemm3s's row limit)
-    const uint32_t voC = (uint32_t)(wm * 64 + 4 * (lane >> 5)) * a.rowC + (uint32_t)(wn * 64 + (lane & 31)) * 4u;
+    // ---- C = old - acc, block by block; of a diagonal tile only the blocks that reach the diagonal (k_gemm3s's row limit)
+    uint32_t rowC2 = a.rowC;      // opaque copy: the row offsets are recomputed here, not kept in SGPRs from the first stages on
+    asm volatile("" : "+s"(rowC2));
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             if (a.upper && ti == tj && 2 * wn + n < 2 * wm + m) continue;
-            float old[16];
+#if defined(G3W_DBG) && G3W_DBG == 3
+            if (acc[m][n][0] != 12345.678f) continue;
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t so = (uint32_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * a.rowC + (uint32_t)n * 128u;
-                old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dC, voC, so, 0));
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t so = (uint32_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * a.rowC + (uint32_t)n * 128u;
-                const float v = old[r] - acc[m][n][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dC, voC, so, 0);
+                const float v = oldc[m][n][r] - acc[m][n][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dC, voC, soC(rowC2, m, n, r), 0);
             }
         }
 }
@@ -209,7 +238,7 @@ bool gemm3w_eligible(const SgemmArgs& a) {
     if (opt(OPT_GEMM3_NO_WIDE) || opt(OPT_GEMM3_NOSPEC)) return false;
     if (!a.planesA || !a.planesB || a.batch != 1 || a.epilogue != SG_SUB || a.phase_len != 0) return false;
     if (a.a_upper || a.a_lower || a.b_upper) return false;
-    if (a.M <= 0 || a.N <= 0 || a.M % G_B || a.N % G_B || a.Kd % (2 * G_K) || a.Kd < 4 * G_K) return false;
+    if (a.M <= 0 || a.N <= 0 || a.M % G_B || a.N % G_B || a.Kd % (2 * G_K) || a.Kd < 8 * G_K) return false;
     if (a.ldp % 8 || a.plane_stride % 8 || (((uintptr_t)a.planesA | (uintptr_t)a.planesB) & 15) || ((uintptr_t)a.C & 3)) return false;
     if ((2 * a.plane_stride + ((int64_t)a.Kd + G_K) * a.ldp) * 2 >= (int64_t)0x7fffff00) return false;
     if ((int64_t)G_B * a.ldc * 4 >= (int64_t)0x7fffff00) return false;
