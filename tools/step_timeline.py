@@ -18,7 +18,7 @@ from collections import defaultdict
 
 
 def short(n):
-    n = re.sub(r'\(.*', '', n).replace('void ', '').replace('llmc::', '')
+    n = re.sub(r'\(.*', '', n.replace('(anonymous namespace)::', '')).replace('void ', '').replace('llmc::', '')
     return n[:44]
 
 
