@@ -29,7 +29,7 @@ def one(src):
             return m.group(1) if m else '?'
         name = f('name')
         dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
-        rows.append((re.sub(r'\(.*', '', dem or name)[:64], f('vgpr_count'), f('vgpr_spill_count'), f('sgpr_spill_count'),
+        rows.append((re.sub(r'\(.*', '', (dem or name).replace('(anonymous namespace)::', ''))[:64], f('vgpr_count'), f('vgpr_spill_count'), f('sgpr_spill_count'),
                      f('private_segment_fixed_size'), f('group_segment_fixed_size')))
     return src, rows, ''
 
