@@ -557,6 +557,43 @@ def test_chol_inv_upper_far_updates_on_planes_keep_every_bit(K, monkeypatch):
     assert torch.equal(u_single, u_planes) and torch.equal(u_helper, u_planes)
 
 
+@pytest.mark.parametrize('R,K', [(1024, 2304), (384, 1536)])
+def test_column_loop_same_bits_on_every_far_update_kernel(R, K):
+    """The whole column loop (gptq.py:199-244) with its far updates on k_sgemm_wide's two forms and on k_sgemm: quantized weights,
+    losses, scales and zeros identical to the last bit (R = 384: rows that are no multiple of 256 — the 128 x 128 form or k_sgemm)."""
+    from llmc_amd.compression.quantization import gptq_ops
+    gen = torch.Generator().manual_seed(R + K)
+    X = torch.randn(2 * K, K, generator=gen)
+    H = ((X.T @ X) / K).cuda()
+    H += 0.01 * H.diag().mean() * torch.eye(K, device='cuda')
+    U = gptq_ops.chol_inv_upper(H, check=False)
+    W = (torch.randn(R, K, generator=gen) * 0.02).cuda()
+    res = {}
+    for name, opts in (('default', {}), ('wide4', dict(sgemm_no_wide=4)), ('k_sgemm', dict(sgemm_no_wide=1))):
+        with _ffi.option(**opts), _ffi.helper_streams(False):
+            res[name] = gptq_ops.gptq_quantize(W.clone(), U, False, 0.0, 15.0, 128)
+    for name in ('wide4', 'k_sgemm'):
+        for a, b in zip(res['default'], res[name]):
+            assert (a is None and b is None) or torch.equal(a, b), name
+
+
+def test_factor_same_bits_with_far_updates_on_gemm3w():
+    """K3 (gptq.py:169-176) with every eligible far update on k_gemm3w (threshold lowered so that the K = 4096 factorisation reaches it)
+    against k_gemm3s: the same upper factor of the inverse, bit for bit."""
+    from llmc_amd.compression.quantization.gptq_ops import chol_inv_upper
+    K = 4096
+    gen = torch.Generator().manual_seed(7)
+    X = torch.randn(2 * K, K, generator=gen)
+    X[:, ::7] *= 3
+    H = ((X.T @ X) / K).cuda()
+    H += 0.01 * H.diag().mean() * torch.eye(K, device='cuda')
+    with _ffi.option(gemm3s_min_tiles=1), _ffi.helper_streams(False):
+        u_w = chol_inv_upper(H.clone())
+        with _ffi.option(gemm3_no_wide=1):
+            u_s = chol_inv_upper(H.clone())
+    assert torch.equal(u_w, u_s)
+
+
 def test_hessian_prep_vs_oracle():
     from llmc_amd.compression.quantization.gptq_ops import hessian_prep
     g = load_golden('gptq')
