@@ -93,8 +93,8 @@ def parse_args(argv=None):
     ap.add_argument('--mode', default=None, choices=['independent', 'handoff', 'cooperative'])
     ap.add_argument('--exact-diag', type=int, default=1, help='0: keep the MFMA kernel\'s fp32 diagonal of H (A/B; rounds 1-5\'s default)')
     ap.add_argument('--merge-k1', type=int, default=1, help='0: one Hessian launch per input instead of one per width')
-    ap.add_argument('--overlap', type=int, default=4,
-                    help='streams for the subsets\' factorisations / column loops (independent latency-bound chains); 0 = serial')
+    ap.add_argument('--overlap', type=int, default=3,
+                    help='streams for the subsets\' chains, widest first, the last takes the rest (3 beats 2 and 4); 0 = serial')
     ap.add_argument('--dry', action='store_true', help='GPU-less plumbing check (gloo + CPU stand-ins)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary workloads reported under "extra" (N = 1 only)')
@@ -464,8 +464,8 @@ def main():
 
         def step_independent(record):
             """K1 first — the MFMA kernel owns every CU, nothing overlaps with it: the Hessians of one width in one launch — then
-            the four subsets' factorisations and column loops, independent latency-bound chains, on one stream each, widest
-            first, the library's internal helper streams off (measured schedules: profiles/NOTES.md, r05_schedule_experiments.txt)."""
+            the subsets' factorisations and column loops, independent chains, on --overlap streams, widest first, the internal
+            helper streams off (measured schedules: profiles/NOTES.md, r05_schedule_experiments.txt, r06_stream_map.txt)."""
             ops.timing = timing if record else None
             Hs = ops.hessians([(name, K, acts[name]) for name, K, _ in groups], args.calib_bs, merge=args.merge_k1)
             if args.overlap <= 1 or args.dry:
@@ -475,7 +475,7 @@ def main():
             slot, used = {}, []
             for si, gi in enumerate(order):
                 name = groups[gi][0]
-                st = ops.stream(si % args.overlap)
+                st = ops.stream(min(si, args.overlap - 1))
                 st.wait_stream(cur)
                 with torch.cuda.stream(st), ops.helper_streams(False):
                     slot[gi] = ops.quantize(name, weights[name], Hs[name])
